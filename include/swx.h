@@ -1,0 +1,161 @@
+/* swx.h -- C ABI of libswx.so: the MI355X (gfx950) hot path of stable-ts.
+ *
+ * The reference (jianfch/stable-ts) has NO C ABI / FFI: its hot path is Python that calls the
+ * un-vendored dependency openai-whisper (stable_whisper/whisper_compatibility.py:58-76).  The entry
+ * points below are the native replacements for exactly the callables the reference's glue consumes
+ * at that seam (seam B5); each one cites the reference call site it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer (HBM); h_* is a host pointer
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream)
+ *   - return value: 0 = ok, negative = error (swx_strerror); no call blocks the host unless it says so
+ *   - no hidden device allocation: the caller binds the weight arena and the workspace
+ *   - compute dtype: SWX_F16 (fp16 storage + MFMA, fp32 accumulate/LN/softmax -- what the reference runs on
+ *     a GPU, original_whisper.py:251-260) or SWX_F32 (exact-f32 MFMA; the strict parity mode that matches the
+ *     reference's CPU path, which is always fp32)
+ */
+#ifndef SWX_H
+#define SWX_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWX_F32 0
+#define SWX_F16 1
+
+#define SWX_N_SAMPLES 480000   /* whisper_compatibility.py:86  */
+#define SWX_N_FRAMES 3000      /* whisper_compatibility.py:87  */
+#define SWX_N_FFT 400
+#define SWX_HOP 160
+
+typedef struct swx_dims {      /* == whisper.model.ModelDimensions (read via model.dims.*, e.g. alignment.py:181) */
+    int32_t n_mels, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_vocab, n_text_ctx, n_text_state, n_text_head, n_text_layer;
+} swx_dims;
+
+typedef struct swx_model swx_model;   /* opaque */
+
+const char *swx_strerror(int code);
+int swx_version(void);
+
+/* ---- model lifetime + weights (replaces whisper.load_model + model.to(device), original_whisper.py:995-1002) */
+int swx_model_create(const swx_dims *dims, int dtype, swx_model **out);
+void swx_model_destroy(swx_model *m);
+/* size of the packed weight arena for this model/dtype */
+size_t swx_weights_bytes(const swx_model *m);
+int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes);
+/* copy one checkpoint tensor (upstream state_dict key, fp32, device memory) into its packed slot,
+ * converting/re-laying it out (QKV fusion, conv tap-major layout, fp16 cast) on the device */
+int swx_load_tensor(swx_model *m, const char *name, const float *d_src, int64_t numel, void *stream);
+/* 1 if every slot has been loaded; swx_missing_tensor writes the index-th missing name into buf (returns 0 at the end) */
+int swx_weights_complete(const swx_model *m);
+int swx_missing_tensor(const swx_model *m, int index, char *buf, int buflen);
+/* alignment heads (timing.py:105 reads model.alignment_heads.indices()): pairs (layer, head) */
+int swx_set_alignment_heads(swx_model *m, const int32_t *h_layer_head_pairs, int n_pairs);
+int swx_num_alignment_heads(const swx_model *m);
+
+/* ---- workspace: max_windows = windows processed together by encode/score, max_rows = decoder sequences */
+size_t swx_workspace_bytes(const swx_model *m, int max_windows, int max_rows);
+int swx_bind_workspace(swx_model *m, void *d_ws, size_t bytes, int max_windows, int max_rows);
+
+/* ---- a1: log-mel (replaces whisper.audio.log_mel_spectrogram at original_whisper.py:528-530, alignment.py:410-413)
+ * d_pcm:  f32 [B][480000]  (caller zero-pads each <=30 s segment to exactly 480000 samples, as the reference does)
+ * d_mel:  f32 [B][n_mels][3000]; the clamp floor uses the max over the WHOLE batch when per_item_max==0
+ *         (upstream quirk inherited by refine) and per window when per_item_max!=0 */
+int swx_log_mel(swx_model *m, const float *d_pcm, int B, float *d_mel, int per_item_max, void *stream);
+
+/* ---- a2: encoder (replaces model.encoder(mel), decode.py:27-30, timing.py:59-60)
+ * d_mel f32 [B][n_mels][3000] -> d_xa [B][1500][d] in the compute dtype */
+int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream);
+
+/* ---- cross-attention K/V of every decoder layer for B windows (upstream recomputes them lazily through the
+ * kv-cache hooks; here they are produced once per window and shared by decode + scoring)
+ * d_xkv: compute dtype [L][B*1500][2*d]  (K | V) */
+size_t swx_cross_kv_bytes(const swx_model *m, int B);
+int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *stream);
+
+/* ---- a3/a4: decoding (replaces DecodingTaskStable._main_loop, decode.py:33-65, and the upstream logit filters +
+ * GreedyDecoder / BeamSearchDecoder it drives).  One decode job = W windows x G sequences per window
+ * (G = beam_size or best_of or 1), all advanced in lockstep on the device, no per-step host sync. */
+typedef struct swx_decode_cfg {
+    int32_t n_windows;            /* W */
+    int32_t n_group;              /* G */
+    int32_t beam;                 /* 0 = greedy/sampling (GreedyDecoder), 1 = beam search (BeamSearchDecoder) */
+    float temperature;            /* 0 = argmax */
+    float patience;               /* beam: max_candidates = round(G * patience); <=0 -> 1.0 */
+    int32_t sample_len;           /* max sampled tokens (n_text_ctx/2 = 224 by default) */
+    int32_t sample_begin;         /* len(initial_tokens) (same for every window of a job) */
+    int32_t sot_index;            /* index of <|startoftranscript|> in the initial tokens */
+    int32_t suppress_blank;       /* SuppressBlank */
+    int32_t apply_timestamp_rules;/* ApplyTimestampRules (0 when without_timestamps) */
+    int32_t max_initial_timestamp_index; /* -1 = None (stable-ts forces None, original_whisper.py:262-263) */
+    int32_t eot, sot, no_timestamps, timestamp_begin, no_speech, blank_token; /* tokenizer ids (blank = encode(" ")[0]) */
+    int32_t n_suppress;           /* SuppressTokens list length */
+    int32_t min_tokens;           /* >0: EOT is suppressed until this many tokens were sampled (synthetic-weights
+                                     benchmarking only; 0 = reference behaviour) */
+    uint64_t seed;                /* sampling RNG seed (temperature > 0) */
+} swx_decode_cfg;
+
+/* runs the whole loop; outputs (device):
+ *  d_tokens_out  int32 [W][G_out][n_ctx+1]   final sequences incl. the initial tokens, eot-padded
+ *  d_lens_out    int32 [W][G_out]            length up to (excluding) the first eot after sample_begin
+ *  d_sumlp_out   f32   [W][G_out]            sum_logprobs of each candidate
+ *  d_nospeech    f32   [W]                   softmax(logits[sot_index])[no_speech] at step 0 (decode.py:42-44)
+ *  G_out = G (greedy/best-of) or max(G, max_candidates) (beam)
+ * inputs: d_init_tokens int32 [W][sample_begin]; d_suppress int32 [n_suppress];
+ *         d_ts_mask uint8 [W][1501] or NULL (decode.py:14-16,54); d_xkv from swx_cross_kv for these W windows.
+ * Returns the number of steps executed (>=0) or a negative error.  Blocks until the loop has finished. */
+int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_tokens, const int32_t *d_suppress,
+               const uint8_t *d_ts_mask, const void *d_xkv, int32_t *d_tokens_out, int32_t *d_lens_out,
+               float *d_sumlp_out, float *d_nospeech, void *stream);
+int swx_decode_gout(const swx_decode_cfg *cfg);
+
+/* ---- a6+a7: teacher-forced scoring pass + alignment matrix (replaces timing.py:41-67 _compute_qks and
+ * timing.py:70-112 _compute_atten_weights + the head-mean/negation of timing.py:194-195)
+ * For each window w: tokens d_tokens[w][0..n_tok[w]) = [*sot_sequence, no_timestamps, *text_tokens, eot].
+ *  d_token_probs  f32 [W][max_n]      softmax(logits[n_sot-1+i? see DESIGN.md][:eot])[text_token_i], T values per window
+ *  d_neg_matrix   f32 [W][max_n][1500] rows 0..T (T+1 rows), cols 0..n_frames[w): -(mean over alignment heads of
+ *                 median7(znorm_tokens(softmax_frames(qk * qk_scale)))) -- the DTW input
+ *  n_sot = len(sot_sequence); T[w] = n_tok[w] - n_sot - 2 */
+int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot, int eot,
+              const int32_t *h_n_frames, float qk_scale, int medfilt_width, const void *d_xkv,
+              float *d_token_probs, float *d_neg_matrix, void *stream);
+
+/* full-sequence logits of a teacher-forced pass (model(mel, tokens) as used by refine/locate; also a test hook):
+ * d_logits f32 [W][max_n][n_vocab].  Language detection (model.detect_language, original_whisper.py:329) is this call
+ * with tokens = [[sot]]. */
+int swx_forward_logits(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n,
+                       const void *d_xkv, float *d_logits, void *stream);
+
+/* ---- a7 stand-alone (test hook + extra_models path): weights f32 [W][H][N][ld_f] raw qk ->
+ * neg_matrix f32 [W][N][1500] */
+int swx_align_weights(const float *d_qk, int W, int H, int N, int ld_f, const int32_t *h_n_frames, float qk_scale,
+                      int medfilt_width, float *d_neg_matrix, void *stream);
+
+/* ---- whisper.timing.median_filter (timing.py:110,138): f32 [rows][n] -> [rows][n], reflect padding */
+int swx_median_filter(const float *d_x, int64_t rows, int n, int width, float *d_out, void *stream);
+
+/* ---- a8: DTW + backtrace (replaces whisper.timing.dtw at timing.py:195; CPU tie-break)
+ * d_x f32 [W][ld_n][ld_m] (row-major; window w uses rows 0..N[w), cols 0..M[w));
+ * outputs int32 [W][ld_n+ld_m] text/time indices in forward order and int32 [W] path lengths.
+ * d_trace_ws: uint8 scratch of swx_dtw_workspace_bytes(W, ld_n, ld_m) */
+size_t swx_dtw_workspace_bytes(int W, int ld_n, int ld_m);
+int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_t *d_N, const int32_t *d_M,
+            int32_t *d_text_idx, int32_t *d_time_idx, int32_t *d_len, void *d_trace_ws, void *stream);
+
+/* ---- building blocks exported for the parity tests (same kernels the calls above launch) */
+int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
+                  void *d_c, int64_t ldc, int M, int N, int K, int epilogue, int force_kernel, void *stream);
+int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float *d_b, void *d_y, int rows, int d,
+                       void *stream);
+int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k, const void *d_v, int64_t ldkv,
+                       void *d_o, int64_t ldo, int B, int H, int nq, int nk, int force_kernel, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWX_H */

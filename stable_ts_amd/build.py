@@ -1,0 +1,55 @@
+"""Build libswx.so (hipcc, gfx950) in-tree.  `python -m stable_ts_amd.build`"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libswx.so")
+SOURCES = ["swx_runtime.hip", "swx_gemm.hip", "swx_norm.hip", "swx_attn.hip", "swx_decode.hip", "swx_align.hip",
+           "swx_mel.hip", "swx_dtw.hip"]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \
+        [os.path.join(os.path.dirname(HERE), "include", "swx.h")]
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest(deps):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + ".o")
+        objs.append(o)
+        if not force and os.path.exists(o) and os.path.getmtime(o) >= _newest([s] + deps[len(srcs):]):
+            continue
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-c", s, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- {s}\n{out.decode()}\n")
+        elif verbose and out.strip():
+            print(out.decode())
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,364 @@
+// swx_attn.hip -- attention kernels (d_head = 64 for every Whisper size).
+//
+// Upstream: whisper/model.py::MultiHeadAttention.qkv_attention (q,k each scaled by d_head^-0.25, fp32 softmax),
+// reached from stable_whisper/decode.py:40 (decoder steps), decode.py:27-30 (encoder) and timing.py:58-61 (the
+// teacher-forced pass whose cross-attention qk the word-timestamp code reads).
+//
+//   attn_flash_f16      MFMA flash attention, non-causal, for the MFMA-bound cases (encoder self-attention,
+//                       1500x1500 per head; cross-attention of the scoring pass).  One wave = 16 queries,
+//                       K tile [64 keys][64] and V^T tile [64][64 keys] staged in LDS per 4-wave workgroup.
+//                       S^T = K.Q^T is computed "swapped" so a lane's accumulator registers all belong to ONE query:
+//                       the online-softmax row statistics are lane-local + two shuffles, and the exponentiated tile is
+//                       already laid out as the B operand of O^T += V^T.P^T (no LDS round trip for P).
+//   attn_dense_rowwise  VALU kernel (any dtype): 8 queries that share one K/V (same window, same head) per workgroup;
+//                       K and V are streamed once per workgroup.  Used for the HBM-bound decode-step cross-attention
+//                       (the G beams of a window share the 246 MB/window cross-KV read) and for everything in the
+//                       strict f32 mode.
+//   self_attn_cached    decoder self-attention over the KV cache; beams address the cache through an ancestor table
+//                       (position -> physical row) so that a beam reorder never copies K/V.
+//   qk_capture          raw scaled q.k of the alignment heads only (what timing.py:50-56 hooks out of every layer).
+#include "swx_common.h"
+#include "swx_kernels.h"
+
+namespace {
+
+constexpr int DH = 64;
+
+// ================================================================================================ flash f16
+constexpr int FL_KT = 64;            // keys per tile
+constexpr int FL_LD = 72;            // halfs per LDS row (144 B: keeps b128 / b64 fragment reads aligned)
+
+__global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f16 Ks[FL_KT][FL_LD];   // [key][d]
+    __shared__ __attribute__((aligned(16))) f16 Vt[DH][FL_LD];      // [d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int qn = lane & 15, g = lane >> 4;
+    const f16 *Q = (const f16 *)a.q;
+    const f16 *K = (const f16 *)a.k;
+    const f16 *V = (const f16 *)a.v;
+
+    f16x8 qf[2];
+    {
+        const int qi = q0 + qn;
+        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qi < a.nq ? qi : 0)) * a.ldq + h * DH + g * 8;
+        qf[0] = (qi < a.nq) ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
+        qf[1] = (qi < a.nq) ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -__builtin_inff(), l_run = 0.f;
+
+    for (int kt0 = 0; kt0 < a.nk; kt0 += FL_KT) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, key = c >> 3, dc = (c & 7) * 8;
+            const int kg = kt0 + key;
+            f16x8 kv = (f16x8)(f16)0, vv = (f16x8)(f16)0;
+            if (kg < a.nk) {
+                const size_t off = ((size_t)b * a.nk + kg) * a.ldkv + h * DH + dc;
+                kv = *(const f16x8 *)(K + off);
+                vv = *(const f16x8 *)(V + off);
+            }
+            *(f16x8 *)&Ks[key][dc] = kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) Vt[dc + e][key] = vv[e];
+        }
+        __syncthreads();
+
+        // S^T tiles: s[t][r] = score(key = kt0 + t*16 + g*4 + r, query = q0 + qn)
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const f16x8 kf = *(const f16x8 *)&Ks[t * 16 + qn][kk * 32 + g * 8];
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+        }
+        float tmax = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt0 + t * 16 + g * 4 + r;
+                const float v = (key < a.nk) ? s[t][r] * 0.125f : -__builtin_inff();
+                s[t][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);      // m_run = -inf on the first tile -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[t][r] - m_new);
+                s[t][r] = p;
+                psum += p;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { o[t][0] *= alpha; o[t][1] *= alpha; o[t][2] *= alpha; o[t][3] *= alpha; }
+
+        // O^T += V^T . P^T ; k-slot (g, j) of k-block c <-> key 32c + (j<4 ? g*4+j : 16 + g*4 + j-4)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f16x8 pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { pb[r] = (f16)s[2 * c][r]; pb[4 + r] = (f16)s[2 * c + 1][r]; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f16x4 lo = *(const f16x4 *)&Vt[t * 16 + qn][32 * c + g * 4];
+                const f16x4 hi = *(const f16x4 *)&Vt[t * 16 + qn][32 * c + 16 + g * 4];
+                f16x8 va;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = lo[e]; va[4 + e] = hi[e]; }
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, o[t], 0, 0, 0);
+            }
+        }
+    }
+
+    const int qi = q0 + qn;
+    if (qi < a.nq) {
+        const float inv = 1.0f / l_run;
+        f16 *op = (f16 *)a.o + ((size_t)b * a.q_rows_per_batch + qi) * a.ldo + h * DH;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f16x4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[t][r] * inv);
+            *(f16x4 *)(op + t * 16 + g * 4) = ov;
+        }
+    }
+}
+
+// ============================================================================================ dense rowwise
+constexpr int RW_QB = 8;
+constexpr int RW_MAXK = 1536;
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dense_rowwise(AttnArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *qs = smem;                       // [RW_QB][64]
+    float *sc = smem + RW_QB * DH;          // [RW_QB][nk_pad]
+    const int nkp = (a.nk + 3) & ~3;
+    float *part = sc + RW_QB * nkp;         // [4][RW_QB][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RW_QB;
+    const int nqb = min(RW_QB, a.nq - q0);
+    const T *Q = (const T *)a.q;
+    const T *K = (const T *)a.k + (size_t)b * a.nk * a.ldkv + h * DH;
+    const T *V = (const T *)a.v + (size_t)b * a.nk * a.ldkv + h * DH;
+
+    for (int i = tid; i < RW_QB * DH; i += 256) {
+        const int qi = i >> 6, d = i & 63;
+        qs[i] = (qi < nqb) ? to_f32<T>(Q[((size_t)b * a.q_rows_per_batch + q0 + qi) * a.ldq + h * DH + d]) : 0.f;
+    }
+    __syncthreads();
+
+    // scores
+    for (int j = tid; j < a.nk; j += 256) {
+        const T *kr = K + (size_t)j * a.ldkv;
+        float acc[RW_QB];
+#pragma unroll
+        for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = 0.f;
+#pragma unroll 2
+        for (int d0 = 0; d0 < DH; d0 += 8) {
+            float kv[8];
+            load8<T>(kr + d0, kv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = fmaf(qs[qi * DH + d0 + e], kv[e], acc[qi]);
+        }
+#pragma unroll
+        for (int qi = 0; qi < RW_QB; ++qi) sc[qi * nkp + j] = acc[qi] * 0.125f;
+    }
+    __syncthreads();
+
+    // softmax: wave handles queries wave, wave+4
+    for (int qi = wave; qi < nqb; qi += 4) {
+        float *row = sc + qi * nkp;
+        float mx = -__builtin_inff();
+        for (int j = lane; j < a.nk; j += 64) mx = fmaxf(mx, row[j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < a.nk; j += 64) { const float e = expf(row[j] - mx); row[j] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        for (int j = lane; j < a.nk; j += 64) row[j] *= inv;
+    }
+    __syncthreads();
+
+    // out = P V : thread (slice = wave, d = lane)
+    float acc[RW_QB];
+#pragma unroll
+    for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = 0.f;
+    for (int j = wave; j < a.nk; j += 4) {
+        const float vv = to_f32<T>(V[(size_t)j * a.ldkv + lane]);
+#pragma unroll
+        for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = fmaf(sc[qi * nkp + j], vv, acc[qi]);
+    }
+#pragma unroll
+    for (int qi = 0; qi < RW_QB; ++qi) part[(wave * RW_QB + qi) * DH + lane] = acc[qi];
+    __syncthreads();
+    for (int i = tid; i < nqb * DH; i += 256) {
+        const int qi = i >> 6, d = i & 63;
+        const float v = part[(0 * RW_QB + qi) * DH + d] + part[(1 * RW_QB + qi) * DH + d] +
+                        part[(2 * RW_QB + qi) * DH + d] + part[(3 * RW_QB + qi) * DH + d];
+        ((T *)a.o)[((size_t)b * a.q_rows_per_batch + q0 + qi) * a.ldo + h * DH + d] = from_f32<T>(v);
+    }
+}
+
+// ========================================================================================== cached self-attn
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(SelfAttnArgs a, int row_mul)
+{
+    // grid (n_new, R): copy k,v of token i of row r into the cache at position pos0[r] + i
+    const int i = blockIdx.x, ri = blockIdx.y;
+    const int r = ri * row_mul;
+    const int pos = a.pos0[r] + i;
+    const T *src = (const T *)a.qkv + ((size_t)ri * a.n_new + i) * a.ldqkv;
+    T *kc = (T *)a.kcache + ((size_t)r * a.n_ctx + pos) * a.d;
+    T *vc = (T *)a.vcache + ((size_t)r * a.n_ctx + pos) * a.d;
+    for (int c = threadIdx.x; c < a.d; c += 256) { kc[c] = src[a.d + c]; vc[c] = src[2 * a.d + c]; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_mul)
+{
+    // grid (n_new, H, R): one wave per (row, new token, head); causal over positions [0, pos0 + i]
+    __shared__ float qs[DH];
+    __shared__ float ps[512];
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x, h = blockIdx.y, ri = blockIdx.z;
+    const int r = ri * row_mul;
+    const int pos = a.pos0[r] + i;
+    const T *qp = (const T *)a.qkv + ((size_t)ri * a.n_new + i) * a.ldqkv + h * DH;
+    qs[lane] = to_f32<T>(qp[lane]);
+    __syncthreads();
+    const int32_t *anc = a.anc ? a.anc + (size_t)r * a.n_ctx : nullptr;
+    float mx = -__builtin_inff();
+    for (int j = lane; j <= pos; j += 64) {
+        const int pr = anc ? anc[j] : r;
+        const T *kr = (const T *)a.kcache + ((size_t)pr * a.n_ctx + j) * a.d + h * DH;
+        float acc = 0.f;
+#pragma unroll 2
+        for (int d0 = 0; d0 < DH; d0 += 8) {
+            float kv[8];
+            load8<T>(kr + d0, kv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[d0 + e], kv[e], acc);
+        }
+        acc *= 0.125f;
+        ps[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j <= pos; j += 64) { const float e = expf(ps[j] - mx); ps[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    float acc = 0.f;
+    for (int j = 0; j <= pos; ++j) {
+        const int pr = anc ? anc[j] : r;
+        const T *vr = (const T *)a.vcache + ((size_t)pr * a.n_ctx + j) * a.d + h * DH;
+        acc = fmaf(ps[j] * inv, to_f32<T>(vr[lane]), acc);
+    }
+    ((T *)a.o)[((size_t)ri * a.n_new + i) * a.ldo + h * DH + lane] = from_f32<T>(acc);
+}
+
+// =============================================================================================== qk capture
+template <typename T>
+__global__ __launch_bounds__(256) void qk_capture_kernel(const T *__restrict__ q, int64_t ldq, int q_rows_per_w, int row0,
+                                                         const T *__restrict__ k, int64_t ldk, int nk,
+                                                         const int32_t *__restrict__ heads, int head_slot0, int slots_total,
+                                                         float *__restrict__ out, int out_ld_n, int out_ld_f)
+{
+    // grid (n_rows, n_heads, W)
+    __shared__ float qs[DH];
+    const int i = blockIdx.x, hs = blockIdx.y, w = blockIdx.z;
+    const int head = heads[hs];
+    const T *qp = q + ((size_t)w * q_rows_per_w + row0 + i) * ldq + head * DH;
+    if (threadIdx.x < DH) qs[threadIdx.x] = to_f32<T>(qp[threadIdx.x]);
+    __syncthreads();
+    float *orow = out + (((size_t)w * slots_total + head_slot0 + hs) * out_ld_n + i) * out_ld_f;
+    for (int f = threadIdx.x; f < nk; f += 256) {
+        const T *kr = k + ((size_t)w * nk + f) * ldk + head * DH;
+        float acc = 0.f;
+#pragma unroll 2
+        for (int d0 = 0; d0 < DH; d0 += 8) {
+            float kv[8];
+            load8<T>(kr + d0, kv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[d0 + e], kv[e], acc);
+        }
+        orow[f] = acc * 0.125f;
+    }
+}
+
+}  // namespace
+
+int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
+{
+    if (a.B <= 0 || a.nq <= 0 || a.nk <= 0) return 0;
+    if (a.nk > RW_MAXK) return -5;
+    const bool flash = (dtype == SWX_F16) && (force_kernel == 2 || (force_kernel == 0 && a.nq >= 32));
+    if (flash) {
+        if (dtype != SWX_F16) return -5;
+        dim3 g(cdiv(a.nq, 64), a.H, a.B);
+        hipLaunchKernelGGL(attn_flash_f16, g, dim3(256), 0, s, a);
+    } else {
+        dim3 g(cdiv(a.nq, RW_QB), a.H, a.B);
+        const int nkp = (a.nk + 3) & ~3;
+        const size_t smem = sizeof(float) * ((size_t)RW_QB * DH + (size_t)RW_QB * nkp + (size_t)4 * RW_QB * DH);
+        if (dtype == SWX_F16) hipLaunchKernelGGL(attn_dense_rowwise<f16>, g, dim3(256), smem, s, a);
+        else hipLaunchKernelGGL(attn_dense_rowwise<float>, g, dim3(256), smem, s, a);
+    }
+    SWX_CHECK_LAUNCH();
+    return 0;
+}
+
+int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s)
+{
+    if (a.R <= 0 || a.n_new <= 0) return 0;
+    if (a.n_ctx > 512) return -5;
+    dim3 g1(a.n_new, a.R);
+    dim3 g2(a.n_new, a.H, a.R);
+    if (dtype == SWX_F16) {
+        hipLaunchKernelGGL(kv_append_kernel<f16>, g1, dim3(256), 0, s, a, row_mul);
+        hipLaunchKernelGGL(self_attn_cached<f16>, g2, dim3(64), 0, s, a, row_mul);
+    } else {
+        hipLaunchKernelGGL(kv_append_kernel<float>, g1, dim3(256), 0, s, a, row_mul);
+        hipLaunchKernelGGL(self_attn_cached<float>, g2, dim3(64), 0, s, a, row_mul);
+    }
+    SWX_CHECK_LAUNCH();
+    return 0;
+}
+
+int swx_qk_capture(int dtype, const void *q, int64_t ldq, int q_rows_per_w, int row0, int n_rows, const void *k,
+                   int64_t ldk, int nk, const int32_t *heads, int n_heads, int head_slot0, int slots_total, int W,
+                   float *out, int out_ld_n, int out_ld_f, hipStream_t s)
+{
+    if (n_rows <= 0 || n_heads <= 0 || W <= 0) return 0;
+    dim3 g(n_rows, n_heads, W);
+    if (dtype == SWX_F16)
+        hipLaunchKernelGGL(qk_capture_kernel<f16>, g, dim3(256), 0, s, (const f16 *)q, ldq, q_rows_per_w, row0, (const f16 *)k, ldk, nk, heads, head_slot0, slots_total, out, out_ld_n, out_ld_f);
+    else
+        hipLaunchKernelGGL(qk_capture_kernel<float>, g, dim3(256), 0, s, (const float *)q, ldq, q_rows_per_w, row0, (const float *)k, ldk, nk, heads, head_slot0, slots_total, out, out_ld_n, out_ld_f);
+    SWX_CHECK_LAUNCH();
+    return 0;
+}

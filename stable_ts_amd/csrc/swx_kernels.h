@@ -1,0 +1,74 @@
+// swx_kernels.h -- internal launcher prototypes shared by the translation units of libswx.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/swx.h"
+
+#define EPI_BIAS 1
+#define EPI_GELU 2
+#define EPI_RES 4
+#define EPI_OUT_F32 8
+#define EPI_RESF32MOD 16
+
+struct GemmArgs {
+    const void *A; int64_t lda;     // [M][K] compute dtype
+    const void *W; int64_t ldw;     // [N][K] compute dtype
+    const float *bias;              // [N] or null
+    const void *R; int64_t ldr;     // residual, compute dtype (may alias C)
+    const float *Rf; int res_mod;   // f32 residual [res_mod][N], row index = m % res_mod
+    void *C; int64_t ldc;           // compute dtype, or f32 with EPI_OUT_F32
+    int M, N, K;
+    int epi;
+};
+int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
+
+// ---- swx_norm.hip
+int swx_layernorm(int dtype, const void *x, int64_t ldx, const float *gamma, const float *beta, void *y, int64_t ldy,
+                  int rows, int d, hipStream_t s);
+// melT[b][t+1][c] (c < Cp, zero padded; rows 0 and 3001 zero) <- mel[b][c][t]
+int swx_mel_transpose(int dtype, const float *mel, int B, int n_mels, int Cp, void *melT, hipStream_t s);
+int swx_fill_zero(void *p, size_t bytes, hipStream_t s);
+// x[r][i] = tok_emb[tokens[r*ld_tok + i]] + pos_emb[pos0[r] + i]  for i < n_new[r] (rows of d)
+int swx_embed(int dtype, const int32_t *tokens, int64_t ld_tok, const int32_t *tok_off, const int32_t *pos0, int R, int n_new,
+              const void *tok_emb, const float *pos_emb, int d, void *x, hipStream_t s);
+int swx_convert_f32(int dtype, const float *src, void *dst, int64_t n, hipStream_t s);
+// strided/re-laid-out weight copies used by swx_load_tensor
+int swx_copy_rows(int dtype, const float *src, int64_t src_ld, void *dst, int64_t dst_ld, int64_t rows, int64_t cols,
+                  hipStream_t s);
+int swx_copy_conv_w(int dtype, const float *src, int out_c, int in_c, int in_cp, void *dst, hipStream_t s);
+
+// ---- swx_attn.hip
+struct AttnArgs {
+    const void *q; int64_t ldq;      // [B*nq][...] head h at column h*64
+    const void *k; const void *v; int64_t ldkv;   // [B*nk][...] head h at column h*64
+    void *o; int64_t ldo;
+    int B, H, nq, nk;
+    int q_rows_per_batch;            // rows of q per batch item (== nq unless grouped)
+};
+// dense (non-causal) attention over nk keys: encoder self-attention and cross-attention
+int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s);
+// decoder self-attention over the per-row KV cache with ancestor indirection
+struct SelfAttnArgs {
+    const void *qkv; int64_t ldqkv;  // [R*n_new][3d]: q | k | v of the new tokens
+    void *kcache; void *vcache;      // [Mphys][n_ctx][d]
+    int32_t *anc;                    // [rows][n_ctx] cache row holding position p of a logical row (null = identity)
+    const int32_t *pos0;             // [R] position of the first new token of each row
+    void *o; int64_t ldo;            // [R*n_new][d]
+    int R, n_new, H, n_ctx, d;
+};
+// logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
+int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);
+// raw scaled qk of selected heads: out[w][hi][i][f] = 0.125 * q[w][row0+i][head] . k[w][f][head]
+int swx_qk_capture(int dtype, const void *q, int64_t ldq, int q_rows_per_w, int row0, int n_rows, const void *k,
+                   int64_t ldk, int nk, const int32_t *heads, int n_heads, int head_slot0, int slots_total, int W,
+                   float *out, int out_ld_n, int out_ld_f, hipStream_t s);
+
+// ---- swx_align.hip / swx_mel.hip
+int swx_align_weights_launch(const float *d_qk, float *d_p, float *d_mean, float *d_sd, int W, int H, int N, int ld_f,
+                             const int *d_n_rows, const int *d_n_frames, float qk_scale, int medfilt_width,
+                             float *d_neg_matrix, int out_ld_n, int out_ld_f, hipStream_t s);
+int swx_mel_launch(const float *d_pcm, int B, const float *d_hann, const double2 *d_twiddle, const float *d_filters,
+                   int n_mels, float *d_mel, unsigned *d_gmax, int per_item_max, hipStream_t s);
+
+// ---- swx_decode.hip
+struct DecodeState;   // device-resident bookkeeping, defined in swx_decode.hip

@@ -1,0 +1,841 @@
+// swx_runtime.hip -- the C ABI of libswx.so (include/swx.h): weight arena, workspace, and the host-side drivers that
+// sequence the gfx950 kernels for the encoder, the decoding loop and the teacher-forced scoring pass.
+// No device allocation happens here: the caller binds the arena and the workspace (PyTorch owns the memory).
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <cstdio>
+#include "swx_common.h"
+#include "swx_kernels.h"
+#include "swx_decode.h"
+
+namespace {
+
+enum SlotKind { SK_MAT = 0, SK_VEC = 1, SK_CONV = 2 };
+
+struct Slot {
+    size_t off = 0;        // byte offset in the arena
+    int kind = SK_VEC;
+    int64_t rows = 0, cols = 0;   // source shape (MAT: [rows][cols]; CONV: out_c=rows, in_c=cols)
+    int64_t dst_ld = 0;    // MAT: destination leading dimension; CONV: padded in-channels
+    bool loaded = false;
+};
+
+struct LayerW {
+    size_t ln1_g, ln1_b, wqkv, bqkv, wo, bo;
+    size_t lnx_g, lnx_b, wcq, bcq, wckv, bckv, wco, bco;   // decoder only
+    size_t ln2_g, ln2_b, w1, b1, w2, b2;
+};
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct swx_model {
+    swx_dims dims;
+    int dtype;
+    size_t esz;                     // bytes per compute element
+    int Cp;                         // conv1 input channels padded to a multiple of 32
+    std::map<std::string, Slot> slots;
+    std::vector<LayerW> enc, dec;
+    size_t o_conv1_w, o_conv1_b, o_conv2_w, o_conv2_b, o_enc_pos, o_lnpost_g, o_lnpost_b;
+    size_t o_tok_emb, o_dec_pos, o_ln_g, o_ln_b;
+    size_t o_hann, o_twiddle, o_filters, o_heads, o_zeros;
+    size_t arena_bytes = 0;
+    unsigned char *arena = nullptr;
+    // alignment heads
+    std::vector<std::vector<int>> heads_by_layer;   // per decoder layer
+    std::vector<int> head_slot0;                    // first capture slot of each layer
+    int n_align = 0;
+    // workspace
+    unsigned char *ws = nullptr;
+    size_t ws_bytes = 0;
+    int max_windows = 0, max_rows = 0, ws_n_align = 0;
+    struct WsLayout {
+        size_t melT, h1, x, h, qkv, att, u, gmax, small_i32, zeros_i32;
+        size_t tokens0, tokens1, anc0, anc1, pos0, sum_lp, sum_lp_next, row_done, win_done, win_done_prev, n_done;
+        size_t fin_tokens, fin_score, fin_len, fin_count, cand_lp, cand_tok, logits, hid2;
+        size_t kcache, vcache, sk, sv, cap, mean, sd, suppress;
+        size_t total;
+        int64_t rows_big, logits_rows;
+    } L;
+
+    template <typename P> P *A(size_t off) const { return (P *)(arena + off); }
+    template <typename P> P *Wp(size_t off) const { return (P *)(ws + off); }
+};
+
+namespace {
+
+constexpr int FIN_CAP = 32;
+constexpr int MAX_GROUP = 16;
+constexpr int MAX_SUPPRESS = 4096;
+constexpr int SMALL_I32 = 8192;
+
+size_t add_slot(swx_model *m, size_t &cur, const std::string &name, int kind, int64_t rows, int64_t cols, int64_t dst_ld,
+                size_t bytes, size_t base_off = (size_t)-1, size_t sub_off = 0)
+{
+    Slot s;
+    s.kind = kind; s.rows = rows; s.cols = cols; s.dst_ld = dst_ld;
+    if (base_off == (size_t)-1) { s.off = cur; cur = align_up(cur + bytes); }
+    else s.off = base_off + sub_off;
+    m->slots[name] = s;
+    return s.off;
+}
+
+void build_layout(swx_model *m)
+{
+    const swx_dims &D = m->dims;
+    const size_t e = m->esz;
+    size_t cur = 0;
+    auto mat = [&](const std::string &n, int64_t r, int64_t c) { return add_slot(m, cur, n, SK_MAT, r, c, c, (size_t)r * c * e); };
+    auto vec = [&](const std::string &n, int64_t c) { return add_slot(m, cur, n, SK_VEC, 1, c, c, (size_t)c * 4); };
+    auto reserve = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes); return o; };
+
+    const int da = D.n_audio_state, dt = D.n_text_state;
+    m->Cp = (D.n_mels + 31) / 32 * 32;
+    m->o_conv1_w = add_slot(m, cur, "encoder.conv1.weight", SK_CONV, da, D.n_mels, m->Cp, (size_t)da * 3 * m->Cp * e);
+    m->o_conv1_b = vec("encoder.conv1.bias", da);
+    m->o_conv2_w = add_slot(m, cur, "encoder.conv2.weight", SK_CONV, da, da, da, (size_t)da * 3 * da * e);
+    m->o_conv2_b = vec("encoder.conv2.bias", da);
+    m->o_enc_pos = add_slot(m, cur, "encoder.positional_embedding", SK_VEC, 1, (int64_t)D.n_audio_ctx * da, 0, (size_t)D.n_audio_ctx * da * 4);
+
+    auto block = [&](const std::string &p, int d, bool cross) {
+        LayerW w{};
+        w.ln1_g = vec(p + "attn_ln.weight", d);
+        w.ln1_b = vec(p + "attn_ln.bias", d);
+        w.wqkv = reserve((size_t)3 * d * d * e);
+        add_slot(m, cur, p + "attn.query.weight", SK_MAT, d, d, d, 0, w.wqkv, 0);
+        add_slot(m, cur, p + "attn.key.weight", SK_MAT, d, d, d, 0, w.wqkv, (size_t)d * d * e);
+        add_slot(m, cur, p + "attn.value.weight", SK_MAT, d, d, d, 0, w.wqkv, (size_t)2 * d * d * e);
+        w.bqkv = reserve((size_t)3 * d * 4);
+        add_slot(m, cur, p + "attn.query.bias", SK_VEC, 1, d, d, 0, w.bqkv, 0);
+        add_slot(m, cur, p + "attn.value.bias", SK_VEC, 1, d, d, 0, w.bqkv, (size_t)2 * d * 4);
+        w.wo = mat(p + "attn.out.weight", d, d);
+        w.bo = vec(p + "attn.out.bias", d);
+        if (cross) {
+            w.lnx_g = vec(p + "cross_attn_ln.weight", d);
+            w.lnx_b = vec(p + "cross_attn_ln.bias", d);
+            w.wcq = mat(p + "cross_attn.query.weight", d, d);
+            w.bcq = vec(p + "cross_attn.query.bias", d);
+            w.wckv = reserve((size_t)2 * d * d * e);
+            add_slot(m, cur, p + "cross_attn.key.weight", SK_MAT, d, d, d, 0, w.wckv, 0);
+            add_slot(m, cur, p + "cross_attn.value.weight", SK_MAT, d, d, d, 0, w.wckv, (size_t)d * d * e);
+            w.bckv = reserve((size_t)2 * d * 4);
+            add_slot(m, cur, p + "cross_attn.value.bias", SK_VEC, 1, d, d, 0, w.bckv, (size_t)d * 4);
+            w.wco = mat(p + "cross_attn.out.weight", d, d);
+            w.bco = vec(p + "cross_attn.out.bias", d);
+        }
+        w.ln2_g = vec(p + "mlp_ln.weight", d);
+        w.ln2_b = vec(p + "mlp_ln.bias", d);
+        w.w1 = mat(p + "mlp.0.weight", 4 * d, d);
+        w.b1 = vec(p + "mlp.0.bias", 4 * d);
+        w.w2 = mat(p + "mlp.2.weight", d, 4 * d);
+        w.b2 = vec(p + "mlp.2.bias", d);
+        return w;
+    };
+    for (int l = 0; l < D.n_audio_layer; ++l) m->enc.push_back(block("encoder.blocks." + std::to_string(l) + ".", da, false));
+    m->o_lnpost_g = vec("encoder.ln_post.weight", da);
+    m->o_lnpost_b = vec("encoder.ln_post.bias", da);
+    m->o_tok_emb = mat("decoder.token_embedding.weight", D.n_vocab, dt);
+    m->o_dec_pos = add_slot(m, cur, "decoder.positional_embedding", SK_VEC, 1, (int64_t)D.n_text_ctx * dt, 0, (size_t)D.n_text_ctx * dt * 4);
+    for (int l = 0; l < D.n_text_layer; ++l) m->dec.push_back(block("decoder.blocks." + std::to_string(l) + ".", dt, true));
+    m->o_ln_g = vec("decoder.ln.weight", dt);
+    m->o_ln_b = vec("decoder.ln.bias", dt);
+    // constants
+    m->o_hann = vec("const.hann", SWX_N_FFT);
+    m->o_filters = add_slot(m, cur, "const.mel_filters", SK_VEC, 1, (int64_t)D.n_mels * 201, 0, (size_t)D.n_mels * 201 * 4);
+    m->o_twiddle = reserve(sizeof(double2) * SWX_N_FFT);
+    m->o_heads = reserve(sizeof(int32_t) * (size_t)D.n_text_layer * D.n_text_head);
+    m->o_zeros = reserve(256);
+    m->arena_bytes = cur;
+}
+
+void default_alignment_heads(swx_model *m)
+{
+    const swx_dims &D = m->dims;
+    m->heads_by_layer.assign(D.n_text_layer, {});
+    for (int l = D.n_text_layer / 2; l < D.n_text_layer; ++l)
+        for (int h = 0; h < D.n_text_head; ++h) m->heads_by_layer[l].push_back(h);
+}
+
+int upload_heads(swx_model *m)
+{
+    const swx_dims &D = m->dims;
+    std::vector<int32_t> flat;
+    m->head_slot0.assign(D.n_text_layer, 0);
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        m->head_slot0[l] = (int)flat.size();
+        for (int h : m->heads_by_layer[l]) flat.push_back(h);
+    }
+    m->n_align = (int)flat.size();
+    if (m->arena && !flat.empty()) {
+        hipError_t e = hipMemcpy(m->A<int32_t>(m->o_heads), flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return -100 - (int)e;
+    }
+    return 0;
+}
+
+void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::WsLayout &L)
+{
+    const swx_dims &D = m->dims;
+    const size_t e = m->esz;
+    const int da = D.n_audio_state, dt = D.n_text_state;
+    const int dmax = da > dt ? da : dt;
+    const int TS = D.n_text_ctx + 1;
+    size_t cur = 0;
+    auto take = [&](size_t bytes) { size_t o = cur; cur = align_up(cur + bytes); return o; };
+    int64_t rows_big = (int64_t)Bmax * D.n_audio_ctx;
+    if ((int64_t)Bmax * D.n_text_ctx > rows_big) rows_big = (int64_t)Bmax * D.n_text_ctx;
+    if (Mmax > rows_big) rows_big = Mmax;
+    L.rows_big = rows_big;
+    L.melT = take((size_t)Bmax * 3002 * m->Cp * e);
+    L.h1 = take((size_t)Bmax * 3002 * da * e);
+    L.x = take((size_t)rows_big * dmax * e);
+    L.h = take((size_t)rows_big * dmax * e);
+    L.qkv = take((size_t)rows_big * 3 * dmax * e);
+    L.att = take((size_t)rows_big * dmax * e);
+    L.u = take((size_t)rows_big * 4 * dmax * e);
+    L.gmax = take((size_t)Bmax * 4);
+    L.small_i32 = take((size_t)SMALL_I32 * 4);
+    L.zeros_i32 = take((size_t)(Mmax > Bmax ? Mmax : Bmax) * 4 + 256);
+    L.tokens0 = take((size_t)Mmax * TS * 4);
+    L.tokens1 = take((size_t)Mmax * TS * 4);
+    L.anc0 = take((size_t)Mmax * D.n_text_ctx * 4);
+    L.anc1 = take((size_t)Mmax * D.n_text_ctx * 4);
+    L.pos0 = take((size_t)Mmax * 4);
+    L.sum_lp = take((size_t)Mmax * 4);
+    L.sum_lp_next = take((size_t)Mmax * 4);
+    L.row_done = take((size_t)Mmax * 4);
+    L.win_done = take((size_t)Bmax * 4);
+    L.win_done_prev = take((size_t)Bmax * 4);
+    L.n_done = take(256);
+    L.fin_tokens = take((size_t)Bmax * FIN_CAP * TS * 4);
+    L.fin_score = take((size_t)Bmax * FIN_CAP * 4);
+    L.fin_len = take((size_t)Bmax * FIN_CAP * 4);
+    L.fin_count = take((size_t)Bmax * 4);
+    L.cand_lp = take((size_t)Mmax * (MAX_GROUP + 1) * 4);
+    L.cand_tok = take((size_t)Mmax * (MAX_GROUP + 1) * 4);
+    int64_t lrows = (int64_t)Mmax + 2 * Bmax;     // M step rows + the 2W prefill rows parked at the tail
+    if (lrows < 64) lrows = 64;
+    L.logits_rows = lrows;
+    L.logits = take((size_t)lrows * D.n_vocab * 4);
+    L.hid2 = take((size_t)2 * Bmax * dt * e);
+    L.kcache = take((size_t)D.n_text_layer * Mmax * D.n_text_ctx * dt * e);
+    L.vcache = take((size_t)D.n_text_layer * Mmax * D.n_text_ctx * dt * e);
+    L.sk = take((size_t)Bmax * D.n_text_ctx * dt * e);
+    L.sv = take((size_t)Bmax * D.n_text_ctx * dt * e);
+    L.cap = take((size_t)Bmax * (n_align > 0 ? n_align : 1) * D.n_text_ctx * D.n_audio_ctx * 4);
+    L.mean = take((size_t)Bmax * (n_align > 0 ? n_align : 1) * D.n_audio_ctx * 4);
+    L.sd = take((size_t)Bmax * (n_align > 0 ? n_align : 1) * D.n_audio_ctx * 4);
+    L.suppress = take((size_t)MAX_SUPPRESS * 4);
+    L.total = cur;
+}
+
+inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+#define SWX_TRY(expr) do { int _r = (expr); if (_r < 0) return _r; } while (0)
+
+GemmArgs gemm_args(const void *A, int64_t lda, const void *W, int64_t ldw, const float *bias, void *C, int64_t ldc,
+                   int M, int N, int K, int epi)
+{
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.epi = epi;
+    g.R = nullptr; g.ldr = 0; g.Rf = nullptr; g.res_mod = 1;
+    return g;
+}
+
+// x += Linear(a) ; used for the attention / MLP output projections
+int gemm_residual(swx_model *m, const void *A, int64_t lda, size_t w_off, size_t b_off, void *X, int64_t ldx, int M, int N,
+                  int K, hipStream_t s)
+{
+    GemmArgs g = gemm_args(A, lda, m->arena + w_off, K, m->A<float>(b_off), X, ldx, M, N, K, EPI_BIAS | EPI_RES);
+    g.R = X; g.ldr = ldx;
+    return swx_gemm(m->dtype, g, 0, s);
+}
+
+// ------------------------------------------------------------------------------------------------ decoder forward
+struct FwdCfg {
+    int W;                 // windows
+    int rpw;               // logical rows per window in this pass
+    int row_mul;           // logical row id = grid row * row_mul
+    int n_new;             // new tokens per row
+    const int32_t *tokens; int64_t ld_tok;
+    const int32_t *pos0;   // device, indexed by logical row id
+    unsigned char *kcache, *vcache;
+    size_t layer_stride;   // bytes between layers in the cache (0 = single-layer scratch)
+    int cache_rows;        // rows per layer in the cache
+    int32_t *anc;
+    const unsigned char *xkv;
+    bool capture; int cap_row0, cap_rows, cap_ld_n;
+};
+
+int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
+{
+    const swx_dims &D = m->dims;
+    const int d = D.n_text_state, H = D.n_text_head;
+    const size_t e = m->esz;
+    const int R = f.W * f.rpw;
+    const int rows = R * f.n_new;
+    if (rows > m->L.rows_big) return -8;
+    unsigned char *x = m->ws + m->L.x, *h = m->ws + m->L.h, *qkv = m->ws + m->L.qkv, *att = m->ws + m->L.att, *u = m->ws + m->L.u;
+    SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, R, f.n_new, m->arena + m->o_tok_emb,
+                      m->A<float>(m->o_dec_pos), d, x, s));
+    // embed indexes rows by grid row; with row_mul > 1 the caller passes pre-strided token / position views
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const LayerW &w = m->dec[l];
+        SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.ln1_g), m->A<float>(w.ln1_b), h, d, rows, d, s));
+        SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wqkv, d, m->A<float>(w.bqkv), qkv, 3 * d, rows, 3 * d, d, EPI_BIAS), 0, s));
+        SelfAttnArgs sa{};
+        sa.qkv = qkv; sa.ldqkv = 3 * d;
+        sa.kcache = f.kcache + (size_t)l * f.layer_stride;
+        sa.vcache = f.vcache + (size_t)l * f.layer_stride;
+        sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
+        sa.R = R; sa.n_new = f.n_new; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d;
+        SWX_TRY(swx_self_attention(m->dtype, sa, f.row_mul, s));
+        SWX_TRY(gemm_residual(m, att, d, w.wo, w.bo, x, d, rows, d, d, s));
+        // cross attention
+        SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.lnx_g), m->A<float>(w.lnx_b), h, d, rows, d, s));
+        SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wcq, d, m->A<float>(w.bcq), qkv, d, rows, d, d, EPI_BIAS), 0, s));
+        const unsigned char *kl = f.xkv + (size_t)l * f.W * D.n_audio_ctx * 2 * d * e;
+        AttnArgs ca{};
+        ca.q = qkv; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)d * e; ca.ldkv = 2 * d; ca.o = att; ca.ldo = d;
+        ca.B = f.W; ca.H = H; ca.nq = f.rpw * f.n_new; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw * f.n_new;
+        SWX_TRY(swx_attention(m->dtype, ca, 0, s));
+        if (f.capture && !m->heads_by_layer[l].empty()) {
+            SWX_TRY(swx_qk_capture(m->dtype, qkv, d, f.rpw * f.n_new, f.cap_row0, f.cap_rows, kl, 2 * d, D.n_audio_ctx,
+                                   m->A<int32_t>(m->o_heads) + m->head_slot0[l], (int)m->heads_by_layer[l].size(),
+                                   m->head_slot0[l], m->n_align, f.W, m->Wp<float>(m->L.cap), f.cap_ld_n, D.n_audio_ctx, s));
+        }
+        SWX_TRY(gemm_residual(m, att, d, w.wco, w.bco, x, d, rows, d, d, s));
+        // MLP
+        SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.ln2_g), m->A<float>(w.ln2_b), h, d, rows, d, s));
+        SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.w1, d, m->A<float>(w.b1), u, 4 * d, rows, 4 * d, d, EPI_BIAS | EPI_GELU), 0, s));
+        SWX_TRY(gemm_residual(m, u, 4 * d, w.w2, w.b2, x, d, rows, d, 4 * d, s));
+    }
+    return 0;
+}
+
+int logits_gemm(swx_model *m, const void *hid, int64_t ld, int rows, float *out, hipStream_t s)
+{
+    const swx_dims &D = m->dims;
+    return swx_gemm(m->dtype, gemm_args(hid, ld, m->arena + m->o_tok_emb, D.n_text_state, nullptr, out, D.n_vocab, rows,
+                                        D.n_vocab, D.n_text_state, EPI_OUT_F32), 0, s);
+}
+
+__global__ __launch_bounds__(256) void token_prob_kernel(const float *__restrict__ logits, int V, int eot,
+                                                         const int32_t *__restrict__ target_tok, float *__restrict__ out)
+{
+    // one block per row: softmax(logits[row][:eot])[target]
+    __shared__ float sh[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float *lg = logits + (size_t)row * V;
+    float mx = -__builtin_inff();
+    for (int i = tid; i < eot; i += 256) mx = fmaxf(mx, lg[i]);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) sh[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < eot; i += 256) sum += expf(lg[i] - mx);
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) sh[tid >> 6] = sum;
+    __syncthreads();
+    sum = sh[0] + sh[1] + sh[2] + sh[3];
+    if (tid == 0) {
+        const int t = target_tok[row];
+        out[row] = (t >= 0 && t < eot) ? expf(lg[t] - mx) / sum : 0.f;
+    }
+}
+
+__global__ void score_targets_kernel(const int32_t *__restrict__ tokens, int max_n, int n_sot, int rows_per_w,
+                                     int32_t *__restrict__ targets, int total)
+{
+    // row (w, i) of the probability pass predicts tokens[w][n_sot + 1 + i]
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int w = idx / rows_per_w, i = idx % rows_per_w;
+    const int p = n_sot + 1 + i;
+    targets[idx] = (p < max_n) ? tokens[(size_t)w * max_n + p] : -1;
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+const char *swx_strerror(int code)
+{
+    switch (code) {
+        case 0: return "ok";
+        case -1: return "invalid argument";
+        case -2: return "size out of range";
+        case -3: return "unsupported filter width";
+        case -4: return "gemm shape/alignment not supported";
+        case -5: return "attention shape not supported";
+        case -7: return "not implemented";
+        case -8: return "workspace too small for this call";
+        case -9: return "weights / workspace not bound";
+        case -10: return "unknown tensor name";
+        case -11: return "tensor size mismatch";
+        default: return code <= -100 ? "HIP runtime error (code = -100 - hipError_t)" : "unknown error";
+    }
+}
+
+int swx_version(void) { return 1; }
+
+int swx_model_create(const swx_dims *dims, int dtype, swx_model **out)
+{
+    if (!dims || !out || (dtype != SWX_F32 && dtype != SWX_F16)) return -1;
+    if (dims->n_audio_state % 64 || dims->n_text_state % 64) return -1;
+    if (dims->n_audio_state / dims->n_audio_head != 64 || dims->n_text_state / dims->n_text_head != 64) return -1;
+    if (dims->n_text_ctx > 448 || dims->n_audio_ctx > 1500) return -2;
+    swx_model *m = new swx_model();
+    m->dims = *dims;
+    m->dtype = dtype;
+    m->esz = dtype == SWX_F16 ? 2 : 4;
+    build_layout(m);
+    default_alignment_heads(m);
+    upload_heads(m);
+    *out = m;
+    return 0;
+}
+
+void swx_model_destroy(swx_model *m) { delete m; }
+
+size_t swx_weights_bytes(const swx_model *m) { return m ? m->arena_bytes : 0; }
+
+int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes)
+{
+    if (!m || !d_arena || bytes < m->arena_bytes) return -1;
+    m->arena = (unsigned char *)d_arena;
+    hipError_t e = hipMemset(d_arena, 0, m->arena_bytes);
+    if (e != hipSuccess) return -100 - (int)e;
+    std::vector<double2> tw(SWX_N_FFT);
+    for (int i = 0; i < SWX_N_FFT; ++i) {
+        const double a = 2.0 * M_PI * (double)i / (double)SWX_N_FFT;
+        tw[i].x = cos(a); tw[i].y = sin(a);
+    }
+    e = hipMemcpy(m->arena + m->o_twiddle, tw.data(), sizeof(double2) * SWX_N_FFT, hipMemcpyHostToDevice);
+    if (e != hipSuccess) return -100 - (int)e;
+    for (auto &kv : m->slots) kv.second.loaded = false;
+    return upload_heads(m);
+}
+
+int swx_load_tensor(swx_model *m, const char *name, const float *d_src, int64_t numel, void *stream)
+{
+    if (!m || !m->arena) return -9;
+    auto it = m->slots.find(name);
+    if (it == m->slots.end()) return -10;
+    Slot &sl = it->second;
+    hipStream_t s = S(stream);
+    if (sl.kind == SK_MAT) {
+        if (numel != sl.rows * sl.cols) return -11;
+        SWX_TRY(swx_copy_rows(m->dtype, d_src, sl.cols, m->arena + sl.off, sl.dst_ld, sl.rows, sl.cols, s));
+    } else if (sl.kind == SK_CONV) {
+        if (numel != sl.rows * sl.cols * 3) return -11;
+        SWX_TRY(swx_copy_conv_w(m->dtype, d_src, (int)sl.rows, (int)sl.cols, (int)sl.dst_ld, m->arena + sl.off, s));
+    } else {
+        if (numel != sl.cols) return -11;
+        hipError_t e = hipMemcpyAsync(m->arena + sl.off, d_src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return -100 - (int)e;
+    }
+    sl.loaded = true;
+    return 0;
+}
+
+int swx_weights_complete(const swx_model *m)
+{
+    if (!m) return 0;
+    for (auto &kv : m->slots) if (!kv.second.loaded) return 0;
+    return 1;
+}
+
+int swx_missing_tensor(const swx_model *m, int index, char *buf, int buflen)
+{
+    int k = 0;
+    for (auto &kv : m->slots)
+        if (!kv.second.loaded) {
+            if (k == index) { snprintf(buf, buflen, "%s", kv.first.c_str()); return 1; }
+            ++k;
+        }
+    return 0;
+}
+
+int swx_set_alignment_heads(swx_model *m, const int32_t *pairs, int n_pairs)
+{
+    if (!m || (n_pairs > 0 && !pairs)) return -1;
+    const swx_dims &D = m->dims;
+    std::vector<std::vector<int>> by(D.n_text_layer);
+    for (int i = 0; i < n_pairs; ++i) {
+        const int l = pairs[2 * i], h = pairs[2 * i + 1];
+        if (l < 0 || l >= D.n_text_layer || h < 0 || h >= D.n_text_head) return -1;
+        by[l].push_back(h);
+    }
+    m->heads_by_layer = by;
+    return upload_heads(m);
+}
+
+int swx_num_alignment_heads(const swx_model *m) { return m ? m->n_align : 0; }
+
+size_t swx_workspace_bytes(const swx_model *m, int max_windows, int max_rows)
+{
+    if (!m || max_windows <= 0 || max_rows <= 0) return 0;
+    swx_model::WsLayout L;
+    ws_layout(m, max_windows, max_rows, m->n_align, L);
+    return L.total;
+}
+
+int swx_bind_workspace(swx_model *m, void *d_ws, size_t bytes, int max_windows, int max_rows)
+{
+    if (!m || !d_ws || max_windows <= 0 || max_rows <= 0) return -1;
+    swx_model::WsLayout L;
+    ws_layout(m, max_windows, max_rows, m->n_align, L);
+    if (bytes < L.total) return -8;
+    m->ws = (unsigned char *)d_ws;
+    m->ws_bytes = bytes;
+    m->max_windows = max_windows;
+    m->max_rows = max_rows;
+    m->ws_n_align = m->n_align;
+    m->L = L;
+    hipError_t e = hipMemset(m->ws + L.zeros_i32, 0, (size_t)(max_rows > max_windows ? max_rows : max_windows) * 4 + 256);
+    if (e != hipSuccess) return -100 - (int)e;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------- mel
+int swx_log_mel(swx_model *m, const float *d_pcm, int B, float *d_mel, int per_item_max, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (B > m->max_windows) return -8;
+    return swx_mel_launch(d_pcm, B, m->A<float>(m->o_hann), m->A<double2>(m->o_twiddle), m->A<float>(m->o_filters),
+                          m->dims.n_mels, d_mel, m->Wp<unsigned>(m->L.gmax), per_item_max, S(stream));
+}
+
+// ----------------------------------------------------------------------------------------------------- encoder
+int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (B <= 0) return 0;
+    if (B > m->max_windows) return -8;
+    const swx_dims &D = m->dims;
+    const int d = D.n_audio_state, H = D.n_audio_head, S_ = D.n_audio_ctx;
+    const size_t e = m->esz;
+    hipStream_t s = S(stream);
+    unsigned char *melT = m->ws + m->L.melT, *h1 = m->ws + m->L.h1;
+    unsigned char *x = m->ws + m->L.x, *h = m->ws + m->L.h, *qkv = m->ws + m->L.qkv, *att = m->ws + m->L.att, *u = m->ws + m->L.u;
+    const int rows = B * S_;
+    if (D.n_audio_ctx != 1500) return -2;
+
+    SWX_TRY(swx_mel_transpose(m->dtype, d_mel, B, D.n_mels, m->Cp, melT, s));
+    // conv1 (k=3, pad 1) as a GEMM over overlapping rows of the channel-last mel: A row t = melT[t .. t+2][:]
+    SWX_TRY(swx_fill_zero(h1, (size_t)B * 3002 * d * e, s));
+    for (int b = 0; b < B; ++b) {
+        const unsigned char *a = melT + (size_t)b * 3002 * m->Cp * e;
+        unsigned char *c = h1 + ((size_t)b * 3002 + 1) * d * e;
+        SWX_TRY(swx_gemm(m->dtype, gemm_args(a, m->Cp, m->arena + m->o_conv1_w, 3 * m->Cp, m->A<float>(m->o_conv1_b), c, d,
+                                             3000, d, 3 * m->Cp, EPI_BIAS | EPI_GELU), 0, s));
+    }
+    // conv2 (k=3, stride 2, pad 1): A row t' = h1[2t' .. 2t'+2][:] (padded row index), then + positional embedding
+    for (int b = 0; b < B; ++b) {
+        const unsigned char *a = h1 + (size_t)b * 3002 * d * e;
+        GemmArgs g = gemm_args(a, 2 * d, m->arena + m->o_conv2_w, 3 * d, m->A<float>(m->o_conv2_b), x + (size_t)b * S_ * d * e, d,
+                               S_, d, 3 * d, EPI_BIAS | EPI_GELU | EPI_RESF32MOD);
+        g.Rf = m->A<float>(m->o_enc_pos); g.res_mod = S_;
+        SWX_TRY(swx_gemm(m->dtype, g, 0, s));
+    }
+    for (int l = 0; l < D.n_audio_layer; ++l) {
+        const LayerW &w = m->enc[l];
+        SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.ln1_g), m->A<float>(w.ln1_b), h, d, rows, d, s));
+        SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wqkv, d, m->A<float>(w.bqkv), qkv, 3 * d, rows, 3 * d, d, EPI_BIAS), 0, s));
+        AttnArgs a{};
+        a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * e; a.v = qkv + (size_t)2 * d * e; a.ldkv = 3 * d; a.o = att; a.ldo = d;
+        a.B = B; a.H = H; a.nq = S_; a.nk = S_; a.q_rows_per_batch = S_;
+        SWX_TRY(swx_attention(m->dtype, a, 0, s));
+        SWX_TRY(gemm_residual(m, att, d, w.wo, w.bo, x, d, rows, d, d, s));
+        SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.ln2_g), m->A<float>(w.ln2_b), h, d, rows, d, s));
+        SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.w1, d, m->A<float>(w.b1), u, 4 * d, rows, 4 * d, d, EPI_BIAS | EPI_GELU), 0, s));
+        SWX_TRY(gemm_residual(m, u, 4 * d, w.w2, w.b2, x, d, rows, d, 4 * d, s));
+    }
+    SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_lnpost_g), m->A<float>(m->o_lnpost_b), d_xa, d, rows, d, s));
+    return 0;
+}
+
+size_t swx_cross_kv_bytes(const swx_model *m, int B)
+{
+    if (!m) return 0;
+    return (size_t)m->dims.n_text_layer * B * m->dims.n_audio_ctx * 2 * m->dims.n_text_state * m->esz;
+}
+
+int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *stream)
+{
+    if (!m || !m->arena) return -9;
+    const swx_dims &D = m->dims;
+    const int d = D.n_text_state, rows = B * D.n_audio_ctx;
+    if (D.n_audio_state != d) return -1;
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const LayerW &w = m->dec[l];
+        unsigned char *out = (unsigned char *)d_xkv + (size_t)l * rows * 2 * d * m->esz;
+        SWX_TRY(swx_gemm(m->dtype, gemm_args(d_xa, d, m->arena + w.wckv, d, m->A<float>(w.bckv), out, 2 * d, rows, 2 * d, d, EPI_BIAS), 0, S(stream)));
+    }
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------------------------- decode
+int swx_decode_gout(const swx_decode_cfg *cfg)
+{
+    if (!cfg) return 0;
+    if (!cfg->beam) return cfg->n_group;
+    const float pat = cfg->patience > 0.f ? cfg->patience : 1.0f;
+    const int mc = (int)lrintf((float)cfg->n_group * pat);   // Python round(): half-to-even, as lrintf in the default mode
+    return mc > cfg->n_group ? mc : cfg->n_group;
+}
+
+int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_tokens, const int32_t *d_suppress,
+               const uint8_t *d_ts_mask, const void *d_xkv, int32_t *d_tokens_out, int32_t *d_lens_out,
+               float *d_sumlp_out, float *d_nospeech, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (!cfg || !d_init_tokens || !d_xkv) return -1;
+    const swx_dims &D = m->dims;
+    const int W = cfg->n_windows, G = cfg->n_group, M = W * G;
+    if (W <= 0 || G <= 0 || G > MAX_GROUP) return -1;
+    if (W > m->max_windows || M > m->max_rows) return -8;
+    if (cfg->n_suppress > MAX_SUPPRESS || cfg->n_suppress < 0) return -2;
+    const int n_init = cfg->sample_begin;
+    if (n_init <= 0 || n_init > D.n_text_ctx) return -1;
+    hipStream_t s = S(stream);
+    const int d = D.n_text_state;
+    const size_t e = m->esz;
+
+    DecodeBufs b{};
+    b.cfg = *cfg;
+    b.W = W; b.G = G; b.M = M; b.V = D.n_vocab; b.TS = D.n_text_ctx + 1; b.n_ctx = D.n_text_ctx; b.n_init = n_init;
+    const float pat = cfg->patience > 0.f ? cfg->patience : 1.0f;
+    b.max_cand = cfg->beam ? (int)lrintf((float)G * pat) : 0;
+    if (cfg->beam && (b.max_cand <= 0 || b.max_cand > FIN_CAP)) return -2;
+    b.fin_cap = FIN_CAP;
+    b.tokens[0] = m->Wp<int32_t>(m->L.tokens0); b.tokens[1] = m->Wp<int32_t>(m->L.tokens1);
+    const bool use_anc = G > 1;
+    b.anc[0] = use_anc ? m->Wp<int32_t>(m->L.anc0) : nullptr;
+    b.anc[1] = use_anc ? m->Wp<int32_t>(m->L.anc1) : nullptr;
+    b.pos0 = m->Wp<int32_t>(m->L.pos0);
+    b.sum_lp = m->Wp<float>(m->L.sum_lp); b.sum_lp_next = m->Wp<float>(m->L.sum_lp_next);
+    b.row_done = m->Wp<int32_t>(m->L.row_done);
+    b.win_done = m->Wp<int32_t>(m->L.win_done); b.win_done_prev = m->Wp<int32_t>(m->L.win_done_prev);
+    b.n_done = m->Wp<int32_t>(m->L.n_done);
+    b.fin_tokens = m->Wp<int32_t>(m->L.fin_tokens); b.fin_score = m->Wp<float>(m->L.fin_score);
+    b.fin_len = m->Wp<int32_t>(m->L.fin_len); b.fin_count = m->Wp<int32_t>(m->L.fin_count);
+    b.cand_lp = m->Wp<float>(m->L.cand_lp); b.cand_tok = m->Wp<int32_t>(m->L.cand_tok);
+    b.logits = m->Wp<float>(m->L.logits);
+    b.ts_mask = d_ts_mask;
+    int32_t *sup = m->Wp<int32_t>(m->L.suppress);
+    if (cfg->n_suppress > 0) {
+        hipError_t er = hipMemcpyAsync(sup, d_suppress, (size_t)cfg->n_suppress * 4, hipMemcpyDeviceToDevice, s);
+        if (er != hipSuccess) return -100 - (int)er;
+    }
+    b.suppress = sup;
+    hipError_t er = hipMemsetAsync(b.win_done_prev, 0, (size_t)W * 4, s);
+    if (er != hipSuccess) return -100 - (int)er;
+
+    SWX_TRY(swx_decode_init(b, d_init_tokens, s));
+
+    const size_t layer_stride = (size_t)m->max_rows * D.n_text_ctx * d * e;
+    // ---- prefill: one row per window (row w*G), n_init tokens
+    FwdCfg f{};
+    f.W = W; f.rpw = 1; f.row_mul = G; f.n_new = n_init;
+    f.tokens = b.tokens[0]; f.ld_tok = (int64_t)G * b.TS;
+    f.pos0 = m->Wp<int32_t>(m->L.zeros_i32);      // all zeros (any stride)
+    f.kcache = m->ws + m->L.kcache; f.vcache = m->ws + m->L.vcache; f.layer_stride = layer_stride; f.cache_rows = m->max_rows;
+    f.anc = nullptr; f.xkv = (const unsigned char *)d_xkv; f.capture = false;
+    SWX_TRY(decoder_forward(m, f, s));
+    unsigned char *x = m->ws + m->L.x, *hid2 = m->ws + m->L.hid2;
+    // final LN of the rows at sot_index and at the last initial position of every window -> [W][2][d]
+    SWX_TRY(swx_layernorm(m->dtype, x + (size_t)cfg->sot_index * d * e, (int64_t)n_init * d, m->A<float>(m->o_ln_g),
+                          m->A<float>(m->o_ln_b), hid2, 2 * d, W, d, s));
+    SWX_TRY(swx_layernorm(m->dtype, x + (size_t)(n_init - 1) * d * e, (int64_t)n_init * d, m->A<float>(m->o_ln_g),
+                          m->A<float>(m->o_ln_b), hid2 + (size_t)d * e, 2 * d, W, d, s));
+    // the prefill logits live at the tail of the logits region so that replication to rows [0, M) never overlaps
+    float *lg2 = b.logits + (size_t)(m->L.logits_rows - 2 * W) * D.n_vocab;
+    SWX_TRY(logits_gemm(m, hid2, d, 2 * W, lg2, s));
+    SWX_TRY(swx_decode_after_prefill(b, lg2, d_nospeech, s));
+
+    int cur = 0, steps = 0;
+    int32_t h_done = 0;
+    const int CHECK = 8;
+    for (int i = 0; i < cfg->sample_len; ++i) {
+        SWX_TRY(swx_decode_select(b, i, cur, s));
+        if (cfg->beam) cur ^= 1;
+        steps = i + 1;
+        if (n_init + i + 1 > D.n_text_ctx) break;          // tokens.shape[-1] > n_ctx (decode.py:60)
+        if (steps % CHECK == 0 || steps == cfg->sample_len) {
+            er = hipMemcpyAsync(&h_done, b.n_done, 4, hipMemcpyDeviceToHost, s);
+            if (er != hipSuccess) return -100 - (int)er;
+            er = hipStreamSynchronize(s);
+            if (er != hipSuccess) return -100 - (int)er;
+            if (h_done >= W) break;
+        }
+        if (i + 1 >= cfg->sample_len) break;
+        // ---- one decoder step for all M rows
+        FwdCfg g{};
+        g.W = W; g.rpw = G; g.row_mul = 1; g.n_new = 1;
+        g.tokens = b.tokens[cur]; g.ld_tok = b.TS; g.pos0 = b.pos0;
+        g.kcache = f.kcache; g.vcache = f.vcache; g.layer_stride = layer_stride; g.cache_rows = m->max_rows;
+        g.anc = use_anc ? b.anc[cur] : nullptr; g.xkv = (const unsigned char *)d_xkv; g.capture = false;
+        SWX_TRY(decoder_forward(m, g, s));
+        unsigned char *hh = m->ws + m->L.h;
+        SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, M, d, s));
+        SWX_TRY(logits_gemm(m, hh, d, M, b.logits, s));
+    }
+    const int G_out = swx_decode_gout(cfg);
+    SWX_TRY(swx_decode_finalize(b, cur, steps, d_tokens_out, d_lens_out, d_sumlp_out, G_out, s));
+    er = hipStreamSynchronize(s);
+    if (er != hipSuccess) return -100 - (int)er;
+    return steps;
+}
+
+// ------------------------------------------------------------------------------------------------------ score
+static int score_forward(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot,
+                         const void *d_xkv, bool capture, hipStream_t s)
+{
+    const swx_dims &D = m->dims;
+    if (W > m->max_windows) return -8;
+    if (max_n <= 0 || max_n > D.n_text_ctx) return -2;
+    for (int w = 0; w < W; ++w) if (h_n_tok[w] > max_n || h_n_tok[w] <= 0) return -1;
+    FwdCfg f{};
+    f.W = W; f.rpw = 1; f.row_mul = 1; f.n_new = max_n;
+    f.tokens = d_tokens; f.ld_tok = max_n;
+    f.pos0 = m->Wp<int32_t>(m->L.zeros_i32);
+    f.kcache = m->ws + m->L.sk; f.vcache = m->ws + m->L.sv; f.layer_stride = 0; f.cache_rows = m->max_windows;
+    f.anc = nullptr; f.xkv = (const unsigned char *)d_xkv;
+    f.capture = capture;
+    f.cap_row0 = n_sot; f.cap_rows = max_n - n_sot - 1; f.cap_ld_n = max_n;
+    if (capture && f.cap_rows <= 0) return -1;
+    return decoder_forward(m, f, s);
+}
+
+int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot, int eot,
+              const int32_t *h_n_frames, float qk_scale, int medfilt_width, const void *d_xkv, float *d_token_probs,
+              float *d_neg_matrix, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (W <= 0) return 0;
+    if (m->n_align != m->ws_n_align || m->n_align <= 0) return -8;
+    if (2 * W + 16 > SMALL_I32) return -8;
+    const swx_dims &D = m->dims;
+    hipStream_t s = S(stream);
+    const int d = D.n_text_state;
+    const size_t e = m->esz;
+    SWX_TRY(score_forward(m, d_tokens, h_n_tok, W, max_n, n_sot, d_xkv, true, s));
+
+    // per-window row / frame counts on the device
+    std::vector<int32_t> hv(2 * W);
+    for (int w = 0; w < W; ++w) {
+        const int T = h_n_tok[w] - n_sot - 2;
+        if (T < 0) return -1;
+        hv[w] = T + 1;
+        int F = h_n_frames[w];
+        if (F < 1) F = 1;
+        if (F > D.n_audio_ctx) F = D.n_audio_ctx;
+        hv[W + w] = F;
+    }
+    int32_t *d_small = m->Wp<int32_t>(m->L.small_i32);
+    hipError_t er = hipMemcpyAsync(d_small, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, s);
+    if (er != hipSuccess) return -100 - (int)er;
+    er = hipStreamSynchronize(s);     // hv goes out of scope; pageable copies are staged synchronously anyway
+    if (er != hipSuccess) return -100 - (int)er;
+
+    // token probabilities: rows n_sot .. n_sot+T-1 of the final-LN'd hidden states -> logits[:, :eot] -> softmax -> gather
+    unsigned char *x = m->ws + m->L.x, *hh = m->ws + m->L.h;
+    const int rows = W * max_n;
+    SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, rows, d, s));
+    const int rpw = max_n - n_sot - 2;     // probability rows per window (T_max)
+    if (rpw > 0) {
+        float *lg = m->Wp<float>(m->L.logits);
+        int32_t *targets = (int32_t *)(m->ws + m->L.att);     // att is free after the forward pass
+        const int total = W * rpw;
+        hipLaunchKernelGGL(score_targets_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, d_tokens, max_n, n_sot, rpw, targets, total);
+        const int chunk = (int)m->L.logits_rows;
+        for (int w = 0; w < W; ++w) {
+            for (int r0 = 0; r0 < rpw; r0 += chunk) {
+                const int nr = (rpw - r0) < chunk ? (rpw - r0) : chunk;
+                const unsigned char *hid = hh + ((size_t)w * max_n + n_sot + r0) * d * e;
+                SWX_TRY(logits_gemm(m, hid, d, nr, lg, s));
+                hipLaunchKernelGGL(token_prob_kernel, dim3(nr), dim3(256), 0, s, lg, D.n_vocab, eot, targets + (size_t)w * rpw + r0,
+                                   d_token_probs + (size_t)w * max_n + r0);
+            }
+        }
+        SWX_CHECK_LAUNCH();
+    }
+    // alignment matrix
+    SWX_TRY(swx_align_weights_launch(m->Wp<float>(m->L.cap), m->Wp<float>(m->L.cap), m->Wp<float>(m->L.mean), m->Wp<float>(m->L.sd),
+                                     W, m->n_align, max_n, D.n_audio_ctx, d_small, d_small + W, qk_scale, medfilt_width,
+                                     d_neg_matrix, max_n, D.n_audio_ctx, s));
+    return 0;
+}
+
+int swx_forward_logits(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, const void *d_xkv,
+                       float *d_logits, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (W <= 0) return 0;
+    const swx_dims &D = m->dims;
+    hipStream_t s = S(stream);
+    const int d = D.n_text_state;
+    SWX_TRY(score_forward(m, d_tokens, h_n_tok, W, max_n, 0, d_xkv, false, s));
+    unsigned char *x = m->ws + m->L.x, *hh = m->ws + m->L.h;
+    const int rows = W * max_n;
+    SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, rows, d, s));
+    return logits_gemm(m, hh, d, rows, d_logits, s);
+}
+
+// ----------------------------------------------------------------------------- stand-alone alignment weights
+int swx_align_weights(const float *d_qk, int W, int H, int N, int ld_f, const int32_t *h_n_frames, float qk_scale,
+                      int medfilt_width, float *d_neg_matrix, void *stream)
+{
+    // test hook / extra_models path: allocates its own scratch (the only call that does; not used on the hot path)
+    if (W <= 0) return 0;
+    hipStream_t s = S(stream);
+    float *p = nullptr, *mean = nullptr, *sd = nullptr;
+    int32_t *cnt = nullptr;
+    const size_t nel = (size_t)W * H * N * ld_f;
+    if (hipMalloc(&p, nel * 4) != hipSuccess) return -100;
+    if (hipMalloc(&mean, (size_t)W * H * ld_f * 4) != hipSuccess) return -100;
+    if (hipMalloc(&sd, (size_t)W * H * ld_f * 4) != hipSuccess) return -100;
+    if (hipMalloc(&cnt, (size_t)2 * W * 4) != hipSuccess) return -100;
+    std::vector<int32_t> hv(2 * W);
+    for (int w = 0; w < W; ++w) { hv[w] = N; hv[W + w] = h_n_frames[w]; }
+    hipMemcpy(cnt, hv.data(), hv.size() * 4, hipMemcpyHostToDevice);
+    int r = swx_align_weights_launch(d_qk, p, mean, sd, W, H, N, ld_f, cnt, cnt + W, qk_scale, medfilt_width, d_neg_matrix,
+                                     N, ld_f, s);
+    hipStreamSynchronize(s);
+    hipFree(p); hipFree(mean); hipFree(sd); hipFree(cnt);
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ test hooks
+int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
+                  void *d_c, int64_t ldc, int M, int N, int K, int epilogue, int force_kernel, void *stream)
+{
+    GemmArgs g = gemm_args(d_a, lda, d_w, K, d_bias, d_c, ldc, M, N, K, epilogue);
+    g.R = d_res; g.ldr = ldc;
+    return swx_gemm(dtype, g, force_kernel, S(stream));
+}
+
+int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float *d_b, void *d_y, int rows, int d, void *stream)
+{
+    return swx_layernorm(dtype, d_x, d, d_g, d_b, d_y, d, rows, d, S(stream));
+}
+
+int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k, const void *d_v, int64_t ldkv, void *d_o,
+                       int64_t ldo, int B, int H, int nq, int nk, int force_kernel, void *stream)
+{
+    AttnArgs a{};
+    a.q = d_q; a.ldq = ldq; a.k = d_k; a.v = d_v; a.ldkv = ldkv; a.o = d_o; a.ldo = ldo;
+    a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.q_rows_per_batch = nq;
+    return swx_attention(dtype, a, force_kernel, S(stream));
+}
+
+}  // extern "C"
