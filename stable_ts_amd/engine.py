@@ -1,0 +1,290 @@
+"""Engine -- thin Python owner of one swx_model handle (libswx.so) on one GPU.
+
+PyTorch is used for device memory (arena, workspace, I/O tensors) and streams only; every arithmetic step of the hot
+path is a libswx call.  Nothing here falls back to torch ops or to the CPU.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import SWX_F16, SWX_F32, check, swx_decode_cfg, swx_dims
+from .audio import N_FRAMES, N_SAMPLES, hann_window, slaney_mel_filterbank
+
+
+@dataclass
+class ModelDimensions:
+    n_mels: int
+    n_audio_ctx: int
+    n_audio_state: int
+    n_audio_head: int
+    n_audio_layer: int
+    n_vocab: int
+    n_text_ctx: int
+    n_text_state: int
+    n_text_head: int
+    n_text_layer: int
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _i32arr(vals: Sequence[int]):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+class Engine:
+    def __init__(self, dims: ModelDimensions, dtype: str = "f16", device: str = "cuda:0",
+                 max_windows: int = 1, max_rows: int = 5, alignment_heads: Optional[Sequence[Tuple[int, int]]] = None):
+        _lib.require_gpu()
+        self.lib = _lib.load()
+        self.dims = dims
+        self.dtype_name = dtype
+        self.dtype = {"f16": SWX_F16, "f32": SWX_F32}[dtype]
+        self.tdtype = torch.float16 if dtype == "f16" else torch.float32
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        cd = swx_dims(**{f: getattr(dims, f) for f, _ in swx_dims._fields_})
+        h = ctypes.c_void_p()
+        check(self.lib.swx_model_create(ctypes.byref(cd), self.dtype, ctypes.byref(h)), "swx_model_create")
+        self.h = h
+        nbytes = self.lib.swx_weights_bytes(self.h)
+        self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(self.lib.swx_bind_weights(self.h, _ptr(self.arena), nbytes), "swx_bind_weights")
+        self._load_constants()
+        if alignment_heads is not None:
+            self.set_alignment_heads(alignment_heads)
+        self.max_windows = 0
+        self.max_rows = 0
+        self.ws = None
+        self.reserve(max_windows, max_rows)
+
+    # ------------------------------------------------------------------ lifetime
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                torch.cuda.synchronize(self.device)
+                self.lib.swx_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reserve(self, max_windows: int, max_rows: int):
+        """(Re)bind a workspace large enough for `max_windows` windows and `max_rows` decoder sequences."""
+        max_rows = max(max_rows, max_windows)
+        if self.ws is not None and max_windows <= self.max_windows and max_rows <= self.max_rows and \
+                self.lib.swx_num_alignment_heads(self.h) == self._ws_heads:
+            return
+        torch.cuda.synchronize(self.device)
+        self.ws = None
+        nbytes = self.lib.swx_workspace_bytes(self.h, max_windows, max_rows)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(self.lib.swx_bind_workspace(self.h, _ptr(self.ws), nbytes, max_windows, max_rows), "swx_bind_workspace")
+        self.max_windows, self.max_rows = max_windows, max_rows
+        self._ws_heads = self.lib.swx_num_alignment_heads(self.h)
+
+    # ------------------------------------------------------------------ weights
+    def _load_one(self, name: str, t: torch.Tensor):
+        t = t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        check(self.lib.swx_load_tensor(self.h, name.encode(), _ptr(t), t.numel(), self.stream), f"load {name}")
+        torch.cuda.current_stream(self.device).synchronize()   # `t` may be freed right after
+
+    def _load_constants(self):
+        self._load_one("const.hann", hann_window())
+        self._load_one("const.mel_filters", torch.from_numpy(slaney_mel_filterbank(self.dims.n_mels)))
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        """`sd` uses the upstream checkpoint keys (encoder.blocks.N.attn.query.weight, ...)."""
+        for k, v in sd.items():
+            t = v.detach().to(device=self.device, dtype=torch.float32).contiguous()
+            rc = self.lib.swx_load_tensor(self.h, k.encode(), _ptr(t), t.numel(), self.stream)
+            if rc == -10:
+                if strict:
+                    raise _lib.SwxError(f"unexpected tensor in state dict: {k}")
+                continue
+            check(rc, f"load {k}")
+            torch.cuda.current_stream(self.device).synchronize()
+        if strict and not self.lib.swx_weights_complete(self.h):
+            buf = ctypes.create_string_buffer(256)
+            missing = []
+            i = 0
+            while self.lib.swx_missing_tensor(self.h, i, buf, 256) and i < 8:
+                missing.append(buf.value.decode())
+                i += 1
+            raise _lib.SwxError(f"missing tensors in state dict: {missing} ...")
+
+    def set_alignment_heads(self, pairs: Sequence[Tuple[int, int]]):
+        flat = [int(v) for p in pairs for v in p]
+        check(self.lib.swx_set_alignment_heads(self.h, _i32arr(flat), len(pairs)), "swx_set_alignment_heads")
+        self.alignment_heads = [tuple(p) for p in pairs]
+        if getattr(self, "ws", None) is not None:
+            mw, mr = self.max_windows, self.max_rows
+            self.max_windows = self.max_rows = 0
+            self.reserve(mw, mr)
+
+    @property
+    def n_alignment_heads(self) -> int:
+        return self.lib.swx_num_alignment_heads(self.h)
+
+    # ------------------------------------------------------------------ a1 mel
+    def log_mel(self, pcm: torch.Tensor, per_item_max: bool = False) -> torch.Tensor:
+        """pcm f32 [B, 480000] on this device -> f32 [B, n_mels, 3000]."""
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.shape[-1] == N_SAMPLES and pcm.is_contiguous()
+        B = pcm.shape[0]
+        self.reserve(max(B, self.max_windows), max(self.max_rows, 1))
+        mel = torch.empty(B, self.dims.n_mels, N_FRAMES, dtype=torch.float32, device=self.device)
+        check(self.lib.swx_log_mel(self.h, _ptr(pcm), B, _ptr(mel), int(per_item_max), self.stream), "swx_log_mel")
+        return mel
+
+    # ------------------------------------------------------------------ a2 encoder
+    def encode(self, mel: torch.Tensor) -> torch.Tensor:
+        assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous()
+        if mel.ndim == 2:
+            mel = mel[None]
+        B = mel.shape[0]
+        assert mel.shape[1:] == (self.dims.n_mels, N_FRAMES), mel.shape
+        self.reserve(max(B, self.max_windows), max(self.max_rows, 1))
+        xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, dtype=self.tdtype, device=self.device)
+        check(self.lib.swx_encode(self.h, _ptr(mel), B, _ptr(xa), self.stream), "swx_encode")
+        return xa
+
+    def cross_kv(self, xa: torch.Tensor) -> torch.Tensor:
+        B = xa.shape[0]
+        assert xa.dtype == self.tdtype and xa.is_contiguous()
+        nbytes = self.lib.swx_cross_kv_bytes(self.h, B)
+        xkv = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(self.lib.swx_cross_kv(self.h, _ptr(xa), B, _ptr(xkv), self.stream), "swx_cross_kv")
+        xkv.n_windows = B
+        return xkv
+
+    # ------------------------------------------------------------------ a3/a4 decode
+    def decode(self, xkv: torch.Tensor, init_tokens: Sequence[Sequence[int]], *, n_group: int = 1, beam: bool = False,
+               temperature: float = 0.0, patience: Optional[float] = None, sample_len: int = 224, sot_index: int = 0,
+               suppress_blank: bool = True, apply_timestamp_rules: bool = True,
+               max_initial_timestamp_index: Optional[int] = None, eot: int = 0, sot: int = 0, no_timestamps: int = -1,
+               timestamp_begin: int = 0, no_speech: int = -1, blank_token: int = -1,
+               suppress_tokens: Sequence[int] = (), ts_mask: Optional[torch.Tensor] = None, min_tokens: int = 0,
+               seed: int = 0):
+        W = len(init_tokens)
+        n_init = len(init_tokens[0])
+        assert all(len(t) == n_init for t in init_tokens), "all windows of a job share the initial length"
+        self.reserve(max(W, self.max_windows), max(W * n_group, self.max_rows))
+        cfg = swx_decode_cfg(
+            n_windows=W, n_group=n_group, beam=int(beam), temperature=float(temperature),
+            patience=float(patience or 0.0), sample_len=int(sample_len), sample_begin=n_init, sot_index=int(sot_index),
+            suppress_blank=int(suppress_blank), apply_timestamp_rules=int(apply_timestamp_rules),
+            max_initial_timestamp_index=-1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index),
+            eot=eot, sot=sot, no_timestamps=no_timestamps, timestamp_begin=timestamp_begin, no_speech=no_speech,
+            blank_token=blank_token, n_suppress=len(suppress_tokens), min_tokens=int(min_tokens), seed=int(seed))
+        g_out = self.lib.swx_decode_gout(ctypes.byref(cfg))
+        TS = self.dims.n_text_ctx + 1
+        d_init = torch.tensor(np.asarray(init_tokens, dtype=np.int32), device=self.device)
+        d_sup = torch.tensor(np.asarray(list(suppress_tokens) or [0], dtype=np.int32), device=self.device)
+        d_mask = None
+        if ts_mask is not None:
+            d_mask = ts_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            assert d_mask.shape == (W, 1501)
+        toks = torch.empty(W, g_out, TS, dtype=torch.int32, device=self.device)
+        lens = torch.empty(W, g_out, dtype=torch.int32, device=self.device)
+        sumlp = torch.empty(W, g_out, dtype=torch.float32, device=self.device)
+        nosp = torch.empty(W, dtype=torch.float32, device=self.device)
+        steps = check(self.lib.swx_decode(self.h, ctypes.byref(cfg), _ptr(d_init), _ptr(d_sup), _ptr(d_mask), _ptr(xkv),
+                                          _ptr(toks), _ptr(lens), _ptr(sumlp), _ptr(nosp), self.stream), "swx_decode")
+        return dict(tokens=toks.cpu().numpy(), lens=lens.cpu().numpy(), sum_logprobs=sumlp.cpu().numpy(),
+                    no_speech_prob=nosp.cpu().numpy(), steps=steps, sample_begin=n_init)
+
+    # ------------------------------------------------------------------ a6/a7 score
+    def score(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], n_frames: Sequence[int], n_sot: int, eot: int,
+              qk_scale: float = 1.0, medfilt_width: int = 7):
+        """tokens[w] = [*sot_sequence, no_timestamps, *text_tokens, eot].  Returns (token_probs list, neg_matrix
+        device tensor [W, max_n, 1500], T list)."""
+        W = len(tokens)
+        n_tok = [len(t) for t in tokens]
+        max_n = max(n_tok)
+        self.reserve(max(W, self.max_windows), max(self.max_rows, 1))
+        pad = np.full((W, max_n), eot, dtype=np.int32)
+        for w, t in enumerate(tokens):
+            pad[w, :len(t)] = t
+        d_tok = torch.tensor(pad, device=self.device)
+        probs = torch.zeros(W, max_n, dtype=torch.float32, device=self.device)
+        neg = torch.zeros(W, max_n, self.dims.n_audio_ctx, dtype=torch.float32, device=self.device)
+        check(self.lib.swx_score(self.h, _ptr(d_tok), _i32arr(n_tok), W, max_n, n_sot, eot, _i32arr(n_frames),
+                                 float(qk_scale), int(medfilt_width), _ptr(xkv), _ptr(probs), _ptr(neg), self.stream),
+              "swx_score")
+        T = [n - n_sot - 2 for n in n_tok]
+        p = probs.cpu().numpy()
+        return [p[w, :T[w]].astype(np.float64).tolist() for w in range(W)], neg, T
+
+    def forward_logits(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], pad_token: int = 0) -> torch.Tensor:
+        W = len(tokens)
+        n_tok = [len(t) for t in tokens]
+        max_n = max(n_tok)
+        self.reserve(max(W, self.max_windows), max(self.max_rows, 1))
+        pad = np.full((W, max_n), pad_token, dtype=np.int32)
+        for w, t in enumerate(tokens):
+            pad[w, :len(t)] = t
+        d_tok = torch.tensor(pad, device=self.device)
+        out = torch.empty(W, max_n, self.dims.n_vocab, dtype=torch.float32, device=self.device)
+        check(self.lib.swx_forward_logits(self.h, _ptr(d_tok), _i32arr(n_tok), W, max_n, _ptr(xkv), _ptr(out),
+                                          self.stream), "swx_forward_logits")
+        return out
+
+    # ------------------------------------------------------------------ a8 dtw
+    def dtw(self, x: torch.Tensor, N: Sequence[int], M: Sequence[int]):
+        """x f32 device [W, ld_n, ld_m] (the NEGATED alignment matrix); returns [(text_idx, time_idx)] int64 numpy."""
+        return dtw(x, N, M)
+
+
+def dtw(x: torch.Tensor, N: Sequence[int], M: Sequence[int]):
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.ndim == 3
+    W, ld_n, ld_m = x.shape
+    dev = x.device
+    dN = torch.tensor(np.asarray(N, dtype=np.int32), device=dev)
+    dM = torch.tensor(np.asarray(M, dtype=np.int32), device=dev)
+    cap = ld_n + ld_m
+    ti = torch.empty(W, cap, dtype=torch.int32, device=dev)
+    tj = torch.empty(W, cap, dtype=torch.int32, device=dev)
+    ln = torch.empty(W, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.swx_dtw_workspace_bytes(W, ld_n, ld_m), dtype=torch.uint8, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    check(lib.swx_dtw(_ptr(x), W, ld_n, ld_m, _ptr(dN), _ptr(dM), _ptr(ti), _ptr(tj), _ptr(ln), _ptr(ws), stream), "swx_dtw")
+    ti, tj, ln = ti.cpu().numpy(), tj.cpu().numpy(), ln.cpu().numpy()
+    return [(ti[w, :ln[w]].astype(np.int64), tj[w, :ln[w]].astype(np.int64)) for w in range(W)]
+
+
+def median_filter(x: torch.Tensor, width: int) -> torch.Tensor:
+    """whisper.timing.median_filter on the device (f32, last axis)."""
+    lib = _lib.load()
+    assert x.is_cuda and x.dtype == torch.float32
+    xc = x.contiguous()
+    n = xc.shape[-1]
+    rows = xc.numel() // n
+    out = torch.empty_like(xc)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+    # the kernel's grid.y carries the row index: chunk it
+    flat_in, flat_out = xc.view(rows, n), out.view(rows, n)
+    for r0 in range(0, rows, 65535):
+        r1 = min(rows, r0 + 65535)
+        check(lib.swx_median_filter(_ptr(flat_in[r0:r1]), r1 - r0, n, width, _ptr(flat_out[r0:r1]), stream), "swx_median_filter")
+    return out
+
+
+def align_weights(qk: torch.Tensor, n_frames: Sequence[int], qk_scale: float = 1.0, medfilt_width: int = 7) -> torch.Tensor:
+    """qk f32 device [W, H, N, ld_f] raw scaled attention logits -> NEGATED mean matrix [W, N, ld_f]."""
+    lib = _lib.load()
+    assert qk.is_cuda and qk.dtype == torch.float32 and qk.is_contiguous() and qk.ndim == 4
+    W, H, N, ld_f = qk.shape
+    out = torch.zeros(W, N, ld_f, dtype=torch.float32, device=qk.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(qk.device).cuda_stream)
+    check(lib.swx_align_weights(_ptr(qk), W, H, N, ld_f, _i32arr(n_frames), float(qk_scale), int(medfilt_width), _ptr(out),
+                                stream), "swx_align_weights")
+    return out

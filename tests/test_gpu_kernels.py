@@ -1,0 +1,285 @@
+"""GPU parity tests of the individual HIP kernels, through the C ABI, against the CPU oracle (oracle/whisper/*).
+
+bit-exact: DTW paths, median filter.   Tolerances (stated per test) for floating-point kernels.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.whisper import audio as oa
+from oracle.whisper import timing as ot
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from stable_ts_amd import _lib
+    return _lib.load()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------------------- DTW
+def _dtw_case(shape, quant=None, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal(shape).astype(np.float32)
+    if quant:
+        x = (np.round(x * quant) / quant).astype(np.float32)
+    return x
+
+
+@pytest.mark.parametrize("shape,quant", [((1, 1), None), ((1, 9), None), ((9, 1), None), ((3, 5), 1), ((7, 31), None),
+                                         ((23, 57), 4), ((64, 200), 2), ((65, 333), None), ((130, 700), 3),
+                                         ((226, 1500), None), ((226, 1500), 2), ((448, 1500), None), ((446, 1377), 1)])
+def test_dtw_bit_exact(shape, quant):
+    from stable_ts_amd.engine import dtw
+    x = _dtw_case(shape, quant, seed=shape[0] * 7 + shape[1])
+    ref_i, ref_j = ot.dtw_cpu(x.astype(np.float64))
+    (ti, tj), = dtw(torch.from_numpy(x)[None].cuda().contiguous(), [shape[0]], [shape[1]])
+    assert ti.tolist() == ref_i.tolist()
+    assert tj.tolist() == ref_j.tolist()
+
+
+def test_dtw_known_answer_and_batch_ragged():
+    from stable_ts_amd.engine import dtw
+    # SURVEY.md 8c known-answer vector + a ragged batch inside one padded tensor
+    shapes = [(3, 5), (100, 1500), (37, 911), (1, 1), (225, 1499)]
+    ld_n, ld_m = 226, 1500
+    X = np.full((len(shapes), ld_n, ld_m), np.nan, dtype=np.float32)
+    refs = []
+    for k, (n, m) in enumerate(shapes):
+        x = np.zeros((n, m), np.float32) if k == 0 else _dtw_case((n, m), 3 if k % 2 else None, seed=k)
+        X[k, :n, :m] = x
+        refs.append(ot.dtw_cpu(x.astype(np.float64)))
+    out = dtw(torch.from_numpy(X).cuda(), [s[0] for s in shapes], [s[1] for s in shapes])
+    assert out[0][0].tolist() == [0, 1, 2, 2, 2, 2, 2] and out[0][1].tolist() == [0, 0, 0, 1, 2, 3, 4]
+    for (ti, tj), (ri, rj) in zip(out, refs):
+        assert ti.tolist() == ri.tolist() and tj.tolist() == rj.tolist()
+
+
+def test_dtw_path_properties_full_size():
+    # size-independent properties at the maximum size: monotone, unit steps, endpoints, length bounds
+    from stable_ts_amd.engine import dtw
+    n, m = 448, 1500
+    x = _dtw_case((n, m), None, seed=99)
+    (ti, tj), = dtw(torch.from_numpy(x)[None].cuda().contiguous(), [n], [m])
+    assert (ti[0], tj[0]) == (0, 0) and (ti[-1], tj[-1]) == (n - 1, m - 1)
+    di, dj = np.diff(ti), np.diff(tj)
+    assert ((di == 0) | (di == 1)).all() and ((dj == 0) | (dj == 1)).all() and ((di + dj) >= 1).all()
+    assert max(n, m) <= len(ti) <= n + m - 1
+
+
+# --------------------------------------------------------------------------------------------------- median filter
+@pytest.mark.parametrize("shape,width", [((3, 17, 211), 7), ((2, 5, 1500), 7), ((4, 9), 7), ((5, 3), 7), ((2, 64), 5), ((1, 100), 3)])
+def test_median_filter_bit_exact(shape, width):
+    from stable_ts_amd.engine import median_filter
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1))
+    ref = ot.median_filter(x, width)
+    got = median_filter(x.cuda(), width).cpu()
+    assert torch.equal(got, ref)
+
+
+# ------------------------------------------------------------------------------------------------- align weights
+def _align_ref(qk, F, qk_scale=1.0, width=7):
+    w = qk[..., :F]
+    w = (w * qk_scale).softmax(dim=-1)
+    std, mean = torch.std_mean(w, dim=-2, keepdim=True, unbiased=False)
+    w = (w - mean) / std
+    w = ot.median_filter(w, width)
+    return -(w.mean(dim=0))
+
+
+@pytest.mark.parametrize("H,N,F", [(5, 12, 300), (10, 101, 1500), (6, 40, 777), (3, 7, 3)])
+def test_align_weights_matches_reference_formula(H, N, F):
+    # timing.py:105-110 + :194-195 on the CPU vs the fused kernels; tolerance 2e-5 abs on z-scores of O(1)
+    from stable_ts_amd.engine import align_weights
+    g = torch.Generator().manual_seed(H * 100 + N)
+    qk = torch.randn(1, H, N, 1500, generator=g) * 2.0
+    ref = _align_ref(qk[0], F)
+    got = align_weights(qk.cuda().contiguous(), [F]).cpu()[0, :, :F]
+    torch.testing.assert_close(got, ref, rtol=0, atol=2e-5)
+
+
+def test_align_then_dtw_path_equals_oracle():
+    from stable_ts_amd.engine import align_weights, dtw
+    g = torch.Generator().manual_seed(5)
+    H, N, F = 8, 60, 1234
+    # peaky, roughly monotone attention so that the path is meaningful
+    base = -0.5 * ((torch.arange(1500)[None, :] - torch.linspace(30, 1200, N)[:, None]) / 25.0) ** 2
+    qk = base[None, None] + 0.3 * torch.randn(1, H, N, 1500, generator=g)
+    ref = _align_ref(qk[0], F)
+    neg = align_weights(qk.cuda().contiguous(), [F])
+    (ti, tj), = dtw(neg, [N], [F])
+    ri, rj = ot.dtw_cpu(ref.double().numpy())
+    # the matrices agree to ~1e-6, so the DTW paths must coincide except at exact cost ties (none here)
+    assert ti.tolist() == ri.tolist() and tj.tolist() == rj.tolist()
+
+
+# -------------------------------------------------------------------------------------------------------- mel
+def _audio(n, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n) / 16000.0
+    x = 0.3 * torch.sin(2 * np.pi * 440 * t) * (0.5 + 0.5 * torch.sin(2 * np.pi * 3 * t))
+    x += 0.1 * torch.sin(2 * np.pi * 1234.5 * t) + 0.01 * torch.randn(n, generator=g)
+    x[40000:52000] = 0
+    return x.float()
+
+
+def _engine_for_mel(n_mels):
+    from stable_ts_amd.engine import Engine, ModelDimensions
+    dims = ModelDimensions(n_mels, 1500, 64, 1, 1, 51864, 448, 64, 1, 1)
+    return Engine(dims, dtype="f32", max_windows=2, max_rows=2)
+
+
+@pytest.mark.parametrize("n_mels", [80, 128])
+def test_log_mel_matches_oracle(n_mels):
+    # tolerance: 1e-3 abs in (log10+4)/4 units (an f32 FFT on the CPU side carries ~1e-4 of its own near the clamp floor);
+    # median error is required to be ~1e-6
+    eng = _engine_for_mel(n_mels)
+    x = torch.stack([_audio(480000, 1), oa.pad_or_trim(_audio(200000, 2) * 0.1, 480000)])
+    got = eng.log_mel(x.cuda().contiguous(), per_item_max=True).cpu()
+    for b in range(2):
+        ref = oa.log_mel_spectrogram(x[b], n_mels)
+        err = (got[b] - ref).abs()
+        assert err.max().item() < 1e-3, err.max().item()
+        assert err.median().item() < 5e-6, err.median().item()
+    # batch-global max (upstream quirk used by refine): equals oracle on the stacked batch
+    got2 = eng.log_mel(x.cuda().contiguous(), per_item_max=False).cpu()
+    ref2 = oa.log_mel_spectrogram(x, n_mels)
+    assert (got2 - ref2).abs().max().item() < 1e-3
+
+
+def test_log_mel_silence_and_short():
+    eng = _engine_for_mel(80)
+    x = torch.zeros(1, 480000)
+    got = eng.log_mel(x.cuda(), per_item_max=True).cpu()
+    ref = oa.log_mel_spectrogram(x[0], 80)
+    assert torch.allclose(got[0], ref, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------------- gemm
+def _gemm(dtype, a, w, bias=None, res=None, epi=0, force=0, out_f32=False):
+    lib = _lib()
+    M, K = a.shape
+    N = w.shape[0]
+    tdt = torch.float16 if dtype == 1 else torch.float32
+    c = torch.empty(M, N, dtype=torch.float32 if out_f32 else tdt, device="cuda")
+    rc = lib.swx_test_gemm(dtype, _p(a), a.stride(0), _p(w), None if bias is None else _p(bias),
+                           None if res is None else _p(res), _p(c), N, M, N, K, epi, force, _stream())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return c
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1500, 384, 384), (300, 1152, 384), (77, 130, 96), (3000, 384, 288),
+                                   (16, 1280, 1280), (5, 51866, 384), (100, 512, 2048)])
+def test_gemm_f16_tiled_and_skinny(M, N, K):
+    # A=asymmetric random (G9): f16 inputs, f32 accumulate; reference = f64 matmul of the same f16 values.
+    # tolerance: 2e-3 relative to the row/col magnitude (one f16 rounding of the output)
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.5).half().cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = (a.double() @ w.double().T + bias.double())
+    kinds = [1] + ([2] if (M <= 128 and K % 128 == 0) else [])
+    for force in kinds:
+        c = _gemm(1, a, w, bias=bias, epi=1, force=force)
+        err = (c.double() - ref).abs().max().item()
+        scale = ref.abs().max().item()
+        assert err <= 2e-3 * scale + 1e-3, (force, err, scale)
+        c32 = _gemm(1, a, w, bias=bias, epi=1 | 8, force=force, out_f32=True)
+        err = (c32.double() - ref).abs().max().item()
+        assert err <= 2e-5 * scale * max(1.0, (K / 256) ** 0.5) + 1e-4, (force, err, scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (1500, 384, 384), (77, 130, 96), (3000, 384, 240), (5, 51864, 384)])
+def test_gemm_f32_exact_mode(M, N, K):
+    # exact-f32 MFMA: error vs f64 is f32 round-off only: <= 2e-6 * sum|a||b| bound, checked as 3e-6 relative
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    ref = a.double() @ w.double().T + bias.double()
+    c = _gemm(0, a, w, bias=bias, epi=1)
+    bound = (a.double().abs() @ w.double().abs().T + bias.double().abs())
+    assert ((c.double() - ref).abs() <= 3e-6 * bound + 1e-6).all()
+
+
+def test_gemm_epilogues():
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 200, 256, 128
+    for dtype, tdt, tol in ((0, torch.float32, 1e-5), (1, torch.float16, 4e-3)):
+        a = (torch.randn(M, K, generator=g) * 0.3).to(tdt).cuda()
+        w = (torch.randn(N, K, generator=g) * 0.3).to(tdt).cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        res = torch.randn(M, N, generator=g).to(tdt).cuda()
+        lin = a.double() @ w.double().T + bias.double()
+        gelu = torch.nn.functional.gelu(lin)
+        c = _gemm(dtype, a, w, bias=bias, epi=1 | 2)
+        assert (c.double() - gelu).abs().max().item() < tol * max(1.0, gelu.abs().max().item())
+        c = _gemm(dtype, a, w, bias=bias, res=res, epi=1 | 4)
+        assert (c.double() - (lin + res.double())).abs().max().item() < tol * max(1.0, lin.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_layernorm(dtype):
+    lib = _lib()
+    tdt = torch.float16 if dtype else torch.float32
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(301, 384, generator=g) * 3 + 1).to(tdt).cuda()
+    gam = torch.randn(384, generator=g).cuda()
+    bet = torch.randn(384, generator=g).cuda()
+    y = torch.empty_like(x)
+    assert lib.swx_test_layernorm(dtype, _p(x), _p(gam), _p(bet), _p(y), 301, 384, _stream()) == 0
+    ref = torch.nn.functional.layer_norm(x.float(), (384,), gam, bet, 1e-5)
+    tol = 2e-3 if dtype else 2e-5
+    assert (y.float() - ref).abs().max().item() < tol * ref.abs().max().item()
+
+
+# --------------------------------------------------------------------------------------------------- attention
+def _attn(dtype, q, k, v, force):
+    lib = _lib()
+    B, nq, Hd = q.shape
+    nk = k.shape[1]
+    H = Hd // 64
+    o = torch.empty_like(q)
+    rc = lib.swx_test_attention(dtype, _p(q), Hd, _p(k), _p(v), Hd, _p(o), Hd, B, H, nq, nk, force, _stream())
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return o
+
+
+def _attn_ref(q, k, v):
+    B, nq, Hd = q.shape
+    H = Hd // 64
+    qh = q.double().view(B, nq, H, 64).permute(0, 2, 1, 3)
+    kh = k.double().view(B, -1, H, 64).permute(0, 2, 1, 3)
+    vh = v.double().view(B, -1, H, 64).permute(0, 2, 1, 3)
+    w = (qh @ kh.transpose(-1, -2) * 0.125).softmax(-1)
+    return (w @ vh).permute(0, 2, 1, 3).reshape(B, nq, Hd)
+
+
+@pytest.mark.parametrize("B,H,nq,nk", [(1, 2, 64, 64), (2, 3, 1500, 1500), (1, 6, 100, 1500), (2, 2, 5, 1500), (1, 1, 17, 70)])
+def test_attention_kernels(B, H, nq, nk):
+    g = torch.Generator().manual_seed(B * 100 + nq)
+    q = torch.randn(B, nq, H * 64, generator=g)
+    k = torch.randn(B, nk, H * 64, generator=g)
+    v = torch.randn(B, nk, H * 64, generator=g)   # asymmetric random V catches any d<->key transposition
+    # f32 rowwise: 1e-5
+    o = _attn(0, q.cuda(), k.cuda(), v.cuda(), 1)
+    ref = _attn_ref(q, k, v)
+    assert (o.cpu().double() - ref).abs().max().item() < 2e-5
+    qh, kh, vh = q.half(), k.half(), v.half()
+    refh = _attn_ref(qh, kh, vh)
+    for force in (1, 2):   # rowwise f16, flash MFMA f16
+        o = _attn(1, qh.cuda(), kh.cuda(), vh.cuda(), force)
+        err = (o.cpu().double() - refh).abs().max().item()
+        assert err < 6e-3, (force, err)

@@ -1,0 +1,239 @@
+"""GPU parity of the model-level entry points of libswx (encoder, teacher-forced logits, decoding loop, scoring +
+alignment matrix + DTW) against the CPU oracle with the SAME seeded random weights at real architecture dims.
+
+Strict mode (dtype f32) is held to the north-star bar: identical token ids, bit-exact DTW paths, logprobs within 1e-3.
+The fp16 mode (what the reference itself runs on a GPU) is held to fp16 tolerances and reported as agreement.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stable as ost
+from oracle.whisper import model as om
+from oracle.whisper.decoding import DecodingOptions
+from oracle.whisper.tokenizer import get_tokenizer
+
+pytestmark = pytest.mark.gpu
+
+_CACHE = {}
+
+
+def _dims(name):
+    return om.dims_for(name)
+
+
+def _oracle(name, seed=1234, std=0.02, gain=3.0, heads=None):
+    key = ("o", name, seed, std, gain, heads)
+    if key not in _CACHE:
+        m = om.build_model(name, seed=seed, std=std, embed_gain=gain)
+        if heads is not None:
+            mask = torch.zeros(m.dims.n_text_layer, m.dims.n_text_head, dtype=torch.bool)
+            for l, h in heads:
+                mask[l, h] = True
+            m.set_alignment_heads_mask(mask)
+        _CACHE[key] = m
+    return _CACHE[key]
+
+
+def _engine(name, dtype, seed=1234, std=0.02, gain=3.0, heads=None, max_windows=2, max_rows=10):
+    from stable_ts_amd.engine import Engine, ModelDimensions
+    key = ("e", name, dtype, seed, std, gain, heads)
+    if key not in _CACHE:
+        d = _dims(name)
+        eng = Engine(ModelDimensions(**d.__dict__), dtype=dtype, max_windows=max_windows, max_rows=max_rows,
+                     alignment_heads=heads)
+        eng.load_state_dict(om.random_state_dict(d, seed, std, gain))
+        _CACHE[key] = eng
+    return _CACHE[key]
+
+
+def _mel(n_mels, seed=0, B=1):
+    g = torch.Generator().manual_seed(seed)
+    t = torch.linspace(0, 1, 3000)
+    base = torch.sin(t[None, None, :] * (5 + torch.arange(n_mels)[None, :, None] * 0.37)) * 0.5
+    return (base + 0.3 * torch.randn(B, n_mels, 3000, generator=g)).float()
+
+
+HEADS_TINY = ((2, 1), (2, 4), (3, 0), (3, 2), (3, 5))
+
+
+@pytest.mark.parametrize("name", ["tiny.en", "base.en"])
+def test_encoder_f32(name):
+    m, eng = _oracle(name), _engine(name, "f32")
+    mel = _mel(m.dims.n_mels, 1, B=2)
+    with torch.no_grad():
+        ref = m.encoder(mel)
+    got = eng.encode(mel.cuda().contiguous()).cpu()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_encoder_f16_tiny():
+    m, eng = _oracle("tiny.en"), _engine("tiny.en", "f16")
+    mel = _mel(80, 2, B=2)
+    with torch.no_grad():
+        ref = m.encoder(mel)
+    got = eng.encode(mel.cuda().contiguous()).float().cpu()
+    # fp16 storage of activations through 4 layers: 3e-2 abs on LN-normalised outputs of O(1)
+    err = (got - ref).abs()
+    assert err.max().item() < 6e-2 and err.mean().item() < 6e-3, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("name,dtype,tol", [("tiny.en", "f32", 1e-3), ("base.en", "f32", 1e-3), ("tiny.en", "f16", 0.25)])
+def test_forward_logits(name, dtype, tol):
+    m, eng = _oracle(name), _engine(name, dtype)
+    mel = _mel(m.dims.n_mels, 3, B=2)
+    g = torch.Generator().manual_seed(11)
+    toks = [torch.randint(0, 50000, (n,), generator=g).tolist() for n in (37, 20)]
+    with torch.no_grad():
+        xa = m.encoder(mel)
+        refs = [m.decoder(torch.tensor([t]), xa[i:i + 1])[0] for i, t in enumerate(toks)]
+    xkv = eng.cross_kv(eng.encode(mel.cuda().contiguous()))
+    got = eng.forward_logits(xkv, toks).cpu()
+    for i, t in enumerate(toks):
+        err = (got[i, :len(t)] - refs[i]).abs().max().item()
+        assert err < tol, (i, err)
+        lp_err = (got[i, :len(t)].log_softmax(-1) - refs[i].log_softmax(-1)).abs().max().item()
+        assert lp_err < tol, (i, lp_err)
+
+
+def _tok_cfg(tok, task):
+    return dict(eot=tok.eot, sot=tok.sot, no_timestamps=tok.no_timestamps, timestamp_begin=tok.timestamp_begin,
+                no_speech=tok.no_speech, blank_token=tok.encode(" ")[0], suppress_tokens=list(task._get_suppress_tokens()))
+
+
+def _rank(out, w):
+    """upstream MaximumLikelihoodRanker with length_penalty=None: argmax of sum_logprob / length"""
+    scores = []
+    for k in range(out["tokens"].shape[1]):
+        ln = int(out["lens"][w, k])
+        scores.append(-np.inf if ln < 0 else (out["sum_logprobs"][w, k] / ln if ln > 0 else -np.inf))
+    return int(np.argmax(scores))
+
+
+def _oracle_decode(m, mel, **opt):
+    min_tokens = opt.pop("min_tokens", 0)
+    ts_mask = opt.pop("ts_token_mask", None)
+    options = DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, **opt)
+    return ost.decode_stable(m, mel, options, ts_token_mask=ts_mask, min_tokens=min_tokens)
+
+
+@pytest.mark.parametrize("name,gain,opts", [
+    ("tiny.en", 3.0, dict(sample_len=40, min_tokens=40)),
+    ("tiny.en", 9.0, dict(sample_len=40, min_tokens=40)),
+    ("tiny.en", 3.0, dict(sample_len=24, min_tokens=0)),
+    ("base.en", 3.0, dict(sample_len=30, min_tokens=30, prompt=[1000, 2000, 3001, 40000, 7])),
+    ("tiny.en", 3.0, dict(sample_len=32, min_tokens=32, beam_size=5)),
+    ("tiny.en", 2.0, dict(sample_len=32, min_tokens=32, beam_size=5)),
+    ("tiny.en", 3.0, dict(sample_len=40, min_tokens=6, beam_size=3, patience=2.0)),
+    ("base.en", 3.0, dict(sample_len=28, min_tokens=28, beam_size=5, prompt=[555, 666])),
+])
+def test_decode_strict_f32_identical_tokens(name, gain, opts):
+    m, eng = _oracle(name, gain=gain), _engine(name, "f32", gain=gain)
+    mels = _mel(m.dims.n_mels, 21, B=2)
+    opts = dict(opts)
+    for w in range(2):
+        res, _ = _oracle_decode(m, mels[w], **dict(opts))
+        task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None,
+                                                         **{k: v for k, v in opts.items() if k != "min_tokens"}))
+        tok = task.tokenizer
+        xkv = eng.cross_kv(eng.encode(mels[w:w + 1].cuda().contiguous()))
+        out = eng.decode(xkv, [list(task.initial_tokens)], n_group=task.n_group, beam=opts.get("beam_size") is not None,
+                         patience=opts.get("patience"), sample_len=task.sample_len, sot_index=task.sot_index,
+                         min_tokens=opts.get("min_tokens", 0), **_tok_cfg(tok, task))
+        sb = out["sample_begin"]
+        best = _rank(out, 0)
+        got_tokens = out["tokens"][0, best, sb: sb + int(out["lens"][0, best])].tolist()
+        assert got_tokens == res.tokens, (w, got_tokens, res.tokens)
+        got_avg = out["sum_logprobs"][0, best] / (len(got_tokens) + 1)
+        assert abs(got_avg - res.avg_logprob) < 1e-3
+        assert abs(out["no_speech_prob"][0] - res.no_speech_prob) < 1e-4 + 1e-2 * res.no_speech_prob
+
+
+def test_decode_batched_windows_equal_single():
+    # W windows decoded in lockstep == each window decoded alone (the sharding / batching contract)
+    name = "tiny.en"
+    m, eng = _oracle(name), _engine(name, "f32")
+    mels = _mel(80, 31, B=2)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=20, beam_size=5))
+    tok = task.tokenizer
+    kw = dict(n_group=5, beam=True, sample_len=20, sot_index=task.sot_index, min_tokens=20, **_tok_cfg(tok, task))
+    xkv2 = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    both = eng.decode(xkv2, [list(task.initial_tokens)] * 2, **kw)
+    for w in range(2):
+        xkv1 = eng.cross_kv(eng.encode(mels[w:w + 1].cuda().contiguous()))
+        one = eng.decode(xkv1, [list(task.initial_tokens)], **kw)
+        assert np.array_equal(one["tokens"][0], both["tokens"][w])
+        assert np.allclose(one["sum_logprobs"][0], both["sum_logprobs"][w], atol=1e-4)
+
+
+def test_decode_ts_mask_and_greedy_eot():
+    name = "tiny.en"
+    m, eng = _oracle(name), _engine(name, "f32")
+    mel = _mel(80, 41, B=1)
+    mask = torch.zeros(1501, dtype=torch.bool)
+    mask[::3] = True
+    mask[100:400] = True
+    res, _ = _oracle_decode(m, mel[0], sample_len=36, min_tokens=30, ts_token_mask=mask)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=36))
+    xkv = eng.cross_kv(eng.encode(mel.cuda().contiguous()))
+    out = eng.decode(xkv, [list(task.initial_tokens)], sample_len=36, sot_index=task.sot_index, min_tokens=30,
+                     ts_mask=mask[None], **_tok_cfg(task.tokenizer, task))
+    sb = out["sample_begin"]
+    got = out["tokens"][0, 0, sb: sb + int(out["lens"][0, 0])].tolist()
+    assert got == res.tokens
+
+
+def test_decode_f16_agreement_tiny():
+    # fp16 weights/activations vs the fp32 oracle on random weights: report agreement of the greedy token stream;
+    # the first tokens must agree (divergence later is the expected near-tie effect of random logits)
+    name = "tiny.en"
+    m, eng = _oracle(name), _engine(name, "f16")
+    mel = _mel(80, 51, B=1)
+    res, _ = _oracle_decode(m, mel[0], sample_len=24, min_tokens=24)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=24))
+    xkv = eng.cross_kv(eng.encode(mel.cuda().contiguous()))
+    out = eng.decode(xkv, [list(task.initial_tokens)], sample_len=24, sot_index=task.sot_index, min_tokens=24,
+                     **_tok_cfg(task.tokenizer, task))
+    sb = out["sample_begin"]
+    got = out["tokens"][0, 0, sb: sb + int(out["lens"][0, 0])].tolist()
+    n_same = 0
+    for a, b in zip(got, res.tokens):
+        if a != b:
+            break
+        n_same += 1
+    assert n_same >= 3, (got, res.tokens)
+
+
+@pytest.mark.parametrize("name,heads", [("tiny.en", HEADS_TINY), ("base.en", None)])
+def test_score_alignment_dtw_strict(name, heads):
+    m, eng = _oracle(name, heads=heads), _engine(name, "f32", heads=heads)
+    if heads is None:
+        heads_list = [tuple(p) for p in m.alignment_heads.indices().T.tolist()]
+        eng.set_alignment_heads(heads_list)
+    tok = get_tokenizer(False, num_languages=m.num_languages)
+    mels = _mel(m.dims.n_mels, 61, B=2)
+    g = torch.Generator().manual_seed(5)
+    texts = [torch.randint(18, 50000, (n,), generator=g).tolist() for n in (57, 23)]
+    num_samples = [480000, 301234]
+    toks, refs = [], []
+    for w in range(2):
+        wt, cache = ost.find_alignment(m, tok, texts[w], mels[w], num_samples[w], return_cache=True)
+        refs.append((wt, cache))
+        toks.append([*tok.sot_sequence, tok.no_timestamps, *texts[w], tok.eot])
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    n_frames = [round(n / 320) for n in num_samples]
+    probs, neg, T = eng.score(xkv, toks, n_frames, n_sot=len(tok.sot_sequence), eot=tok.eot)
+    paths = eng.dtw(neg, [t + 1 for t in T], n_frames)
+    for w in range(2):
+        wt, cache = refs[w]
+        ref_p = np.asarray(cache["text_token_probs"])
+        assert np.abs(np.asarray(probs[w]) - ref_p).max() < 1e-3 * max(1e-3, ref_p.max()) + 1e-7
+        ref_neg = cache["neg_matrix"]
+        got_neg = neg[w, :T[w] + 1, :n_frames[w]].cpu()
+        assert (got_neg - ref_neg).abs().max().item() < 2e-3
+        # DTW: the kernel on the ORACLE's matrix is bit-exact (tests/test_gpu_kernels.py); on the GPU's own matrix the
+        # path must coincide too unless two cumulative costs tie to within f32 round-off
+        ri, rj = cache["dtw_path"]
+        ti, tj = paths[w]
+        assert ti.tolist() == ri.tolist() and tj.tolist() == rj.tolist()
