@@ -1,0 +1,269 @@
+"""The model object: same attribute surface the reference's glue reads from ``whisper.model.Whisper`` after
+``stable_whisper.load_model`` / ``modify_model`` (whisper_word_level/original_whisper.py:931-1009; SURVEY.md 8b seam B1),
+backed by an ``Engine`` (libswx.so) instead of torch modules.
+"""
+import os
+import types
+import warnings
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from .audio import N_FRAMES, N_SAMPLES
+from .engine import Engine, ModelDimensions
+
+# upstream architecture table (whisper/__init__.py::_MODELS dims; facts)
+_DIMS = {
+    "tiny.en": (80, 1500, 384, 6, 4, 51864, 448, 384, 6, 4),
+    "tiny": (80, 1500, 384, 6, 4, 51865, 448, 384, 6, 4),
+    "base.en": (80, 1500, 512, 8, 6, 51864, 448, 512, 8, 6),
+    "base": (80, 1500, 512, 8, 6, 51865, 448, 512, 8, 6),
+    "small.en": (80, 1500, 768, 12, 12, 51864, 448, 768, 12, 12),
+    "small": (80, 1500, 768, 12, 12, 51865, 448, 768, 12, 12),
+    "medium.en": (80, 1500, 1024, 16, 24, 51864, 448, 1024, 16, 24),
+    "medium": (80, 1500, 1024, 16, 24, 51865, 448, 1024, 16, 24),
+    "large-v1": (80, 1500, 1280, 20, 32, 51865, 448, 1280, 20, 32),
+    "large-v2": (80, 1500, 1280, 20, 32, 51865, 448, 1280, 20, 32),
+    "large-v3": (128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 32),
+    "large": (128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 32),
+    "large-v3-turbo": (128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 4),
+    "turbo": (128, 1500, 1280, 20, 32, 51866, 448, 1280, 20, 4),
+}
+
+
+def available_models() -> List[str]:
+    return list(_DIMS)
+
+
+def dims_for(name: str) -> ModelDimensions:
+    return ModelDimensions(*_DIMS[name])
+
+
+def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> torch.Tensor:
+    """Encoder positional embedding (a buffer in upstream checkpoints; regenerated when a state dict lacks it)."""
+    inc = np.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    t = torch.arange(length)[:, None] * inv[None, :]
+    return torch.cat([torch.sin(t), torch.cos(t)], dim=1)
+
+
+def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Seeded random weights under the upstream checkpoint keys (no checkpoint exists offline).  Same generator order
+    as the test oracle so that both sides see identical weights for a given seed."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    da, dt = dims.n_audio_state, dims.n_text_state
+
+    def rnd(*shape, s=std):
+        return torch.randn(*shape, generator=g) * s
+
+    def ln(prefix, d):
+        sd[prefix + ".weight"] = torch.ones(d)
+        sd[prefix + ".bias"] = torch.zeros(d)
+
+    def attn(prefix, d):
+        sd[prefix + ".query.weight"] = rnd(d, d)
+        sd[prefix + ".query.bias"] = rnd(d)
+        sd[prefix + ".key.weight"] = rnd(d, d)
+        sd[prefix + ".value.weight"] = rnd(d, d)
+        sd[prefix + ".value.bias"] = rnd(d)
+        sd[prefix + ".out.weight"] = rnd(d, d)
+        sd[prefix + ".out.bias"] = rnd(d)
+
+    def block(prefix, d, cross):
+        attn(prefix + ".attn", d)
+        ln(prefix + ".attn_ln", d)
+        if cross:
+            attn(prefix + ".cross_attn", d)
+            ln(prefix + ".cross_attn_ln", d)
+        sd[prefix + ".mlp.0.weight"] = rnd(4 * d, d)
+        sd[prefix + ".mlp.0.bias"] = rnd(4 * d)
+        sd[prefix + ".mlp.2.weight"] = rnd(d, 4 * d)
+        sd[prefix + ".mlp.2.bias"] = rnd(d)
+        ln(prefix + ".mlp_ln", d)
+
+    # order follows nn.Module.state_dict() of upstream's Whisper (encoder first)
+    sd["encoder.positional_embedding"] = sinusoids(dims.n_audio_ctx, da)
+    sd["encoder.conv1.weight"] = rnd(da, dims.n_mels, 3)
+    sd["encoder.conv1.bias"] = rnd(da)
+    sd["encoder.conv2.weight"] = rnd(da, da, 3)
+    sd["encoder.conv2.bias"] = rnd(da)
+    for i in range(dims.n_audio_layer):
+        block(f"encoder.blocks.{i}", da, False)
+    ln("encoder.ln_post", da)
+    sd["decoder.positional_embedding"] = torch.randn(dims.n_text_ctx, dt, generator=g) * 0.01
+    sd["decoder.token_embedding.weight"] = rnd(dims.n_vocab, dt, s=std * embed_gain)
+    for i in range(dims.n_text_layer):
+        block(f"decoder.blocks.{i}", dt, True)
+    ln("decoder.ln", dt)
+    return sd
+
+
+class SparseHeads:
+    """Stand-in for the sparse bool tensor ``model.alignment_heads`` (timing.py:105 calls ``.indices().T``)."""
+
+    def __init__(self, pairs: Sequence[Tuple[int, int]]):
+        self.pairs = [tuple(p) for p in pairs]
+
+    def indices(self) -> torch.Tensor:
+        return torch.tensor(self.pairs, dtype=torch.long).reshape(-1, 2).T
+
+    def __len__(self):
+        return len(self.pairs)
+
+
+class Whisper:
+    """MI355X-native Whisper.  ``model.transcribe / align / align_words`` are bound like the reference's
+    ``modify_model`` does (original_whisper.py:931-949)."""
+
+    def __init__(self, dims: ModelDimensions, device: Union[str, torch.device] = "cuda:0", dtype: str = "f16",
+                 alignment_heads: Optional[Sequence[Tuple[int, int]]] = None, max_windows: int = 1, max_rows: int = 5):
+        self.dims = dims
+        if alignment_heads is None:   # upstream default: every head of the upper half of the decoder
+            alignment_heads = [(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)]
+        self.engine = Engine(dims, dtype=dtype, device=str(device), max_windows=max_windows, max_rows=max_rows,
+                             alignment_heads=alignment_heads)
+        self.alignment_heads = SparseHeads(alignment_heads)
+        self.dq = False
+        self._bind_api()
+
+    # -- reference-visible attributes
+    @property
+    def device(self) -> torch.device:
+        return self.engine.device
+
+    @property
+    def is_multilingual(self) -> bool:
+        return self.dims.n_vocab >= 51865
+
+    @property
+    def num_languages(self) -> int:
+        return self.dims.n_vocab - 51765 - int(self.is_multilingual)
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return self.engine.tdtype
+
+    def set_alignment_heads(self, pairs: Sequence[Tuple[int, int]]):
+        self.engine.set_alignment_heads(pairs)
+        self.alignment_heads = SparseHeads(pairs)
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        if "encoder.positional_embedding" not in sd:
+            sd = dict(sd)
+            sd["encoder.positional_embedding"] = sinusoids(self.dims.n_audio_ctx, self.dims.n_audio_state)
+        self.engine.load_state_dict(sd, strict=strict)
+        return self
+
+    # -- hot-path pieces with the upstream call shapes
+    def log_mel(self, audio: torch.Tensor, padding: int = 0) -> torch.Tensor:
+        """whisper.audio.log_mel_spectrogram for one <=30 s segment (len + padding must be 480000; the callers
+        guarantee it: original_whisper.py:528-530, alignment.py:410-413).  Returns f32 [n_mels, 3000] on the device."""
+        return self.log_mel_batch([audio], [padding])[0]
+
+    def log_mel_batch(self, audios: Sequence[torch.Tensor], paddings: Optional[Sequence[int]] = None) -> torch.Tensor:
+        B = len(audios)
+        buf = torch.zeros(B, N_SAMPLES, dtype=torch.float32, device=self.device)
+        for b, a in enumerate(audios):
+            a = torch.as_tensor(a, dtype=torch.float32)
+            n = a.shape[-1]
+            pad = 0 if paddings is None else paddings[b]
+            if n + pad != N_SAMPLES:
+                raise ValueError(f"segment length + padding must be {N_SAMPLES}, got {n} + {pad}")
+            buf[b, :n] = a.to(self.device)
+        return self.engine.log_mel(buf, per_item_max=True)
+
+    def encoder(self, mel: torch.Tensor) -> torch.Tensor:
+        mel = mel.to(device=self.device, dtype=torch.float32)
+        if mel.ndim == 2:
+            mel = mel[None]
+        return self.engine.encode(mel.contiguous())
+
+    embed_audio = encoder
+
+    def cross_kv(self, audio_features: torch.Tensor) -> torch.Tensor:
+        return self.engine.cross_kv(audio_features.contiguous())
+
+    def logits(self, tokens: Sequence[Sequence[int]], audio_features: torch.Tensor) -> torch.Tensor:
+        """model(mel, tokens) / model.logits: teacher-forced full-sequence logits, f32 [W, n, n_vocab]."""
+        return self.engine.forward_logits(self.cross_kv(audio_features), tokens)
+
+    def detect_language(self, mel_or_features: torch.Tensor, tokenizer=None):
+        """model.detect_language (original_whisper.py:329): argmax / softmax over the language tokens at <|sot|>."""
+        from .tokenizer import get_tokenizer
+        if tokenizer is None:
+            tokenizer = get_tokenizer(self.is_multilingual, num_languages=self.num_languages)
+        if tokenizer.language is None or tokenizer.language_token not in tokenizer.sot_sequence:
+            raise ValueError("This model doesn't have language tokens so it can't perform lang id")
+        x = mel_or_features
+        single = x.ndim == 2
+        if single:
+            x = x[None]
+        if tuple(x.shape[-2:]) != (self.dims.n_audio_ctx, self.dims.n_audio_state):
+            x = self.encoder(x)
+        lg = self.logits([[tokenizer.sot]] * x.shape[0], x)[:, 0].float().cpu()
+        mask = torch.ones(lg.shape[-1], dtype=torch.bool)
+        mask[list(tokenizer.all_language_tokens)] = False
+        lg[:, mask] = -np.inf
+        lang_tokens = lg.argmax(dim=-1)
+        probs = lg.softmax(dim=-1)
+        out = [{c: probs[i, j].item() for j, c in zip(tokenizer.all_language_tokens, tokenizer.all_language_codes)}
+               for i in range(x.shape[0])]
+        return (lang_tokens[0], out[0]) if single else (lang_tokens, out)
+
+    def _bind_api(self):
+        from .transcribe import transcribe_stable
+        from .alignment import align, align_words
+        self.transcribe = types.MethodType(transcribe_stable, self)
+        self.transcribe_stable = self.transcribe
+        self.align = types.MethodType(align, self)
+        self.align_words = types.MethodType(align_words, self)
+
+
+def _read_checkpoint(path: str):
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    dims = ckpt["dims"]
+    dims = ModelDimensions(**dims) if isinstance(dims, dict) else ModelDimensions(**dims.__dict__)
+    return dims, ckpt["model_state_dict"]
+
+
+def load_model(name: str, device: Optional[Union[str, torch.device]] = None, download_root: str = None,
+               in_memory: bool = False, cpu_preload: bool = True, dq: bool = False, engine: Optional[str] = None, *,
+               dtype: Optional[str] = None, weights: Optional[str] = None, seed: int = 1234,
+               alignment_heads: Optional[Sequence[Tuple[int, int]]] = None, **model_kwargs) -> Whisper:
+    """Same signature as stable_whisper.load_model (original_whisper.py:953-1009) plus keyword-only extensions.
+
+    name     an official model name or a path to an upstream ``.pt`` checkpoint ({dims, model_state_dict})
+    dtype    'f16' (default, what the reference uses on a GPU) or 'f32' (strict parity with the reference's CPU path)
+    weights  'random' -> seeded random initialisation at the architecture `name` (no network / no checkpoint offline)
+    """
+    if dq:
+        raise NotImplementedError("dq (CPU dynamic quantisation, quantization.py:35-55) has no GPU counterpart")
+    if engine not in (None, "amd", "mi355x"):
+        raise NotImplementedError(f"engine={engine!r}: this package is a single MI355X-native engine (no dual backend)")
+    device = "cuda:0" if device is None else str(device)
+    if device == "cuda":
+        device = "cuda:0"
+    if not device.startswith("cuda"):
+        raise RuntimeError("stable_ts_amd runs on an MI355X only (device='cuda[:i]'); there is no CPU path")
+    dtype = dtype or "f16"
+    sd = None
+    if os.path.isfile(name):
+        dims, sd = _read_checkpoint(name)
+    elif name in _DIMS:
+        dims = dims_for(name)
+        root = download_root or os.path.join(os.path.expanduser("~"), ".cache", "whisper")
+        path = os.path.join(root, name + ".pt")
+        if weights != "random" and os.path.isfile(path):
+            dims, sd = _read_checkpoint(path)
+        elif weights != "random":
+            raise RuntimeError(f"no checkpoint for {name!r} under {root} and no network to download one; "
+                               f"pass a path, or weights='random' for seeded random weights")
+    else:
+        raise RuntimeError(f"Model {name} not found; available models = {available_models()}")
+    model = Whisper(dims, device=device, dtype=dtype, alignment_heads=alignment_heads, **model_kwargs)
+    if sd is None:
+        sd = random_state_dict(dims, seed=seed, std=model_kwargs.get("std", 0.02))
+    model.load_state_dict(sd)
+    return model
