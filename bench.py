@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- real-time factor of the MI355X hot path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full pass of model.transcribe() over the workload of BASELINE.json configs[2]:
+  large-v3 architecture (random-init weights; no checkpoints exist offline), 10 min of synthetic 16 kHz audio
+  (20 x 30-s windows, already resident in HBM when the timed region starts), word_timestamps=True, beam_size=5,
+  window-parallel batches, fixed decode budget per window (sample_len = min_tokens = 112: random weights have no
+  meaningful EOT -- BASELINE.md section 3), temperature 0 without fallback thresholds.
+Weak scaling: every rank processes its own 10-minute recording; value = N * K * 600 s / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline     -- the dominant kernel class of an extra, instrumented pass (HIP events on the launch stream inside
+                  libswx): algorithmic flops (or bytes) / measured time vs the gfx950 peak
+  cpu_baseline -- the CPU oracle (oracle/, a port: the reference's CPU path is not runnable offline) on the same
+                  workload shape, bounded sample, timed on this box's host cores (rank 0, N=1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F16_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0             # HBM3E spec, MI355X_MICROARCH.md
+CLASS_NAMES = ["gemm_f16_tiled", "gemm_f16_skinny", "attn_flash_f16", "attn_dense_rowwise", "self_attn_cached",
+               "decode_select", "mel", "align_weights", "dtw", "layernorm"]
+CLASS_BOUND = ["mfma", "hbm", "mfma", "hbm", "hbm", "hbm", "hbm", "hbm", "hbm", "hbm"]
+
+LARGE_V3_HEADS = [(l, h) for l, h in ((7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6))]
+
+
+def synth_audio(seconds: float, seed: int = 0) -> torch.Tensor:
+    n = int(seconds * 16000)
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n) / 16000.0
+    x = torch.zeros(n)
+    for k in range(5):
+        f = 120.0 * (k + 1) * (1.0 + 0.37 * k)
+        am = 0.5 + 0.5 * torch.sin(2 * np.pi * (1.3 + 0.7 * k) * t + k)
+        x += (0.25 / (k + 1)) * torch.sin(2 * np.pi * f * t) * am
+    x += 0.01 * torch.randn(n, generator=g)
+    for i, s in enumerate(torch.arange(4.0, seconds, 5.0).tolist()):
+        d = 0.3 + 0.7 * ((i * 7919) % 10) / 10.0
+        x[int(s * 16000): int((s + d) * 16000)] = 0.0
+    return (x * 0.5 / x.abs().max()).float()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="large-v3")
+    ap.add_argument("--minutes", type=float, default=10.0)
+    ap.add_argument("--batch", type=int, default=20, help="windows per GPU batch")
+    ap.add_argument("--beam", type=int, default=5)
+    ap.add_argument("--tokens", type=int, default=112, help="fixed decode budget per window")
+    ap.add_argument("--dtype", default="f16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import stable_ts_amd as sw
+    from stable_ts_amd import parallel as par
+    rank, local, world = par.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+
+    dims = sw.dims_for(args.model)
+    heads = LARGE_V3_HEADS if dims.n_text_layer == 32 and dims.n_text_head == 20 else None
+    model = sw.Whisper(dims, device=dev, dtype=args.dtype, alignment_heads=heads, max_windows=args.batch,
+                       max_rows=args.batch * args.beam)
+    sd = None
+    if rank == 0:
+        sd = sw.random_state_dict(dims, seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5)
+        model.load_state_dict(sd)
+    par.broadcast_arena(model.engine.arena, src=0)        # RCCL broadcast of the packed weights (no-op at N=1)
+    if rank != 0:
+        model.engine._load_constants()
+
+    seconds = args.minutes * 60.0
+    audio = synth_audio(seconds, seed=rank).to(dev)
+    kw = dict(language="en", temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None,
+              no_speech_threshold=None, beam_size=args.beam if args.beam > 1 else None, sample_len=args.tokens,
+              min_tokens=args.tokens, word_timestamps=True, regroup=False, batch_size=args.batch)
+
+    def step():
+        return model.transcribe(audio, **kw)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    par.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    par.barrier()
+    dt = par.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
+
+    n_words = len(res.all_words()) if res is not None else 0
+    n_segs = len(res.segments) if res is not None else 0
+    gathered = par.gather_results([dict(rank=rank, segments=n_segs, words=n_words)])
+
+    out = None
+    if rank == 0:
+        value = world * args.steps * seconds / dt
+        out = {
+            "metric": "real-time factor (audio-sec/wall-sec) large-v3 word_timestamps=True",
+            "value": round(value, 2), "unit": "x real time", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} (random-init), {args.minutes:g} min synthetic 16 kHz audio per GPU, "
+                                   f"word_timestamps=True, beam_size={args.beam}, {args.tokens} decode steps/window, "
+                                   f"window-parallel batch {args.batch}",
+                       "windows_per_gpu": int(np.ceil(seconds / 30.0)), "segments": n_segs, "words": n_words,
+                       "parallelism": f"dp{world} (windows sharded, no data-path collective)"},
+        }
+
+    # ---- roofline: one extra instrumented pass (not part of `value`)
+    if rank == 0 and not args.no_roofline:
+        lib = model.engine.lib
+        lib.swx_prof_enable(1)
+        step()
+        buf = (ctypes.c_double * (3 * len(CLASS_NAMES)))()
+        lib.swx_prof_collect(buf, len(CLASS_NAMES))
+        lib.swx_prof_enable(0)
+        rows = []
+        for c, name in enumerate(CLASS_NAMES):
+            n, ms, work = buf[3 * c], buf[3 * c + 1], buf[3 * c + 2]
+            if n > 0:
+                rows.append(dict(kernel=name, bound=CLASS_BOUND[c], launches=int(n), total_ms=round(ms, 3),
+                                 avg_us=round(1000.0 * ms / n, 2), work=work))
+        rows.sort(key=lambda r: -r["total_ms"])
+        if rows:
+            top = rows[0]
+            if top["bound"] == "mfma":
+                ach = top["work"] / (top["total_ms"] * 1e-3) / 1e12
+                peak, unit = PEAK_MFMA_F16_TFLOPS if args.dtype == "f16" else 157.3, "TFLOP/s"
+            else:
+                ach = top["work"] / (top["total_ms"] * 1e-3) / 1e9
+                peak, unit = PEAK_HBM_GBS, "GB/s"
+            out["roofline"] = {"kernel": top["kernel"], "bound": top["bound"], "achieved": round(ach, 2), "peak": peak,
+                               "unit": unit, "frac": round(ach / peak, 4), "traffic": None,
+                               "avg_launch_us": top["avg_us"], "launches": top["launches"]}
+            out["kernel_time_ms"] = {r["kernel"]: r["total_ms"] for r in rows}
+            for r in rows[1:4]:
+                a = r["work"] / (r["total_ms"] * 1e-3) / (1e12 if r["bound"] == "mfma" else 1e9) if r["work"] else 0.0
+                out.setdefault("roofline_others", []).append(
+                    dict(kernel=r["kernel"], bound=r["bound"], achieved=round(a, 2), unit="TFLOP/s" if r["bound"] == "mfma" else "GB/s"))
+
+    # ---- CPU baseline (oracle port), bounded sample, rank 0 at N=1 only
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, sd, dims)
+        except Exception as e:   # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, sd, dims):
+    """The CPU oracle (restated reference path, fp32, torch CPU) on ONE 30-s window of the same workload shape with a
+    reduced decode budget, every stage timed; the decode loop time is scaled linearly to the full budget."""
+    from oracle import stable as ost
+    from oracle.whisper import model as om
+    from oracle.whisper.audio import log_mel_spectrogram
+    from oracle.whisper.decoding import DecodingOptions
+    from oracle.whisper.tokenizer import get_tokenizer
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = om.Whisper(om.ModelDimensions(**dims.__dict__))
+    m.load_state_dict(sd)
+    m.eval()
+    mask = torch.zeros(dims.n_text_layer, dims.n_text_head, dtype=torch.bool)
+    heads = LARGE_V3_HEADS if dims.n_text_layer == 32 else [(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)]
+    for l, h in heads:
+        mask[l, h] = True
+    m.set_alignment_heads_mask(mask)
+    audio = synth_audio(30.0, seed=0)
+    steps_cpu = 8
+    t = {}
+    t0 = time.perf_counter()
+    mel = log_mel_spectrogram(audio, dims.n_mels)
+    t["mel"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        xa = m.encoder(mel[None])
+    t["encoder"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    opts = DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=steps_cpu,
+                           beam_size=args.beam if args.beam > 1 else None)
+    res, _ = ost.decode_stable(m, mel, opts, audio_features=xa, min_tokens=steps_cpu)
+    t["decode"] = (time.perf_counter() - t0) * (args.tokens / steps_cpu)
+    tok = get_tokenizer(m.is_multilingual, num_languages=m.num_languages, language="en", task="transcribe")
+    g = torch.Generator().manual_seed(0)
+    text_tokens = torch.randint(18, 50000, (96,), generator=g).tolist()
+    t0 = time.perf_counter()
+    ost.find_alignment(m, tok, text_tokens, mel, 480000, audio_features=xa)
+    t["word_timestamps"] = time.perf_counter() - t0
+    total = sum(t.values())
+    return {"value": round(30.0 / total, 4), "unit": "x real time", "cores": cores, "kind": "port",
+            "sample": f"one 30-s window of the same workload on the CPU oracle (torch fp32, {cores} threads): mel + encoder + "
+                      f"beam-{args.beam} decode of {steps_cpu} steps scaled x{args.tokens / steps_cpu:g} to {args.tokens} + "
+                      f"scoring/alignment/DTW of 96 tokens",
+            "stage_seconds": {k: round(v, 3) for k, v in t.items()}}
+
+
+if __name__ == "__main__":
+    main()

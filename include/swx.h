@@ -147,6 +147,13 @@ size_t swx_dtw_workspace_bytes(int W, int ld_n, int ld_m);
 int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_t *d_N, const int32_t *d_M,
             int32_t *d_text_idx, int32_t *d_time_idx, int32_t *d_len, void *d_trace_ws, void *stream);
 
+/* ---- measurement: per-kernel-class HIP-event timing on the launch stream (bench.py's roofline object).
+ * classes: 0 gemm tiled (work=flops) 1 gemm skinny (bytes) 2 flash attention (flops) 3 rowwise attention (bytes)
+ *          4 cached self-attention 5 select/beam 6 mel 7 align-weights 8 dtw 9 layernorm
+ * swx_prof_collect: out[cls*3+{0,1,2}] = {launches, total ms, total algorithmic work}; returns the class count */
+int swx_prof_enable(int on);
+int swx_prof_collect(double *out, int n_classes);
+
 /* ---- building blocks exported for the parity tests (same kernels the calls above launch) */
 int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
                   void *d_c, int64_t ldc, int M, int N, int K, int epilogue, int force_kernel, void *stream);

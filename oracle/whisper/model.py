@@ -260,7 +260,7 @@ def dims_for(name: str) -> ModelDimensions:
 
 
 def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02,
-                      embed_gain: float = 1.0) -> Dict[str, Tensor]:
+                      embed_gain: float = 1.0, ts_gain: float = 1.0) -> Dict[str, Tensor]:
     """Deterministic random weights at the real architecture (no checkpoints exist offline).
 
     Linear / conv / embedding ~ N(0, std), biases ~ N(0, std), LN gamma=1 beta=0,
@@ -278,13 +278,15 @@ def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02
             sd[k] = torch.randn(v.shape, generator=g) * 0.01
         elif k == "decoder.token_embedding.weight":
             sd[k] = torch.randn(v.shape, generator=g) * std * embed_gain
+            if ts_gain != 1.0:   # shrink the 1501 timestamp rows so that text tokens win more often (richer transcripts)
+                sd[k][dims.n_vocab - 1501:] *= ts_gain
         else:
             sd[k] = torch.randn(v.shape, generator=g) * std
     return sd
 
 
-def build_model(name_or_dims, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0) -> Whisper:
+def build_model(name_or_dims, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0, ts_gain: float = 1.0) -> Whisper:
     dims = dims_for(name_or_dims) if isinstance(name_or_dims, str) else name_or_dims
     model = Whisper(dims)
-    model.load_state_dict(random_state_dict(dims, seed, std, embed_gain))
+    model.load_state_dict(random_state_dict(dims, seed, std, embed_gain, ts_gain))
     return model.eval()

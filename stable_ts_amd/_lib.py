@@ -62,6 +62,8 @@ SYMBOLS = {
     "swx_dtw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "swx_dtw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                         c_void_p]),
+    "swx_prof_enable": (c_int, [c_int]),
+    "swx_prof_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
     "swx_test_gemm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                               c_int, c_int, c_int, c_void_p]),
     "swx_test_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -6,6 +6,7 @@
 // HBM-bound: three streaming passes over H*(T+1)*F f32 (13.5 MB for large-v3), fused so that the only thing
 // written besides the [H][F] statistics is the final (T+1)xF matrix.
 #include "swx_common.h"
+#include "swx_kernels.h"
 
 // ---- pass 1: p = softmax_f(qk * scale) over f in [0, F) ; one wave per (w, h, i) row --------------------
 __global__ __launch_bounds__(256) void swx_align_softmax_kernel(const float *__restrict__ qk, float *__restrict__ p,
@@ -117,6 +118,7 @@ int swx_align_weights_launch(const float *d_qk, float *d_p, float *d_mean, float
                              float *d_neg_matrix, int out_ld_n, int out_ld_f, hipStream_t s)
 {
     if (W <= 0 || H <= 0 || N <= 0) return 0;
+    SwxProfScope prof(PC_ALIGN, (double)W * H * N * ld_f * 4.0 * 3, s);
     const long rows = (long)W * H * N;
     hipLaunchKernelGGL(swx_align_softmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, d_qk, d_p, W, H, N, ld_f,
                        d_n_rows, d_n_frames, qk_scale);

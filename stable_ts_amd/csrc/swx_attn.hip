@@ -317,11 +317,15 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     if (a.B <= 0 || a.nq <= 0 || a.nk <= 0) return 0;
     if (a.nk > RW_MAXK) return -5;
     const bool flash = (dtype == SWX_F16) && (force_kernel == 2 || (force_kernel == 0 && a.nq >= 32));
+    const size_t esz = dtype == SWX_F16 ? 2 : 4;
     if (flash) {
         if (dtype != SWX_F16) return -5;
+        SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
         dim3 g(cdiv(a.nq, 64), a.H, a.B);
         hipLaunchKernelGGL(attn_flash_f16, g, dim3(256), 0, s, a);
     } else {
+        // algorithmic bytes: K and V of every (window, head) once + q in + o out
+        SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
         dim3 g(cdiv(a.nq, RW_QB), a.H, a.B);
         const int nkp = (a.nk + 3) & ~3;
         const size_t smem = sizeof(float) * ((size_t)RW_QB * DH + (size_t)RW_QB * nkp + (size_t)4 * RW_QB * DH);
@@ -336,6 +340,7 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
 {
     if (a.R <= 0 || a.n_new <= 0) return 0;
     if (a.n_ctx > 512) return -5;
+    SwxProfScope prof(PC_SELF_ATTN, 0.0, s);
     dim3 g1(a.n_new, a.R);
     dim3 g2(a.n_new, a.H, a.R);
     if (dtype == SWX_F16) {

@@ -454,6 +454,7 @@ int swx_decode_after_prefill(const DecodeBufs &b, const float *lg2, float *nospe
 }
 int swx_decode_select(const DecodeBufs &b, int step, int cur, hipStream_t s)
 {
+    SwxProfScope prof(PC_SELECT, (double)b.M * b.V * 4.0, s);
     hipLaunchKernelGGL(decode_select_kernel, dim3(b.M), dim3(SEL_T), 0, s, b, step, cur);
     if (b.cfg.beam) {
         hipLaunchKernelGGL(decode_beam_update_kernel, dim3(b.W), dim3(256), 0, s, b, step, cur);

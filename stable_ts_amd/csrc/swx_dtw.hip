@@ -12,6 +12,7 @@
 // (M + ceil(N/R) - 1 steps), not by bandwidth.  The 2-bit moves of a lane's R rows for one column are packed
 // into one u16 and written to a [M][64] trace plane; the backtrace walks it and emits the path in forward order.
 #include "swx_common.h"
+#include "swx_kernels.h"
 
 template <int R>
 __global__ __launch_bounds__(64) void swx_dtw_kernel(const float *__restrict__ x_all, int ld_n, int ld_m,
@@ -118,6 +119,7 @@ extern "C" int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_
     if (W <= 0) return 0;
     if (ld_n <= 0 || ld_m <= 0 || ld_n > 448) return -2;
     hipStream_t s = (hipStream_t)stream;
+    SwxProfScope prof(PC_DTW, (double)W * ld_n * ld_m * 5.0, s);
     size_t per = swx_dtw_workspace_bytes(1, ld_n, ld_m);
     const int R = (ld_n + 63) / 64;
 #define SWX_DTW_LAUNCH(RR) hipLaunchKernelGGL(swx_dtw_kernel<RR>, dim3(W), dim3(64), 0, s, d_x, ld_n, ld_m, d_N, d_M, \

@@ -240,6 +240,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
         const bool use_skinny = force_kernel == 2 ? skinny_ok : (force_kernel == 1 ? false : skinny_ok);
         if (force_kernel == 2 && !skinny_ok) return -4;
         if (use_skinny) {
+            SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * ((g.epi & EPI_OUT_F32) ? 4 : 2), s);
             dim3 grid(cdiv(g.N, 16));
             const int mt = cdiv(g.M, 16);
             if (mt <= 1) hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g);
@@ -247,11 +248,13 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             else if (mt <= 4) hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g);
             else hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g);
         } else {
+            SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
             dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
             hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
         }
     } else {
         if (g.K % 16 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return -4;
+        SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
         dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
         hipLaunchKernelGGL(gemm_f32_tiled, grid, dim3(256), 0, s, g);
     }

@@ -22,6 +22,18 @@ struct GemmArgs {
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 
+// ---- in-library kernel timing (HIP events on the launch stream), used by bench.py for the roofline object
+enum SwxProfClass { PC_GEMM_TILED = 0, PC_GEMM_SKINNY = 1, PC_ATTN_FLASH = 2, PC_ATTN_ROWWISE = 3, PC_SELF_ATTN = 4,
+                    PC_SELECT = 5, PC_MEL = 6, PC_ALIGN = 7, PC_DTW = 8, PC_NORM = 9, PC_COUNT = 10 };
+bool swx_prof_on();
+void swx_prof_begin(int cls, double work, hipStream_t s);   // work = algorithmic flops (MFMA classes) or bytes (HBM classes)
+void swx_prof_end(hipStream_t s);
+struct SwxProfScope {
+    hipStream_t s; bool on;
+    SwxProfScope(int cls, double work, hipStream_t st) : s(st), on(swx_prof_on()) { if (on) swx_prof_begin(cls, work, st); }
+    ~SwxProfScope() { if (on) swx_prof_end(s); }
+};
+
 // ---- swx_norm.hip
 int swx_layernorm(int dtype, const void *x, int64_t ldx, const float *gamma, const float *beta, void *y, int64_t ldy,
                   int rows, int d, hipStream_t s);

@@ -8,6 +8,7 @@
 // FFT, which keeps the clamp-floor region of the spectrum (8 decades below the peak) within parity tolerance.
 // 0.96 GFLOP f64 per 30-s window; LDS-bound (one 16-B twiddle read per bin-tap shared by 8 frames).
 #include "swx_common.h"
+#include "swx_kernels.h"
 
 #define MEL_FB 8          // frames per workgroup
 #define MEL_NFFT 400
@@ -107,6 +108,7 @@ int swx_mel_launch(const float *d_pcm, int B, const float *d_hann, const double2
                    int n_mels, float *d_mel, unsigned *d_gmax, int per_item_max, hipStream_t s)
 {
     if (B <= 0) return 0;
+    SwxProfScope prof(PC_MEL, (double)B * (480000.0 * 4 + (double)n_mels * 3000 * 4), s);
     hipError_t e = hipMemsetAsync(d_gmax, 0, sizeof(unsigned) * B, s);   // 0 < ordered(-inf)
     if (e != hipSuccess) return -100 - (int)e;
     hipLaunchKernelGGL(swx_mel_power_kernel, dim3(MEL_NFRAMES / MEL_FB, B), dim3(256), 0, s, d_pcm, d_hann, d_twiddle,

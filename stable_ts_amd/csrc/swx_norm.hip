@@ -84,6 +84,7 @@ int swx_layernorm(int dtype, const void *x, int64_t ldx, const float *gamma, con
                   int rows, int d, hipStream_t s)
 {
     if (rows <= 0) return 0;
+    SwxProfScope prof(PC_NORM, 2.0 * rows * (double)d * (dtype == SWX_F16 ? 2 : 4), s);
     if (dtype == SWX_F16)
         hipLaunchKernelGGL(layernorm_kernel<f16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const f16 *)x, ldx, gamma, beta, (f16 *)y, ldy, rows, d);
     else

@@ -235,6 +235,23 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
 
 inline hipStream_t S(void *s) { return (hipStream_t)s; }
 
+// ---------------------------------------------------------------------------------------------- profiler
+struct ProfRec { int cls; double work; hipEvent_t a, b; };
+bool g_prof_enabled = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_pool;
+size_t g_pool_next = 0;
+
+hipEvent_t prof_event()
+{
+    if (g_pool_next == g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_next++];
+}
+
 #define SWX_TRY(expr) do { int _r = (expr); if (_r < 0) return _r; } while (0)
 
 GemmArgs gemm_args(const void *A, int64_t lda, const void *W, int64_t ldw, const float *bias, void *C, int64_t ldc,
@@ -363,8 +380,47 @@ __global__ void score_targets_kernel(const int32_t *__restrict__ tokens, int max
 
 }  // namespace
 
+bool swx_prof_on() { return g_prof_enabled; }
+void swx_prof_begin(int cls, double work, hipStream_t s)
+{
+    ProfRec r{cls, work, prof_event(), prof_event()};
+    if (!r.a || !r.b) return;
+    (void)hipEventRecord(r.a, s);
+    g_prof.push_back(r);
+}
+void swx_prof_end(hipStream_t s)
+{
+    if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().b, s);
+}
+
 // ================================================================================================== C ABI
 extern "C" {
+
+int swx_prof_enable(int on)
+{
+    g_prof_enabled = on != 0;
+    if (on) { g_prof.clear(); g_pool_next = 0; }
+    return 0;
+}
+
+// out[cls*3 + {0,1,2}] = {launches, total milliseconds, total work}; synchronises the device
+int swx_prof_collect(double *out, int n_classes)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return -100 - (int)e;
+    for (int i = 0; i < n_classes * 3; ++i) out[i] = 0.0;
+    for (auto &r : g_prof) {
+        if (r.cls < 0 || r.cls >= n_classes) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        out[r.cls * 3 + 0] += 1.0;
+        out[r.cls * 3 + 1] += (double)ms;
+        out[r.cls * 3 + 2] += r.work;
+    }
+    g_prof.clear();
+    g_pool_next = 0;
+    return PC_COUNT;
+}
 
 const char *swx_strerror(int code)
 {

@@ -48,7 +48,8 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> tor
     return torch.cat([torch.sin(t), torch.cos(t)], dim=1)
 
 
-def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0,
+                      ts_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Seeded random weights under the upstream checkpoint keys (no checkpoint exists offline).  Same generator order
     as the test oracle so that both sides see identical weights for a given seed."""
     g = torch.Generator().manual_seed(seed)
@@ -93,7 +94,9 @@ def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02
         block(f"encoder.blocks.{i}", da, False)
     ln("encoder.ln_post", da)
     sd["decoder.positional_embedding"] = torch.randn(dims.n_text_ctx, dt, generator=g) * 0.01
-    sd["decoder.token_embedding.weight"] = rnd(dims.n_vocab, dt, s=std * embed_gain)
+    sd["decoder.token_embedding.weight"] = torch.randn(dims.n_vocab, dt, generator=g) * std * embed_gain
+    if ts_gain != 1.0:   # shrink the 1501 timestamp rows: text tokens win more often -> richer synthetic transcripts
+        sd["decoder.token_embedding.weight"][dims.n_vocab - 1501:] *= ts_gain
     for i in range(dims.n_text_layer):
         block(f"decoder.blocks.{i}", dt, True)
     ln("decoder.ln", dt)
@@ -264,6 +267,6 @@ def load_model(name: str, device: Optional[Union[str, torch.device]] = None, dow
         raise RuntimeError(f"Model {name} not found; available models = {available_models()}")
     model = Whisper(dims, device=device, dtype=dtype, alignment_heads=alignment_heads, **model_kwargs)
     if sd is None:
-        sd = random_state_dict(dims, seed=seed, std=model_kwargs.get("std", 0.02))
+        sd = random_state_dict(dims, seed=seed)
     model.load_state_dict(sd)
     return model

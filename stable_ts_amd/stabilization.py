@@ -1,0 +1,174 @@
+"""Non-VAD silence detection and timestamp snapping (default-on in the reference: ``suppress_silence=True``).
+
+Host-side vector code on <=480000 samples per window; not part of the GPU hot path but it moves word boundaries by up
+to hundreds of ms, so it is restated for drop-in behaviour.  Follows
+stabilization/nonvad.py:16-88 (loudness quantisation), stabilization/utils.py:43-111 (mask <-> timings),
+stabilization/__init__.py:16-135,241-254 (NonSpeechPredictor, non-VAD branch) and :300-379 (suppress_silence),
+result.py:681-705 (per-word ``keep_end`` policy).  Silero VAD (``vad=True``) needs torch.hub + network: out of scope.
+"""
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .audio import FRAMES_PER_SECOND, N_SAMPLES_PER_TOKEN, SAMPLE_RATE, TOKENS_PER_SECOND
+from .timing import APPEND_PUNCTUATIONS
+
+
+def audio2loudness(x: torch.Tensor) -> Optional[torch.Tensor]:
+    """nonvad.py:16-39: |x| normalised by (1.75 x the 99.9th-percentile level), resampled to one value per 20 ms."""
+    x = x.abs()
+    k = int(x.numel() * 0.001)
+    thr = torch.topk(x, k).values[-1] if k else x.quantile(0.999, dim=-1)
+    units = round(x.shape[-1] / N_SAMPLES_PER_TOKEN) + 1
+    if units <= 2:
+        return None
+    if thr < 1e-5:
+        return torch.zeros(units, dtype=x.dtype, device=x.device)
+    x = x / min(1.0, float(thr) * 1.75)
+    return F.interpolate(x[None, None], size=units, mode="linear", align_corners=False)[0, 0]
+
+
+def mask2timing(mask, time_offset: float = 0.0) -> Optional[Tuple[np.ndarray, np.ndarray]]:
+    """utils.py:43-86 (no clipping arguments): runs of True -> (starts, ends) in seconds at 50 units/s."""
+    if mask is None or len(mask) == 0 or not bool(mask.any()):
+        return None
+    m = mask.cpu().numpy().copy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
+    p = np.concatenate(([False], m, [False]))
+    starts = np.logical_and(~p[:-2], p[1:-1]).nonzero()[0] / TOKENS_PER_SECOND
+    ends = (np.logical_and(p[1:-1], ~p[2:]).nonzero()[0] + 1) / TOKENS_PER_SECOND
+    if time_offset:
+        starts = starts + time_offset
+        ends = ends + time_offset
+    return starts, ends
+
+
+def timing2mask(starts: np.ndarray, ends: np.ndarray, size: int) -> torch.Tensor:
+    """utils.py:89-111."""
+    out = torch.zeros(size, dtype=torch.bool)
+    a = (starts * TOKENS_PER_SECOND).round().astype(np.int32)
+    b = (ends * TOKENS_PER_SECOND).round().astype(np.int32)
+    for i, j in zip(a, b):
+        out[i:j + 1] = True
+    return out
+
+
+def wav2mask(audio: torch.Tensor, q_levels: int = 20, k_size: int = 5) -> Optional[torch.Tensor]:
+    """nonvad.py:43-88: boolean SILENCE mask per 20-ms unit, or None when the window has no silence."""
+    loud = audio2loudness(audio)
+    if loud is None:
+        return None
+    p = k_size // 2 if k_size else 0
+    if p and p < loud.shape[-1]:
+        m = torch.avg_pool1d(F.pad(loud[None], (p, p), "reflect"), kernel_size=k_size, stride=1)[0]
+    else:
+        m = loud.clone()
+    if q_levels:
+        m = m.mul(q_levels).round()
+    speech = m.bool()
+    if not speech.any():
+        return ~speech
+    s, e = mask2timing(speech)
+    keep = (e - s) > 0.1                    # speech runs of <= 0.1 s are treated as silence
+    silence = ~timing2mask(s[keep], e[keep], loud.shape[-1])
+    if not silence.any():
+        return None
+    return silence
+
+
+class NonSpeechPredictor:
+    """Non-VAD branch of stabilization/__init__.py::NonSpeechPredictor."""
+
+    def __init__(self, q_levels: int = 20, k_size: int = 5, min_word_dur: Optional[float] = 0.1,
+                 min_silence_dur: Optional[float] = None, get_mask: bool = False):
+        self.q_levels, self.k_size = q_levels, k_size
+        self.min_silence_dur = min_silence_dur
+        self.get_mask = get_mask
+        mwd = 0.1 if min_word_dur is None else min_word_dur
+        self.min_units_per_word = max(round(mwd * FRAMES_PER_SECOND), 1)
+        self._starts: List[float] = []
+        self._ends: List[float] = []
+
+    def predict(self, audio: torch.Tensor, offset: float = 0.0) -> dict:
+        audio = audio.detach().float().cpu()
+        mask = wav2mask(audio, self.q_levels, self.k_size)
+        timings = mask2timing(mask, time_offset=offset)
+        if timings is not None:
+            timings = np.stack(timings, axis=0)
+        is_silent = False
+        if mask is not None:
+            is_silent = bool((mask.shape[-1] - int(mask.count_nonzero())) < self.min_units_per_word)
+            pad = torch.zeros(1501, dtype=torch.bool)
+            n = min(1501, mask.shape[-1])
+            pad[:n] = mask[:n]
+            mask = pad
+        if timings is not None and len(timings[0]):
+            self._starts.extend(timings[0].tolist())
+            self._ends.extend(timings[1].tolist())
+        if self.min_silence_dur and timings is not None:
+            keep = (timings[1] - timings[0]) >= self.min_silence_dur
+            timings = np.stack((timings[0][keep], timings[1][keep]), axis=0)
+        return dict(timings=timings, mask=mask if self.get_mask else None, is_silent=is_silent)
+
+    def sections(self) -> List[dict]:
+        """finalize_timings (:120-135): merged, sorted non-speech sections."""
+        if not self._starts:
+            return []
+        s, e = np.sort(np.array(self._starts)), np.sort(np.array(self._ends))
+        while len(s) > 1:
+            ok = s[1:] >= e[:-1]
+            if ok.all():
+                break
+            s = s[np.concatenate(([True], ok))]
+            e = e[np.concatenate((ok, [True]))]
+        return [dict(start=float(a), end=float(b)) for a, b in zip(s, e)]
+
+
+def _snap(obj: dict, starts: np.ndarray, ends: np.ndarray, min_word_dur: float, nonspeech_error: float,
+          keep_end: Optional[bool]):
+    """stabilization/__init__.py:300-379 on a dict with 'start'/'end'."""
+    if len(starts) == 0 or (obj["end"] - obj["start"]) <= min_word_dur:
+        return
+    if keep_end is None or keep_end:
+        hit = np.all((starts <= obj["start"], obj["start"] < ends, ends <= obj["end"]), axis=0).nonzero()[0]
+        if len(hit):
+            obj["start"] = min(float(ends[hit[0]]), round(obj["end"] - min_word_dur, 3))
+            if (obj["end"] - obj["start"]) <= min_word_dur:
+                return
+    if not keep_end:
+        hit = np.all((obj["start"] <= starts, starts < obj["end"], obj["end"] <= ends), axis=0).nonzero()[0]
+        if len(hit):
+            obj["end"] = max(float(starts[hit[0]]), round(obj["start"] + min_word_dur, 3))
+            if (obj["end"] - obj["start"]) <= min_word_dur:
+                return
+    if nonspeech_error:
+        inside = np.logical_and(obj["start"] <= starts, obj["end"] >= ends).nonzero()[0]
+        if len(inside) != 1:
+            return
+        s0, e0 = float(starts[inside[0]]), float(ends[inside[0]])
+        dur = e0 - s0
+        err_start = (s0 - obj["start"]) / dur
+        err_end = (obj["end"] - e0) / dur
+        ke = keep_end if keep_end is not None else (err_start <= err_end)
+        if not (err_start <= nonspeech_error or err_end <= nonspeech_error):
+            return
+        if ke:
+            obj["start"] = min(e0, round(obj["end"] - min_word_dur, 3))
+        else:
+            obj["end"] = max(s0, round(obj["start"] + min_word_dur, 3))
+
+
+def suppress_segment_silence(seg: dict, starts, ends, min_word_dur: float = 0.1, word_level: bool = True,
+                             nonspeech_error: float = 0.1, use_word_position: bool = True):
+    """result.py:681-705 on a segment dict (words = list of dicts); keeps segment start/end in sync with the words."""
+    starts, ends = np.asarray(starts), np.asarray(ends)
+    words = seg.get("words")
+    if words:
+        sel = words if word_level or len(words) == 1 else [words[0], words[-1]]
+        for i, w in enumerate(sel, 1):
+            keep_end = (not (w["word"][-1] in APPEND_PUNCTUATIONS or i == len(sel))) if use_word_position else None
+            _snap(w, starts, ends, min_word_dur, nonspeech_error, keep_end)
+        seg["start"], seg["end"] = words[0]["start"], words[-1]["end"]
+    else:
+        _snap(seg, starts, ends, min_word_dur, nonspeech_error, True)

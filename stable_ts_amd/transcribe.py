@@ -1,0 +1,399 @@
+"""model.transcribe(): the 30-s window loop around the GPU hot path.
+
+Mirrors ``transcribe_stable`` (whisper_word_level/original_whisper.py:27-781) for in-memory 16 kHz audio:
+per window  log-mel -> encoder -> decode_with_fallback (:349-393) -> segment slicing at consecutive timestamp tokens
+(:550-602) -> segment filters (:604-627) -> word timestamps (:635-652) -> instant-word / probability filters (:654-674)
+-> seek advance (:629-633, :703-704), with the prompt carried over between windows (:533, :680-682, :706-708).
+
+Two drivers share one per-batch routine:
+  * sequential (default): identical control flow to the reference, one window per iteration;
+  * ``batch_size=N`` (window-parallel): fixed 30-s stride, no prompt carry-over, N windows per GPU batch -- the mode
+    SURVEY.md 8e describes for throughput / sharding; its oracle is "the reference run on each 30-s clip separately".
+Out of scope here: ffmpeg/yt-dlp audio I/O, denoisers, VAD models, resume, the regroup DSL.
+"""
+import warnings
+import wave
+from dataclasses import replace
+from typing import Callable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from .audio import HOP_LENGTH, N_FRAMES, N_SAMPLES, N_SAMPLES_PER_TOKEN, SAMPLE_RATE
+from .decoding import DecodingOptions, DecodingPlan, DecodingResult
+from .result import WhisperResult
+from .timing import APPEND_PUNCTUATIONS, PREPEND_PUNCTUATIONS, add_word_timestamps_batch
+from .tokenizer import get_tokenizer
+
+_DECODE_KEYS = set(DecodingOptions.__dataclass_fields__)
+
+
+def load_audio(audio) -> torch.Tensor:
+    """torch.Tensor / np.ndarray (already 16 kHz mono, as the reference requires for arrays) or a PCM .wav path
+    (stdlib reader + polyphase resample; no ffmpeg offline).  Returns a 1-D f32 tensor (device preserved)."""
+    if isinstance(audio, torch.Tensor):
+        a = audio
+        if a.ndim == 2:
+            a = a.mean(0)
+        return a.to(torch.float32)
+    if isinstance(audio, np.ndarray):
+        a = torch.from_numpy(np.ascontiguousarray(audio))
+        if a.ndim == 2:
+            a = a.float().mean(0)
+        return a.to(torch.float32)
+    if isinstance(audio, (str, bytes)) and str(audio).lower().endswith(".wav"):
+        with wave.open(audio, "rb") as wf:
+            sr, ch, sw, n = wf.getframerate(), wf.getnchannels(), wf.getsampwidth(), wf.getnframes()
+            raw = wf.readframes(n)
+        if sw != 2:
+            raise RuntimeError("only 16-bit PCM wav files are supported without ffmpeg")
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        x = x.reshape(-1, ch).mean(1)
+        if sr != SAMPLE_RATE:
+            from math import gcd
+            from scipy.signal import resample_poly
+            g = gcd(sr, SAMPLE_RATE)
+            x = resample_poly(x, SAMPLE_RATE // g, sr // g).astype(np.float32)
+        return torch.from_numpy(x)
+    raise RuntimeError(f"Failed to load audio: {type(audio)} (ffmpeg / URL inputs are out of scope offline)")
+
+
+def _xkv_select(model, xkv, idx: Sequence[int]):
+    """Sub-batch of a cross-KV buffer [L][W*1500][2d] (device-side gather; memory movement only)."""
+    W = xkv.n_windows
+    if list(idx) == list(range(W)):
+        return xkv
+    d = model.dims
+    t = xkv.view(model.engine.tdtype).view(d.n_text_layer, W, d.n_audio_ctx * 2 * d.n_text_state)
+    sel = t.index_select(1, torch.tensor(list(idx), device=t.device)).contiguous().view(torch.uint8).view(-1)
+    sel.n_windows = len(idx)
+    return sel
+
+
+def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float], prompts, ts_masks,
+                          compression_ratio_threshold, logprob_threshold, no_speech_threshold) -> List[DecodingResult]:
+    """original_whisper.py:349-393, for W windows: every window walks the temperature ladder independently; the ones that
+    still need a fallback are re-decoded together at the next temperature."""
+    W = xkv.n_windows
+    results: List[Optional[DecodingResult]] = [None] * W
+    pending = list(range(W))
+    for t in temperatures:
+        kw = dict(base)
+        if t > 0:
+            kw.pop("beam_size", None)
+            kw.pop("patience", None)
+        else:
+            kw.pop("best_of", None)
+        options = DecodingOptions(**kw, temperature=t)
+        sub = _xkv_select(model, xkv, pending)
+        plans = [DecodingPlan(model, replace(options, prompt=(list(prompts[w]) if prompts[w] else None))) for w in pending]
+        groups = {}
+        for k, p in enumerate(plans):
+            groups.setdefault(p.sample_begin, []).append(k)
+        outs: List[Optional[DecodingResult]] = [None] * len(pending)
+        for _, ks in groups.items():       # one lockstep job per distinct initial length
+            sub_k = _xkv_select(model, sub, ks)
+            masks = None
+            if ts_masks is not None:
+                masks = torch.stack([ts_masks[pending[k]] for k in ks])
+            out = model.engine.decode(sub_k, [list(plans[k].initial_tokens) for k in ks], ts_mask=masks,
+                                      **plans[ks[0]].engine_kwargs())
+            for k, r in zip(ks, plans[ks[0]].results(out, [None] * len(ks), [options.language or "en"] * len(ks))):
+                outs[k] = r
+        nxt = []
+        for k, w in enumerate(pending):
+            r = outs[k]
+            results[w] = r
+            need = False
+            if compression_ratio_threshold is not None and r.compression_ratio > compression_ratio_threshold:
+                need = True
+            if logprob_threshold is not None and r.avg_logprob < logprob_threshold:
+                need = True
+            if no_speech_threshold is not None and r.no_speech_prob > no_speech_threshold:
+                need = False
+            if need:
+                nxt.append(w)
+        pending = nxt
+        if not pending:
+            break
+    return results
+
+
+def _slice_segments(tokens: List[int], result: DecodingResult, tokenizer, time_offset: float, seek_sample: int,
+                    segment_duration: float, time_precision: float):
+    """original_whisper.py:406-421, 550-602: cut the window's tokens into segments at consecutive timestamp tokens."""
+    tb = tokenizer.timestamp_begin
+    tk = np.asarray(tokens, dtype=np.int64)
+    is_ts = tk >= tb
+    single_ts_ending = is_ts[-2:].tolist() == [False, True]
+    consecutive = (np.where(is_ts[:-1] & is_ts[1:])[0] + 1).tolist()
+
+    def seg(start, end, toks):
+        toks = [int(t) for t in toks]
+        return dict(seek=round(seek_sample / SAMPLE_RATE, 3), start=start, end=end,
+                    text=tokenizer.decode([t for t in toks if t < tokenizer.eot]), tokens=toks,
+                    temperature=result.temperature, avg_logprob=result.avg_logprob,
+                    compression_ratio=result.compression_ratio, no_speech_prob=result.no_speech_prob)
+
+    segs = []
+    end_ts_pos = 0
+    if consecutive:
+        cuts = list(consecutive)
+        if single_ts_ending:
+            cuts.append(len(tk))
+        last = 0
+        for cut in cuts:
+            sl = tk[last:cut]
+            start_pos = int(sl[0]) - tb
+            end_ts_pos = int(sl[-1]) - tb
+            segs.append(seg(round(time_offset + start_pos * time_precision, 3),
+                            round(time_offset + min(end_ts_pos * time_precision, segment_duration), 3), sl))
+            last = cut
+    else:
+        duration = segment_duration
+        ts = tk[is_ts]
+        if len(ts) > 0 and int(ts[-1]) != tb:
+            end_ts_pos = int(ts[-1]) - tb
+            duration = min(end_ts_pos * time_precision, segment_duration)
+        else:
+            end_ts_pos = 0
+        segs.append(seg(round(time_offset, 3), round(time_offset + duration, 3), tk))
+    return segs, single_ts_ending, end_ts_pos
+
+
+def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
+    """Runs the hot path for a batch of windows.  batch[w] = dict(audio=1-D f32 tensor (<=480000), seek_sample=int,
+    prompt=list[int], ts_mask=bool[1501] | None).  Returns per window dict(segments, segment_samples, result, skipped)."""
+    W = len(batch)
+    audios = [b["audio"] for b in batch]
+    seg_samples = [int(a.shape[-1]) for a in audios]
+    mel = model.log_mel_batch(audios, [max(N_SAMPLES - n, 0) for n in seg_samples])          # :528-530
+    xa = model.encoder(mel)
+    xkv = model.cross_kv(xa)
+    ts_masks = [b.get("ts_mask") for b in batch] if o["suppress_ts_tokens"] else None
+    if ts_masks is not None and all(m is None for m in ts_masks):
+        ts_masks = None
+    elif ts_masks is not None:
+        ts_masks = [torch.zeros(1501, dtype=torch.bool) if m is None else m for m in ts_masks]
+    results = _decode_with_fallback(model, xkv, o["decode_options"], o["temperatures"], [b["prompt"] for b in batch],
+                                    ts_masks, o["compression_ratio_threshold"], o["logprob_threshold"],
+                                    o["no_speech_threshold"])
+    time_precision = (N_FRAMES // model.dims.n_audio_ctx) * HOP_LENGTH / SAMPLE_RATE
+    punct = o["prepend_punctuations"] + o["append_punctuations"]
+    outs = []
+    for w in range(W):
+        r = results[w]
+        out = dict(segments=[], segment_samples=seg_samples[w], result=r, skipped=False, single_ts_ending=False,
+                   num_samples=seg_samples[w])
+        outs.append(out)
+        if o["no_speech_threshold"] is not None:                                                # :537-546
+            skip = r.no_speech_prob > o["no_speech_threshold"]
+            if o["logprob_threshold"] is not None and r.avg_logprob > o["logprob_threshold"]:
+                skip = False
+            if skip:
+                out["skipped"] = True
+                continue
+        if len(r.tokens) == 0:
+            out["skipped"] = True
+            continue
+        time_offset = batch[w]["seek_sample"] / SAMPLE_RATE
+        seg_dur = seg_samples[w] / SAMPLE_RATE
+        segs, single_end, end_ts_pos = _slice_segments(r.tokens, r, tokenizer, time_offset, batch[w]["seek_sample"],
+                                                       seg_dur, time_precision)
+        for i in reversed(range(len(segs))):                                                    # :604-627
+            s = segs[i]
+            if s["text"].strip() in punct:
+                del segs[i]
+            elif o["word_timestamps"]:
+                if s["start"] == s["end"]:
+                    del segs[i]
+            else:
+                nxt = i + 1
+                max_end = s["end"] if nxt >= len(segs) else segs[nxt]["start"]
+                if s["start"] > s["end"]:
+                    if i != 0 and segs[i - 1]["end"] != segs[i - 1]["start"] and segs[i - 1]["end"] < max_end:
+                        s["start"] = segs[i - 1]["end"]
+                    else:
+                        s["start"] = max_end
+        out["segments"] = segs
+        out["single_ts_ending"] = single_end
+        out["num_samples"] = (min(round(end_ts_pos * N_SAMPLES_PER_TOKEN), seg_samples[w]) if end_ts_pos > 0
+                              else seg_samples[w])                                              # :629-633
+
+    if o["word_timestamps"]:
+        idx = [w for w in range(W) if outs[w]["segments"]]
+        if idx:
+            add_word_timestamps_batch(                                                          # :635-652
+                model=model, tokenizer=tokenizer,
+                windows=[dict(segments=outs[w]["segments"], num_samples=outs[w]["num_samples"]) for w in idx],
+                xkv=_xkv_select(model, xkv, idx), prepend_punctuations=o["prepend_punctuations"],
+                append_punctuations=o["append_punctuations"], min_word_dur=o["min_word_dur"],
+                split_callback=o["split_callback"], gap_padding=o["gap_padding"])
+        for w in idx:
+            out = outs[w]
+            segs = out["segments"]
+            for i in reversed(range(len(segs))):                                                # :654-663
+                words = segs[i]["words"]
+                zero = np.array([wd["start"] == wd["end"] for wd in words]).astype(np.float16).mean()
+                if zero > o["max_instant_words"]:
+                    del segs[i]
+            if o["avg_prob_threshold"] and segs:                                                # :665-674
+                time_offset = batch[w]["seek_sample"] / SAMPLE_RATE
+                if out["single_ts_ending"] and (np.mean([wd["probability"] for s in segs for wd in s["words"]])
+                                                < o["avg_prob_threshold"]):
+                    out["num_samples"] = seg_samples[w]
+                    segs.clear()
+                else:
+                    out["num_samples"] = round((segs[-1]["words"][-1]["end"] - time_offset) * SAMPLE_RATE)
+    for w in range(W):
+        out = outs[w]
+        if not out["segments"]:
+            continue
+        if not out["single_ts_ending"] or o["avg_prob_threshold"]:                              # :703-704
+            out["segment_samples"] = out["num_samples"]
+    return outs
+
+
+def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
+                      temperature: Union[float, Tuple[float, ...]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
+                      compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
+                      no_speech_threshold: Optional[float] = 0.6, condition_on_previous_text: bool = True,
+                      initial_prompt: Optional[str] = None, word_timestamps: bool = True,
+                      regroup: Union[bool, str] = True, suppress_silence: bool = True, suppress_word_ts: bool = True,
+                      use_word_position: bool = True, q_levels: int = 20, k_size: int = 5, vad: bool = False,
+                      min_word_dur: Optional[float] = 0.1, min_silence_dur: Optional[float] = None,
+                      nonspeech_error: float = 0.1, prepend_punctuations: Optional[str] = None,
+                      append_punctuations: Optional[str] = None, suppress_ts_tokens: bool = False,
+                      gap_padding: str = " ...", max_instant_words: float = 0.5, avg_prob_threshold: Optional[float] = None,
+                      nonspeech_skip: Optional[float] = None, progress_callback: Callable = None,
+                      ignore_compatibility: bool = True, split_callback: Callable = None,
+                      batch_size: Optional[int] = None, **decode_options) -> WhisperResult:
+    """Same keyword surface as the reference's ``model.transcribe`` for the options that reach the hot path
+    (original_whisper.py:27-79); ``batch_size`` (window-parallel mode) is the only addition."""
+    unknown = set(decode_options) - _DECODE_KEYS
+    if unknown:
+        raise TypeError(f"transcribe() got unexpected keyword argument(s): {sorted(unknown)}")
+    if vad:
+        raise NotImplementedError("vad=True needs the Silero model (torch.hub, network) -- out of scope offline")
+    decode_options = dict(decode_options)
+    decode_options["fp16"] = model.engine.dtype_name == "f16"
+    if "max_initial_timestamp" not in decode_options:
+        decode_options["max_initial_timestamp"] = None                                         # :262-263
+    task = decode_options.get("task", "transcribe")
+    audio = load_audio(audio)
+    total = int(audio.shape[-1])
+
+    language = decode_options.get("language")
+    if not language:
+        if not model.is_multilingual:
+            language = "en"
+        else:                                                                                   # :319-336
+            first = audio[:N_SAMPLES]
+            mel0 = model.log_mel(first, N_SAMPLES - first.shape[-1])
+            _, probs = model.detect_language(mel0)
+            language = max(probs, key=probs.get)
+    decode_options["language"] = language
+    tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language, task=task)
+
+    all_tokens: List[int] = []
+    initial_prompt_tokens: List[int] = []
+    if initial_prompt is not None:                                                              # :342-345
+        initial_prompt_tokens = tokenizer.encode(" " + initial_prompt.strip())
+        all_tokens.extend(initial_prompt_tokens)
+
+    nonspeech = None
+    if suppress_silence or suppress_ts_tokens or nonspeech_skip:
+        from .stabilization import NonSpeechPredictor
+        nonspeech = NonSpeechPredictor(q_levels=q_levels, k_size=k_size, min_word_dur=min_word_dur,
+                                       min_silence_dur=min_silence_dur, get_mask=suppress_ts_tokens)
+
+    o = dict(decode_options=decode_options,
+             temperatures=[temperature] if isinstance(temperature, (int, float)) else list(temperature),
+             compression_ratio_threshold=compression_ratio_threshold, logprob_threshold=logprob_threshold,
+             no_speech_threshold=no_speech_threshold, word_timestamps=word_timestamps,
+             prepend_punctuations=PREPEND_PUNCTUATIONS if prepend_punctuations is None else prepend_punctuations,
+             append_punctuations=APPEND_PUNCTUATIONS if append_punctuations is None else append_punctuations,
+             min_word_dur=0.1 if min_word_dur is None else min_word_dur, split_callback=split_callback,
+             gap_padding=gap_padding, max_instant_words=max_instant_words, avg_prob_threshold=avg_prob_threshold,
+             suppress_ts_tokens=suppress_ts_tokens)
+
+    all_segments: List[dict] = []
+
+    def window_input(seek: int, prompt: List[int]):
+        seg = audio[seek: seek + N_SAMPLES]
+        item = dict(audio=seg, seek_sample=seek, prompt=prompt, ts_mask=None, silence=None, skip=False)
+        if nonspeech is not None:
+            pred = nonspeech.predict(seg, offset=seek / SAMPLE_RATE)
+            item["silence"] = pred["timings"] if suppress_silence else None
+            item["ts_mask"] = pred["mask"]
+            item["skip"] = pred["is_silent"]
+            if nonspeech_skip and pred["timings"] is not None and not item["skip"]:               # :513-526
+                starts = pred["timings"][0] - seek / SAMPLE_RATE
+                ends = pred["timings"][1] - seek / SAMPLE_RATE
+                long_idx = np.flatnonzero((ends - starts) >= nonspeech_skip)
+                if len(long_idx):
+                    k = long_idx[0]
+                    if starts[k] < o["min_word_dur"] or int(starts[k] * SAMPLE_RATE) == 0:
+                        item["skip"] = True
+                        item["skip_samples"] = round(ends[k] * SAMPLE_RATE)
+                    else:
+                        item["audio"] = seg[: int(starts[k] * SAMPLE_RATE)]
+        return item
+
+    def commit(item: dict, out: dict):
+        """original_whisper.py:676-708 for one finished window; returns the samples to advance by."""
+        segs = out["segments"]
+        if not segs:
+            return out["segment_samples"]
+        all_tokens.extend(t for s in segs for t in s["tokens"])
+        if item["silence"] is not None:
+            from .stabilization import suppress_segment_silence
+            for s in segs:
+                suppress_segment_silence(s, *item["silence"], min_word_dur=o["min_word_dur"], word_level=suppress_word_ts,
+                                         nonspeech_error=nonspeech_error, use_word_position=use_word_position)
+        for s in segs:
+            all_segments.append({"id": len(all_segments), **s})
+        return out["segment_samples"]
+
+    seek = 0
+    if batch_size:
+        # ---- window-parallel driver: fixed stride, no prompt carry-over
+        seeks = list(range(0, total, N_SAMPLES))
+        for b0 in range(0, len(seeks), batch_size):
+            items = [window_input(s, list(initial_prompt_tokens)) for s in seeks[b0: b0 + batch_size]]
+            live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
+            outs = _process_batch(model, tokenizer, live, o) if live else []
+            for it, out in zip(live, outs):
+                commit(it, out)
+            if progress_callback is not None:
+                progress_callback(min(total, (b0 + len(items)) * N_SAMPLES) / SAMPLE_RATE, total / SAMPLE_RATE)
+    else:
+        # ---- sequential driver (reference control flow)
+        prompt_reset_since = 0
+        while seek < total:
+            item = window_input(seek, all_tokens[prompt_reset_since:])
+            n_seg = int(item["audio"].shape[-1])
+            if n_seg == 0:
+                break
+            if item["skip"]:
+                seek += item.get("skip_samples", n_seg)
+                continue
+            out = _process_batch(model, tokenizer, [item], o)[0]
+            adv = commit(item, out)
+            if out["segments"]:
+                if not condition_on_previous_text or out["result"].temperature > 0.5:            # :706-708
+                    prompt_reset_since = len(all_tokens)
+            seek += max(int(adv), 1) if adv is not None else n_seg
+            if progress_callback is not None:
+                progress_callback(min(seek, total) / SAMPLE_RATE, total / SAMPLE_RATE)
+
+    text = tokenizer.decode(all_tokens[len(initial_prompt_tokens):])
+    result = WhisperResult(dict(text=text, segments=all_segments, language=language), force_order=not word_timestamps)
+    if nonspeech is not None and suppress_silence:
+        result.nonspeech_sections = nonspeech.sections()
+    if word_timestamps and regroup:
+        from .regroup import regroup_default
+        regroup_default(result, regroup)
+    if len(result.text) == 0:
+        warnings.warn(f"Failed to {task} audio. Result contains no text. ")
+    return result

@@ -1,0 +1,113 @@
+"""Generate golden fixtures by running the REFERENCE's own glue (/root/reference/stable_whisper: transcribe_stable,
+decode.py, timing.py, non_whisper/alignment.py) on top of the CPU oracle (oracle/whisper standing in for the
+un-vendored openai-whisper).  Only runs where /root/reference exists (this container); the JSON it writes is
+committed and is what the GPU tests compare the HIP path against.
+
+    python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))
+
+
+def import_reference():
+    import oracle.whisper as ow
+    sys.modules["whisper"] = ow
+    for sub in ("audio", "model", "decoding", "timing", "tokenizer"):
+        sys.modules["whisper." + sub] = getattr(ow, sub)
+    sys.path.insert(0, "/root/reference")
+    import stable_whisper
+    return stable_whisper
+
+
+def synth_audio(seconds: float, seed: int = 0) -> torch.Tensor:
+    """Synthetic 16 kHz 'speech-like' audio: AM sinusoid bursts + noise, with silent gaps."""
+    n = int(seconds * 16000)
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(n) / 16000.0
+    x = torch.zeros(n)
+    for k in range(5):
+        f = 120.0 * (k + 1) * (1.0 + 0.37 * k)
+        am = 0.5 + 0.5 * torch.sin(2 * np.pi * (1.3 + 0.7 * k) * t + k)
+        x += (0.25 / (k + 1)) * torch.sin(2 * np.pi * f * t) * am
+    x += 0.01 * torch.randn(n, generator=g)
+    gap_starts = torch.arange(4.0, seconds, 5.0)
+    for i, s in enumerate(gap_starts.tolist()):
+        d = 0.3 + 0.7 * ((i * 7919) % 10) / 10.0
+        x[int(s * 16000): int((s + d) * 16000)] = 0.0
+    return (x * 0.5 / x.abs().max()).float()
+
+
+CASES = [
+    dict(name="tiny_en_t0_ss", model="tiny.en", gain=2.0, ts_gain=0.5, seconds=47.0, seed=1,
+         opts=dict(temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+                   sample_len=40, suppress_silence=True)),
+    dict(name="tiny_en_beam_noss", model="tiny.en", gain=2.0, ts_gain=0.5, seconds=33.0, seed=2,
+         opts=dict(temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+                   sample_len=36, beam_size=5, suppress_silence=False)),
+    dict(name="base_en_t0_prompt", model="base.en", gain=2.0, ts_gain=0.5, seconds=38.0, seed=3,
+         opts=dict(temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+                   sample_len=32, suppress_silence=True, initial_prompt=" abcd efgh")),
+]
+
+ALIGN_CASES = [
+    dict(name="align_tiny_en", model="tiny.en", gain=2.0, ts_gain=0.5, seconds=21.0, seed=4, n_words=30),
+]
+
+
+def run():
+    sw = import_reference()
+    from oracle.whisper.model import build_model
+    out = {}
+    for c in CASES:
+        model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+        sw.modify_model(model)
+        audio = synth_audio(c["seconds"], c["seed"])
+        res = model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, regroup=False,
+                               word_timestamps=True, **c["opts"])
+        d = res.to_dict()
+        segs = [dict(start=float(s["start"]), end=float(s["end"]), seek=float(s["seek"]), tokens=[int(t) for t in s["tokens"]],
+                     words=[dict(word=w["word"], start=float(w["start"]), end=float(w["end"]),
+                                 probability=float(w["probability"]), tokens=[int(t) for t in w["tokens"]])
+                            for w in s["words"]]) for s in d["segments"]]
+        out[c["name"]] = dict(case=c, segments=segs, text=d["text"])
+        print(c["name"], len(segs), "segments", sum(len(s["words"]) for s in segs), "words")
+    for c in ALIGN_CASES:
+        model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+        sw.modify_model(model)
+        audio = synth_audio(c["seconds"], c["seed"])
+        g = torch.Generator().manual_seed(c["seed"])
+        ids = (torch.randint(6, 16000, (c["n_words"],), generator=g) * 3 + 19).tolist()      # word-start tokens (id % 3 != 0)
+        from oracle.whisper.tokenizer import get_tokenizer
+        tok = get_tokenizer(False, num_languages=model.num_languages)
+        text = tok.decode(ids)
+        # seam B2 (alignment.py:396-429): the reference's own compute_timestamps on the oracle model
+        from types import SimpleNamespace
+        from stable_whisper.alignment import get_whisper_alignment_func
+        from stable_whisper.non_whisper.alignment import WordToken
+        opts = SimpleNamespace(align=SimpleNamespace(extra_models=None, dynamic_heads=None, aligner="legacy"))
+        func = get_whisper_alignment_func(model, tok, None, opts)
+        wts = [WordToken(tok.decode([i]), [i]) for i in ids]
+        b2 = func(audio, wts)
+        b2 = [dict(word=w["word"], start=float(w["start"]), end=float(w["end"]), probability=float(w["probability"]),
+                   tokens=[int(t) for t in w["tokens"]]) for w in b2]
+        res = model.align(audio, text, language="en", verbose=None, ignore_compatibility=True, regroup=False,
+                          suppress_silence=False, original_split=False)
+        words = [dict(word=w.word, start=float(w.start), end=float(w.end), probability=float(w.probability),
+                      tokens=[int(t) for t in w.tokens]) for w in res.all_words()]
+        out[c["name"]] = dict(case=c, text=text, ids=ids, words=words, b2=b2)
+        print(c["name"], len(words), "words", len(b2), "b2 words")
+    with open(os.path.join(HERE, "reference_glue.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
+if __name__ == "__main__":
+    run()

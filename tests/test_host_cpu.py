@@ -1,0 +1,111 @@
+"""CPU-only tests: C-ABI library loads and exports every symbol of include/swx.h, weight generators agree, host logic."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    from stable_ts_amd import _lib
+    lib = _lib.load(build_if_missing=True)
+    hdr = open(os.path.join(ROOT, "include", "swx.h")).read()
+    names = set(re.findall(r"\b(swx_[a-z0-9_]+)\s*\(", hdr))
+    assert names, "no prototypes found"
+    for n in sorted(names):
+        assert hasattr(lib, n), f"libswx.so does not export {n}"
+        assert n in _lib.SYMBOLS, f"ctypes table lacks {n}"
+    assert lib.swx_version() >= 1
+    assert lib.swx_strerror(-4).decode().startswith("gemm")
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "stable_ts_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_no_cpu_path():
+    import stable_ts_amd as sw
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(Exception):
+        sw.load_model("tiny.en", weights="random")
+    with pytest.raises(RuntimeError):
+        sw.load_model("tiny.en", device="cpu", weights="random")
+
+
+def test_random_state_dict_matches_oracle_generator():
+    import stable_ts_amd as sw
+    from oracle.whisper import model as om
+    for name in ("tiny.en", "base"):
+        a = om.random_state_dict(om.dims_for(name), 7, 0.02, 3.0, 0.5)
+        b = sw.random_state_dict(sw.dims_for(name), 7, 0.02, 3.0, 0.5)
+        assert list(a) == list(b)
+        assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_mel_filterbank_matches_oracle():
+    from oracle.whisper.audio import _mel_filters_np
+    from stable_ts_amd.audio import slaney_mel_filterbank
+    for n in (80, 128):
+        assert np.array_equal(_mel_filters_np(n), slaney_mel_filterbank(n))
+
+
+def test_tokenizer_roundtrip_and_ids():
+    from stable_ts_amd.tokenizer import get_tokenizer
+    en = get_tokenizer(False, num_languages=99)
+    assert (en.eot, en.sot, en.no_timestamps, en.timestamp_begin) == (50256, 50257, 50362, 50363)
+    assert en.timestamp_begin + 1500 == 51863
+    ml = get_tokenizer(True, num_languages=100, language="en", task="transcribe")
+    assert (ml.eot, ml.sot, ml.no_timestamps, ml.timestamp_begin) == (50257, 50258, 50364, 50365)
+    assert ml.sot_sequence == (50258, 50259, 50360)
+    ids = [19, 18, 3, 17, 40000, 21, 0, 16, 25]
+    assert en.encode(en.decode(ids)) == ids
+    assert en.encode(" ...") == [17] and en.encode(" ") == [16]
+
+
+def test_split_tokens_and_punctuation_merge_match_oracle_glue():
+    from oracle import stable as ost
+    from stable_ts_amd import timing as pt
+    from stable_ts_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer(False, num_languages=99)
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        toks = rng.integers(0, 50000, size=rng.integers(1, 30)).tolist()
+        assert pt._split_tokens(list(toks), tok) == ost.split_tokens(list(toks), tok)
+    segs = [dict(tokens=[50363, 19, 20, 0, 50400], seek=0.0), dict(tokens=[50400, 40, 21, 1, 50500], seek=0.0)]
+    a = pt.split_word_tokens([dict(s) for s in segs], tok, padding=" ...")
+    b = ost.split_word_tokens([dict(s) for s in segs], tok, padding=" ...")
+    assert a == b
+
+
+def test_stabilization_matches_reference_semantics():
+    from stable_ts_amd.stabilization import NonSpeechPredictor, mask2timing, suppress_segment_silence, wav2mask
+    t = torch.arange(16000 * 10) / 16000.0
+    x = 0.4 * torch.sin(2 * np.pi * 300 * t)
+    x[16000 * 3: 16000 * 5] = 0
+    m = wav2mask(x)
+    s, e = mask2timing(m)
+    assert len(s) == 1 and abs(s[0] - 3.0) < 0.1 and abs(e[0] - 5.0) < 0.1
+    p = NonSpeechPredictor(get_mask=True).predict(x, offset=10.0)
+    assert not p["is_silent"] and p["mask"].shape == (1501,) and abs(p["timings"][0][0] - 13.0) < 0.1
+    assert NonSpeechPredictor().predict(torch.zeros(16000 * 5))["is_silent"]
+    seg = dict(start=2.0, end=6.0, words=[dict(word=" a", start=2.0, end=3.5), dict(word=" b.", start=3.5, end=6.0)])
+    suppress_segment_silence(seg, s, e, min_word_dur=0.1)
+    assert seg["words"][0]["start"] == 2.0 and seg["words"][1]["end"] == 6.0
+
+
+def test_result_container():
+    from stable_ts_amd.result import UnsortedException, WhisperResult
+    r = WhisperResult(dict(language="en", segments=[dict(start=0.0, end=1.0, text=" a b", seek=0.0, tokens=[1, 2], words=[
+        dict(word=" a", start=0.0, end=0.5, probability=0.9, tokens=[1]), dict(word=" b", start=0.5, end=1.0, probability=0.8, tokens=[2])])]))
+    d = r.to_dict()
+    assert d["text"] == " a b" and d["segments"][0]["words"][1]["end"] == 1.0 and r.has_words and len(r.all_words()) == 2
+    with pytest.raises(UnsortedException):
+        WhisperResult(dict(segments=[dict(start=2.0, end=1.0, text="x")]))

@@ -1,0 +1,55 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: window sharding, weight-arena broadcast, result gather."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from stable_ts_amd import parallel as par
+    r, _, w = par.init_from_env(backend="gloo")
+    arena = torch.arange(1000, dtype=torch.uint8) if r == 0 else torch.zeros(1000, dtype=torch.uint8)
+    par.broadcast_arena(arena, src=0)
+    ok_arena = bool(torch.equal(arena, torch.arange(1000, dtype=torch.uint8)))
+    mine = par.shard_windows(7, r, w)
+    recs = [dict(window=i, words=[dict(word=f"w{i}", start=30.0 * i, end=30.0 * i + 1)]) for i in mine]
+    allr = par.gather_results(recs, dst=0)
+    mx = par.max_over_ranks(float(r + 1))
+    par.barrier()
+    q.put((r, ok_arena, list(mine), None if allr is None else [x["window"] for x in allr], mx))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_roundtrip():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ok0, m0, all0, mx0), (r1, ok1, m1, all1, mx1) = out
+    assert ok0 and ok1
+    assert m0 == [0, 1, 2, 3] and m1 == [4, 5, 6]
+    assert all0 == [0, 1, 2, 3, 4, 5, 6] and all1 is None
+    assert mx0 == mx1 == 2.0
+
+
+def test_shard_windows_partition():
+    from stable_ts_amd.parallel import shard_windows
+    for n in (0, 1, 7, 8, 20, 961):
+        for world in (1, 2, 4, 8):
+            parts = [list(shard_windows(n, r, world)) for r in range(world)]
+            flat = [i for p in parts for i in p]
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
