@@ -21,6 +21,7 @@ import argparse
 import ctypes
 import json
 import os
+import signal
 import sys
 import time
 
@@ -55,6 +56,14 @@ def synth_audio(seconds: float, seed: int = 0) -> torch.Tensor:
     return (x * 0.5 / x.abs().max()).float()
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries exactly one JSON line)"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +77,7 @@ def main():
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=240.0, help="hard cap (s) on the CPU-baseline leg")
     args = ap.parse_args()
 
     import stable_ts_amd as sw
@@ -84,7 +94,9 @@ def main():
                        max_rows=args.batch * args.beam)
     sd = None
     if rank == 0:
+        log("generating random weights")
         sd = sw.random_state_dict(dims, seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5)
+        log("loading weights into the arena")
         model.load_state_dict(sd)
     par.broadcast_arena(model.engine.arena, src=0)        # RCCL broadcast of the packed weights (no-op at N=1)
     if rank != 0:
@@ -100,8 +112,10 @@ def main():
         return model.transcribe(audio, **kw)
 
     res = None
+    log("warmup")
     for _ in range(args.warmup):
         res = step()
+    log("timed steps")
     par.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -111,6 +125,7 @@ def main():
     par.barrier()
     dt = par.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
 
+    log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     n_words = len(res.all_words()) if res is not None else 0
     n_segs = len(res.segments) if res is not None else 0
     gathered = par.gather_results([dict(rank=rank, segments=n_segs, words=n_words)])
@@ -132,6 +147,7 @@ def main():
 
     # ---- roofline: one extra instrumented pass (not part of `value`)
     if rank == 0 and not args.no_roofline:
+        log("instrumented pass (roofline)")
         lib = model.engine.lib
         lib.swx_prof_enable(1)
         step()
@@ -164,10 +180,20 @@ def main():
 
     # ---- CPU baseline (oracle port), bounded sample, rank 0 at N=1 only
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle port)")
+        del model
+        torch.cuda.empty_cache()
+
+        def _alarm(signum, frame):
+            raise TimeoutError(f"cpu baseline exceeded its {args.cpu_budget:g}s budget")
+        signal.signal(signal.SIGALRM, _alarm)
+        signal.alarm(int(args.cpu_budget))
         try:
             out["cpu_baseline"] = cpu_baseline(args, sd, dims)
-        except Exception as e:   # the baseline must never take the bench line down
-            out["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+        except BaseException as e:   # the baseline must never take the bench line down
+            out["cpu_baseline"] = {"value": None, "unit": "x real time", "kind": "port", "error": f"{type(e).__name__}: {e}"}
+        finally:
+            signal.alarm(0)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -183,8 +209,13 @@ def cpu_baseline(args, sd, dims):
     from oracle.whisper.audio import log_mel_spectrogram
     from oracle.whisper.decoding import DecodingOptions
     from oracle.whisper.tokenizer import get_tokenizer
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
     m = om.Whisper(om.ModelDimensions(**dims.__dict__))
     m.load_state_dict(sd)
     m.eval()
@@ -194,15 +225,18 @@ def cpu_baseline(args, sd, dims):
         mask[l, h] = True
     m.set_alignment_heads_mask(mask)
     audio = synth_audio(30.0, seed=0)
-    steps_cpu = 8
+    steps_cpu = 4
     t = {}
+    log("cpu: model built; mel")
     t0 = time.perf_counter()
     mel = log_mel_spectrogram(audio, dims.n_mels)
     t["mel"] = time.perf_counter() - t0
+    log("cpu: encoder")
     t0 = time.perf_counter()
     with torch.no_grad():
         xa = m.encoder(mel[None])
     t["encoder"] = time.perf_counter() - t0
+    log(f"cpu: encoder {t['encoder']:.1f}s; decode")
     t0 = time.perf_counter()
     opts = DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=steps_cpu,
                            beam_size=args.beam if args.beam > 1 else None)
