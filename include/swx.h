@@ -74,7 +74,8 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
 
 /* ---- cross-attention K/V of every decoder layer for B windows (upstream recomputes them lazily through the
  * kv-cache hooks; here they are produced once per window and shared by decode + scoring)
- * d_xkv: compute dtype [L][B*1500][2*d]  (K | V) */
+ * d_xkv: compute dtype [L][B][ K: 1500 x d row-major | V^T: d x 1536 (per head [64][1536], keys contiguous, zero padded) ]
+ *        (the decode-step cross-attention streams both operands as coalesced 16-byte MFMA fragments) */
 size_t swx_cross_kv_bytes(const swx_model *m, int B);
 int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *stream);
 
@@ -159,8 +160,9 @@ int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, cons
                   void *d_c, int64_t ldc, int M, int N, int K, int epilogue, int force_kernel, void *stream);
 int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float *d_b, void *d_y, int rows, int d,
                        void *stream);
+/* vt_kp > 0: d_v is transposed per batch item, [H][64][vt_kp] (keys contiguous, zero padded) -- the cross-KV layout */
 int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k, const void *d_v, int64_t ldkv,
-                       void *d_o, int64_t ldo, int B, int H, int nq, int nk, int force_kernel, void *stream);
+                       void *d_o, int64_t ldo, int B, int H, int nq, int nk, int force_kernel, int vt_kp, void *stream);
 
 #ifdef __cplusplus
 }

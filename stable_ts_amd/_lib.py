@@ -68,7 +68,7 @@ SYMBOLS = {
                               c_int, c_int, c_int, c_void_p]),
     "swx_test_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "swx_test_attention": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
-                                   c_int, c_int, c_int, c_int, c_void_p]),
+                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -59,14 +59,18 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
             const int c = tid + 256 * i, key = c >> 3, dc = (c & 7) * 8;
             const int kg = kt0 + key;
             f16x8 kv = (f16x8)(f16)0, vv = (f16x8)(f16)0;
-            if (kg < a.nk) {
-                const size_t off = ((size_t)b * a.nk + kg) * a.ldkv + h * DH + dc;
-                kv = *(const f16x8 *)(K + off);
-                vv = *(const f16x8 *)(V + off);
-            }
+            if (kg < a.nk) kv = *(const f16x8 *)(K + (size_t)b * a.k_bs + (size_t)kg * a.ldkv + h * DH + dc);
             *(f16x8 *)&Ks[key][dc] = kv;
+            if (a.vt_kp) {
+                // V already transposed in HBM ([H][64][kp], zero padded): chunk c -> d row c>>3, 8 keys at (c&7)*8
+                const int dr = c >> 3, kc = (c & 7) * 8;
+                vv = *(const f16x8 *)(V + (size_t)b * a.v_bs + ((size_t)h * DH + dr) * a.vt_kp + kt0 + kc);
+                *(f16x8 *)&Vt[dr][kc] = vv;
+            } else {
+                if (kg < a.nk) vv = *(const f16x8 *)(V + (size_t)b * a.v_bs + (size_t)kg * a.ldkv + h * DH + dc);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) Vt[dc + e][key] = vv[e];
+                for (int e = 0; e < 8; ++e) Vt[dc + e][key] = vv[e];
+            }
         }
         __syncthreads();
 
@@ -143,6 +147,115 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
     }
 }
 
+// ============================================================================================ decode cross
+// Decode-step cross-attention: <= 16 queries (the G beams of one window) against the window's 1500 encoder positions.
+// HBM-bound: the only traffic that matters is ONE pass over this (window, head)'s K [1500][64] and V^T [64][kp]
+// (384 KB in fp16), so nothing is staged in LDS -- every MFMA fragment is a coalesced 16-byte global load:
+//   S^T[16 keys][16 q] = K-frag . Q^T        (K rows gathered so that a lane ends up holding 8 CONSECUTIVE keys)
+//   O^T[64 d][16 q]   += V^T-frag . P^T      (V^T rows are key-contiguous: 16-byte loads again)
+// 4 waves split the keys (32-key blocks, round-robin) with a private online softmax each and merge through LDS once.
+__global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
+{
+    __shared__ float sm_m[4][16], sm_l[4][16];
+    __shared__ float sm_o[4][DH][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int qn = lane & 15, g = lane >> 4;
+    const f16 *Q = (const f16 *)a.q;
+    const f16 *Kp = (const f16 *)a.k + (size_t)b * a.k_bs + h * DH;
+    const f16 *Vp = (const f16 *)a.v + (size_t)b * a.v_bs + (size_t)h * DH * a.vt_kp;
+
+    f16x8 qf[2];
+    {
+        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qn < a.nq ? qn : 0)) * a.ldq + h * DH + g * 8;
+        qf[0] = (qn < a.nq) ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
+        qf[1] = (qn < a.nq) ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -__builtin_inff(), l_run = 0.f;
+    const int nblk = (a.nk + 31) >> 5;
+    // A-row i of S^T tile t  <->  key k0 + (i>>2)*8 + (i&3) + 4t, so that lane (q, g) owns keys k0 + g*8 + 0..7
+    const int krow = (qn >> 2) * 8 + (qn & 3);
+
+#pragma unroll 2
+    for (int cb = wave; cb < nblk; cb += 4) {
+        const int k0 = cb << 5;
+        f16x8 kf[2][2], vf[4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int key = k0 + krow + 4 * t;
+            const f16 *kr = Kp + (size_t)(key < a.nk ? key : 0) * a.ldkv + g * 8;
+            kf[t][0] = (key < a.nk) ? *(const f16x8 *)(kr) : (f16x8)(f16)0;
+            kf[t][1] = (key < a.nk) ? *(const f16x8 *)(kr + 32) : (f16x8)(f16)0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) vf[t] = *(const f16x8 *)(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);
+
+        f32x4 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][0], qf[0], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][1], qf[1], s[t], 0, 0, 0);
+        }
+        float tmax = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + g * 8 + 4 * t + r;
+                const float v = (key < a.nk) ? s[t][r] * 0.125f : -__builtin_inff();
+                s[t][r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.f;
+        f16x8 pb;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(s[t][r] - m_new);
+                psum += p;
+                pb[4 * t + r] = (f16)p;
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            o[t][0] *= alpha; o[t][1] *= alpha; o[t][2] *= alpha; o[t][3] *= alpha;
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t], pb, o[t], 0, 0, 0);
+        }
+    }
+
+    // merge the four partial softmaxes: o[t][r] is O^T[d = t*16 + g*4 + r][q = qn]
+    if (g == 0) { sm_m[wave][qn] = m_run; sm_l[wave][qn] = l_run; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sm_o[wave][t * 16 + g * 4 + r][qn] = o[t][r];
+    __syncthreads();
+    for (int i = tid; i < a.nq * DH; i += 256) {
+        const int q = i >> 6, d = i & 63;
+        const float M = fmaxf(fmaxf(sm_m[0][q], sm_m[1][q]), fmaxf(sm_m[2][q], sm_m[3][q]));
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float f = __expf(sm_m[w][q] - M);
+            L += sm_l[w][q] * f;
+            O += sm_o[w][d][q] * f;
+        }
+        ((f16 *)a.o)[((size_t)b * a.q_rows_per_batch + q) * a.ldo + h * DH + d] = (f16)(O / L);
+    }
+}
+
 // ============================================================================================ dense rowwise
 constexpr int RW_QB = 8;
 constexpr int RW_MAXK = 1536;
@@ -159,8 +272,8 @@ __global__ __launch_bounds__(256) void attn_dense_rowwise(AttnArgs a)
     const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * RW_QB;
     const int nqb = min(RW_QB, a.nq - q0);
     const T *Q = (const T *)a.q;
-    const T *K = (const T *)a.k + (size_t)b * a.nk * a.ldkv + h * DH;
-    const T *V = (const T *)a.v + (size_t)b * a.nk * a.ldkv + h * DH;
+    const T *K = (const T *)a.k + (size_t)b * a.k_bs + h * DH;
+    const T *V = (const T *)a.v + (size_t)b * a.v_bs + (a.vt_kp ? (size_t)h * DH * a.vt_kp : (size_t)h * DH);
 
     for (int i = tid; i < RW_QB * DH; i += 256) {
         const int qi = i >> 6, d = i & 63;
@@ -206,10 +319,28 @@ __global__ __launch_bounds__(256) void attn_dense_rowwise(AttnArgs a)
     float acc[RW_QB];
 #pragma unroll
     for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = 0.f;
-    for (int j = wave; j < a.nk; j += 4) {
-        const float vv = to_f32<T>(V[(size_t)j * a.ldkv + lane]);
+    if (a.vt_kp) {
+        // transposed V: lane = d streams its own key row, wave = contiguous quarter of the keys
+        const int per = ((a.nk + 31) / 32) * 8;
+        const int j_lo = wave * per, j_hi = min(a.nk, j_lo + per);
+        const T *vr = V + (size_t)lane * a.vt_kp;
+        for (int j0 = j_lo; j0 < j_hi; j0 += 8) {
+            float vv[8];
+            load8<T>(vr + j0, vv);
 #pragma unroll
-        for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = fmaf(sc[qi * nkp + j], vv, acc[qi]);
+            for (int e = 0; e < 8; ++e) {
+                if (j0 + e < j_hi) {
+#pragma unroll
+                    for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = fmaf(sc[qi * nkp + j0 + e], vv[e], acc[qi]);
+                }
+            }
+        }
+    } else {
+        for (int j = wave; j < a.nk; j += 4) {
+            const float vv = to_f32<T>(V[(size_t)j * a.ldkv + lane]);
+#pragma unroll
+            for (int qi = 0; qi < RW_QB; ++qi) acc[qi] = fmaf(sc[qi * nkp + j], vv, acc[qi]);
+        }
     }
 #pragma unroll
     for (int qi = 0; qi < RW_QB; ++qi) part[(wave * RW_QB + qi) * DH + lane] = acc[qi];
@@ -284,7 +415,7 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
 // =============================================================================================== qk capture
 template <typename T>
 __global__ __launch_bounds__(256) void qk_capture_kernel(const T *__restrict__ q, int64_t ldq, int q_rows_per_w, int row0,
-                                                         const T *__restrict__ k, int64_t ldk, int nk,
+                                                         const T *__restrict__ k, int64_t ldk, int64_t k_bs, int nk,
                                                          const int32_t *__restrict__ heads, int head_slot0, int slots_total,
                                                          float *__restrict__ out, int out_ld_n, int out_ld_f)
 {
@@ -297,7 +428,7 @@ __global__ __launch_bounds__(256) void qk_capture_kernel(const T *__restrict__ q
     __syncthreads();
     float *orow = out + (((size_t)w * slots_total + head_slot0 + hs) * out_ld_n + i) * out_ld_f;
     for (int f = threadIdx.x; f < nk; f += 256) {
-        const T *kr = k + ((size_t)w * nk + f) * ldk + head * DH;
+        const T *kr = k + (size_t)w * k_bs + (size_t)f * ldk + head * DH;
         float acc = 0.f;
 #pragma unroll 2
         for (int d0 = 0; d0 < DH; d0 += 8) {
@@ -318,7 +449,12 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     if (a.nk > RW_MAXK) return -5;
     const bool flash = (dtype == SWX_F16) && (force_kernel == 2 || (force_kernel == 0 && a.nq >= 32));
     const size_t esz = dtype == SWX_F16 ? 2 : 4;
-    if (flash) {
+    const bool dec = (dtype == SWX_F16) && a.vt_kp > 0 && a.nq <= 16 && a.nk >= 128 && (force_kernel == 3 || force_kernel == 0);
+    if (force_kernel == 3 && !dec) return -5;
+    if (dec) {
+        SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
+        hipLaunchKernelGGL(attn_decode_cross_f16, dim3(a.H, a.B), dim3(256), 0, s, a);
+    } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
         dim3 g(cdiv(a.nq, 64), a.H, a.B);
@@ -355,15 +491,15 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
 }
 
 int swx_qk_capture(int dtype, const void *q, int64_t ldq, int q_rows_per_w, int row0, int n_rows, const void *k,
-                   int64_t ldk, int nk, const int32_t *heads, int n_heads, int head_slot0, int slots_total, int W,
+                   int64_t ldk, int64_t k_bs, int nk, const int32_t *heads, int n_heads, int head_slot0, int slots_total, int W,
                    float *out, int out_ld_n, int out_ld_f, hipStream_t s)
 {
     if (n_rows <= 0 || n_heads <= 0 || W <= 0) return 0;
     dim3 g(n_rows, n_heads, W);
     if (dtype == SWX_F16)
-        hipLaunchKernelGGL(qk_capture_kernel<f16>, g, dim3(256), 0, s, (const f16 *)q, ldq, q_rows_per_w, row0, (const f16 *)k, ldk, nk, heads, head_slot0, slots_total, out, out_ld_n, out_ld_f);
+        hipLaunchKernelGGL(qk_capture_kernel<f16>, g, dim3(256), 0, s, (const f16 *)q, ldq, q_rows_per_w, row0, (const f16 *)k, ldk, k_bs, nk, heads, head_slot0, slots_total, out, out_ld_n, out_ld_f);
     else
-        hipLaunchKernelGGL(qk_capture_kernel<float>, g, dim3(256), 0, s, (const float *)q, ldq, q_rows_per_w, row0, (const float *)k, ldk, nk, heads, head_slot0, slots_total, out, out_ld_n, out_ld_f);
+        hipLaunchKernelGGL(qk_capture_kernel<float>, g, dim3(256), 0, s, (const float *)q, ldq, q_rows_per_w, row0, (const float *)k, ldk, k_bs, nk, heads, head_slot0, slots_total, out, out_ld_n, out_ld_f);
     SWX_CHECK_LAUNCH();
     return 0;
 }

@@ -24,7 +24,13 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int c
     if (g.epi & EPI_GELU) v = gelu_erf(v);
     if (g.epi & EPI_RESF32MOD) v += g.Rf[(size_t)(row % g.res_mod) * g.N + col];
     if (g.epi & EPI_RES) v += to_f32<T>(((const T *)g.R)[(size_t)row * g.ldr + col]);
-    if (g.epi & EPI_OUT_F32) ((float *)g.C)[(size_t)row * g.ldc + col] = v;
+    if (g.epi & EPI_STORE_VT) {
+        const int w = row / g.vt_s, sidx = row - w * g.vt_s;
+        ((T *)g.C)[(size_t)w * g.vt_bs + (size_t)col * g.vt_kp + sidx] = from_f32<T>(v);   // col = h*64 + dd
+    } else if (g.epi & EPI_CBATCH) {
+        const int w = row / g.vt_s, sidx = row - w * g.vt_s;
+        ((T *)g.C)[(size_t)w * g.vt_bs + (size_t)sidx * g.ldc + col] = from_f32<T>(v);
+    } else if (g.epi & EPI_OUT_F32) ((float *)g.C)[(size_t)row * g.ldc + col] = v;
     else ((T *)g.C)[(size_t)row * g.ldc + col] = from_f32<T>(v);
 }
 
@@ -173,9 +179,15 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
 }
 
 // ----------------------------------------------------------------------------------------------- skinny f16
+// HBM-bound weight streaming for the decode steps.  Workgroup = one 16-column weight panel, its 4 waves split K.
+// Per wave the K slice is walked in chunks of CH k-steps with a two-deep register pipeline: the 16-byte weight
+// fragments (HBM) and the MT activation fragments (L2-resident, re-read by every panel) of chunk c+1 are in flight
+// while the MFMAs of chunk c issue -- without it each k-step exposes a full memory round trip (measured 40 us per
+// launch at M=100 before, rocprof r01 v0).
 template <int MT>
 __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
 {
+    constexpr int CH = MT <= 4 ? 4 : 2;
     __shared__ f32x4 red[3][MT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
@@ -183,6 +195,7 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
     const f16 *W = (const f16 *)g.W;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     const int kslice = g.K / 4;
+    const int nks = kslice / 32;
     const int kb = wave * kslice;
     const int n = n0 + fr;
     const bool nok = n < g.N;
@@ -199,15 +212,35 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
         aok[t] = m < g.M;
         ap[t] = A + (size_t)(aok[t] ? m : 0) * g.lda + kb + fk;
     }
-#pragma unroll 4
-    for (int ks = 0; ks < kslice; ks += 32) {
-        const f16x8 b = nok ? *(const f16x8 *)(wp + ks) : (f16x8)(f16)0;
+    const f16x8 zero8 = (f16x8)(f16)0;
+    auto load = [&](f16x8 (&wf)[CH], f16x8 (&af)[CH][MT], int ks0) {
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const f16x8 a = aok[t] ? *(const f16x8 *)(ap[t] + ks) : (f16x8)(f16)0;
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[t], 0, 0, 0);
+        for (int c = 0; c < CH; ++c) {
+            const int ks = ks0 + c;
+            const bool kok = ks < nks;
+            wf[c] = (nok && kok) ? *(const f16x8 *)(wp + ks * 32) : zero8;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[c][t] = (aok[t] && kok) ? *(const f16x8 *)(ap[t] + ks * 32) : zero8;
         }
+    };
+    auto comp = [&](const f16x8 (&wf)[CH], const f16x8 (&af)[CH][MT]) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][t], wf[c], acc[t], 0, 0, 0);
+    };
+    f16x8 w0[CH], w1[CH], a0[CH][MT], a1[CH][MT];
+    const int nch = (nks + CH - 1) / CH;
+    load(w0, a0, 0);
+    int c = 0;
+    for (; c + 2 <= nch; c += 2) {
+        load(w1, a1, (c + 1) * CH);
+        comp(w0, a0);
+        if (c + 2 < nch) load(w0, a0, (c + 2) * CH);
+        comp(w1, a1);
     }
+    if (c < nch) comp(w0, a0);
+
     if (wave > 0) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) red[wave - 1][t][lane] = acc[t];
@@ -243,10 +276,16 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * ((g.epi & EPI_OUT_F32) ? 4 : 2), s);
             dim3 grid(cdiv(g.N, 16));
             const int mt = cdiv(g.M, 16);
-            if (mt <= 1) hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g);
-            else if (mt <= 2) hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g);
-            else if (mt <= 4) hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g);
-            else hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g);
+            switch (mt) {
+                case 1: hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g); break;
+                case 2: hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g); break;
+                case 3: hipLaunchKernelGGL(gemm_f16_skinny<3>, grid, dim3(256), 0, s, g); break;
+                case 4: hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g); break;
+                case 5: hipLaunchKernelGGL(gemm_f16_skinny<5>, grid, dim3(256), 0, s, g); break;
+                case 6: hipLaunchKernelGGL(gemm_f16_skinny<6>, grid, dim3(256), 0, s, g); break;
+                case 7: hipLaunchKernelGGL(gemm_f16_skinny<7>, grid, dim3(256), 0, s, g); break;
+                default: hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g); break;
+            }
         } else {
             SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
             dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));

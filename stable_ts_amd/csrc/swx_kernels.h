@@ -9,6 +9,8 @@
 #define EPI_RES 4
 #define EPI_OUT_F32 8
 #define EPI_RESF32MOD 16
+#define EPI_CBATCH 64        // C rows are grouped in batch items of vt_s rows, vt_bs elements apart (row-major inside an item)
+#define EPI_STORE_VT 32     // store C transposed per head: C[((row / vt_s) * (N/64) + col/64) * 64 + col%64][row % vt_s] with row stride vt_kp
 
 struct GemmArgs {
     const void *A; int64_t lda;     // [M][K] compute dtype
@@ -19,6 +21,7 @@ struct GemmArgs {
     void *C; int64_t ldc;           // compute dtype, or f32 with EPI_OUT_F32
     int M, N, K;
     int epi;
+    int vt_s, vt_kp; int64_t vt_bs;   // EPI_STORE_VT: rows per batch item, padded key stride, element stride between batch items
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 
@@ -52,11 +55,14 @@ int swx_copy_conv_w(int dtype, const float *src, int out_c, int in_c, int in_cp,
 // ---- swx_attn.hip
 struct AttnArgs {
     const void *q; int64_t ldq;      // [B*nq][...] head h at column h*64
-    const void *k; const void *v; int64_t ldkv;   // [B*nk][...] head h at column h*64
+    const void *k; const void *v; int64_t ldkv;   // row stride of K (and of V when it is row-major); head h at column h*64
+    int64_t k_bs, v_bs;              // element stride between batch items of K / V
+    int vt_kp;                       // 0: V row-major [nk][ldkv]; >0: V transposed per batch item [H][64][vt_kp] (keys contiguous)
     void *o; int64_t ldo;
     int B, H, nq, nk;
     int q_rows_per_batch;            // rows of q per batch item (== nq unless grouped)
 };
+#define SWX_VT_KP 1536               // padded key count of the transposed cross-attention V (64-key tiles never run off a row)
 // dense (non-causal) attention over nk keys: encoder self-attention and cross-attention
 int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s);
 // decoder self-attention over the per-row KV cache with ancestor indirection
@@ -72,7 +78,7 @@ struct SelfAttnArgs {
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);
 // raw scaled qk of selected heads: out[w][hi][i][f] = 0.125 * q[w][row0+i][head] . k[w][f][head]
 int swx_qk_capture(int dtype, const void *q, int64_t ldq, int q_rows_per_w, int row0, int n_rows, const void *k,
-                   int64_t ldk, int nk, const int32_t *heads, int n_heads, int head_slot0, int slots_total, int W,
+                   int64_t ldk, int64_t k_bs, int nk, const int32_t *heads, int n_heads, int head_slot0, int slots_total, int W,
                    float *out, int out_ld_n, int out_ld_f, hipStream_t s);
 
 // ---- swx_align.hip / swx_mel.hip

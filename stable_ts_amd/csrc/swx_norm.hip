@@ -6,6 +6,9 @@
 
 namespace {
 
+// one wave per row; the row is read ONCE into registers (8-element chunks, 16 B per lane for f16), statistics by wave
+// shuffles, result written once.  d <= 8*64*LN_MAXC.
+constexpr int LN_MAXC = 3;
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T *__restrict__ x, int64_t ldx, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, T *__restrict__ y, int64_t ldy,
@@ -15,14 +18,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T *__restrict__ x,
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const T *xr = x + (size_t)row * ldx;
+    const int nchunk = d >> 3;
+    float v[LN_MAXC][8];
     float s = 0.f;
-    for (int i = lane; i < d; i += 64) s += to_f32<T>(xr[i]);
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            load8<T>(xr + ch * 8, v[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[c][e];
+        }
+    }
     const float mean = wave_sum(s) / (float)d;
-    float v = 0.f;
-    for (int i = lane; i < d; i += 64) { const float t = to_f32<T>(xr[i]) - mean; v += t * t; }
-    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + 1e-5f);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = v[c][e] - mean; q += t * t; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
     T *yr = y + (size_t)row * ldy;
-    for (int i = lane; i < d; i += 64) yr[i] = from_f32<T>((to_f32<T>(xr[i]) - mean) * rstd * gamma[i] + beta[i]);
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + 64 * c;
+        if (ch < nchunk) {
+            float gm[8], bt[8];
+            load8<float>(gamma + ch * 8, gm);
+            load8<float>(beta + ch * 8, bt);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yr[ch * 8 + e] = from_f32<T>((v[c][e] - mean) * rstd * gm[e] + bt[e]);
+        }
+    }
 }
 
 template <typename T>
@@ -84,6 +114,7 @@ int swx_layernorm(int dtype, const void *x, int64_t ldx, const float *gamma, con
                   int rows, int d, hipStream_t s)
 {
     if (rows <= 0) return 0;
+    if (d % 8 != 0 || d > 8 * 64 * LN_MAXC) return -2;
     SwxProfScope prof(PC_NORM, 2.0 * rows * (double)d * (dtype == SWX_F16 ? 2 : 4), s);
     if (dtype == SWX_F16)
         hipLaunchKernelGGL(layernorm_kernel<f16>, dim3(cdiv(rows, 4)), dim3(256), 0, s, (const f16 *)x, ldx, gamma, beta, (f16 *)y, ldy, rows, d);

@@ -272,6 +272,11 @@ int gemm_residual(swx_model *m, const void *A, int64_t lda, size_t w_off, size_t
     return swx_gemm(m->dtype, g, 0, s);
 }
 
+inline int64_t xkv_chunk_elems(const swx_dims &D)
+{
+    return (int64_t)D.n_audio_ctx * D.n_text_state + (int64_t)D.n_text_state * SWX_VT_KP;
+}
+
 // ------------------------------------------------------------------------------------------------ decoder forward
 struct FwdCfg {
     int W;                 // windows
@@ -315,13 +320,16 @@ int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
         // cross attention
         SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.lnx_g), m->A<float>(w.lnx_b), h, d, rows, d, s));
         SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wcq, d, m->A<float>(w.bcq), qkv, d, rows, d, d, EPI_BIAS), 0, s));
-        const unsigned char *kl = f.xkv + (size_t)l * f.W * D.n_audio_ctx * 2 * d * e;
+        // cross K/V of this layer: per window [K: 1500 x d row-major | V^T: d x SWX_VT_KP, keys contiguous]
+        const int64_t chunk = xkv_chunk_elems(D);
+        const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
         AttnArgs ca{};
-        ca.q = qkv; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)d * e; ca.ldkv = 2 * d; ca.o = att; ca.ldo = d;
+        ca.q = qkv; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
+        ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
         ca.B = f.W; ca.H = H; ca.nq = f.rpw * f.n_new; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw * f.n_new;
         SWX_TRY(swx_attention(m->dtype, ca, 0, s));
         if (f.capture && !m->heads_by_layer[l].empty()) {
-            SWX_TRY(swx_qk_capture(m->dtype, qkv, d, f.rpw * f.n_new, f.cap_row0, f.cap_rows, kl, 2 * d, D.n_audio_ctx,
+            SWX_TRY(swx_qk_capture(m->dtype, qkv, d, f.rpw * f.n_new, f.cap_row0, f.cap_rows, kl, d, chunk, D.n_audio_ctx,
                                    m->A<int32_t>(m->o_heads) + m->head_slot0[l], (int)m->heads_by_layer[l].size(),
                                    m->head_slot0[l], m->n_align, f.W, m->Wp<float>(m->L.cap), f.cap_ld_n, D.n_audio_ctx, s));
         }
@@ -608,6 +616,7 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
         SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wqkv, d, m->A<float>(w.bqkv), qkv, 3 * d, rows, 3 * d, d, EPI_BIAS), 0, s));
         AttnArgs a{};
         a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * e; a.v = qkv + (size_t)2 * d * e; a.ldkv = 3 * d; a.o = att; a.ldo = d;
+        a.k_bs = (int64_t)S_ * 3 * d; a.v_bs = a.k_bs; a.vt_kp = 0;
         a.B = B; a.H = H; a.nq = S_; a.nk = S_; a.q_rows_per_batch = S_;
         SWX_TRY(swx_attention(m->dtype, a, 0, s));
         SWX_TRY(gemm_residual(m, att, d, w.wo, w.bo, x, d, rows, d, d, s));
@@ -622,19 +631,32 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
 size_t swx_cross_kv_bytes(const swx_model *m, int B)
 {
     if (!m) return 0;
-    return (size_t)m->dims.n_text_layer * B * m->dims.n_audio_ctx * 2 * m->dims.n_text_state * m->esz;
+    return (size_t)m->dims.n_text_layer * B * (size_t)xkv_chunk_elems(m->dims) * m->esz;
 }
 
 int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *stream)
 {
     if (!m || !m->arena) return -9;
     const swx_dims &D = m->dims;
-    const int d = D.n_text_state, rows = B * D.n_audio_ctx;
+    const int d = D.n_text_state, S_ = D.n_audio_ctx;
+    const size_t e = m->esz;
     if (D.n_audio_state != d) return -1;
+    const int64_t chunk = xkv_chunk_elems(D);
+    hipStream_t s = S(stream);
+    // the key padding of V^T (columns S_..KP) must be finite: it is multiplied by exact-zero probabilities
+    SWX_TRY(swx_fill_zero(d_xkv, swx_cross_kv_bytes(m, B), s));
     for (int l = 0; l < D.n_text_layer; ++l) {
         const LayerW &w = m->dec[l];
-        unsigned char *out = (unsigned char *)d_xkv + (size_t)l * rows * 2 * d * m->esz;
-        SWX_TRY(swx_gemm(m->dtype, gemm_args(d_xa, d, m->arena + w.wckv, d, m->A<float>(w.bckv), out, 2 * d, rows, 2 * d, d, EPI_BIAS), 0, S(stream)));
+        unsigned char *base = (unsigned char *)d_xkv + (size_t)l * B * chunk * e;
+        // K (no bias upstream; the fused bias slot is zero): one GEMM over all windows, rows scattered per window chunk
+        GemmArgs gk = gemm_args(d_xa, d, m->arena + w.wckv, d, m->A<float>(w.bckv), base, d, B * S_, d, d, EPI_BIAS | EPI_CBATCH);
+        gk.vt_s = S_; gk.vt_kp = 0; gk.vt_bs = chunk;
+        SWX_TRY(swx_gemm(m->dtype, gk, 0, s));
+        // V, stored transposed per head behind each window's K
+        GemmArgs gv = gemm_args(d_xa, d, m->arena + w.wckv + (size_t)d * d * e, d, m->A<float>(w.bckv) + d,
+                                base + (size_t)S_ * d * e, d, B * S_, d, d, EPI_BIAS | EPI_STORE_VT);
+        gv.vt_s = S_; gv.vt_kp = SWX_VT_KP; gv.vt_bs = chunk;
+        SWX_TRY(swx_gemm(m->dtype, gv, 0, s));
     }
     return 0;
 }
@@ -886,10 +908,12 @@ int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float
 }
 
 int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k, const void *d_v, int64_t ldkv, void *d_o,
-                       int64_t ldo, int B, int H, int nq, int nk, int force_kernel, void *stream)
+                       int64_t ldo, int B, int H, int nq, int nk, int force_kernel, int vt_kp, void *stream)
 {
     AttnArgs a{};
     a.q = d_q; a.ldq = ldq; a.k = d_k; a.v = d_v; a.ldkv = ldkv; a.o = d_o; a.ldo = ldo;
+    a.k_bs = (int64_t)nk * ldkv; a.vt_kp = vt_kp;
+    a.v_bs = vt_kp ? (int64_t)H * 64 * vt_kp : (int64_t)nk * ldkv;
     a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.q_rows_per_batch = nq;
     return swx_attention(dtype, a, force_kernel, S(stream));
 }

@@ -64,7 +64,7 @@ def _xkv_select(model, xkv, idx: Sequence[int]):
     if list(idx) == list(range(W)):
         return xkv
     d = model.dims
-    t = xkv.view(model.engine.tdtype).view(d.n_text_layer, W, d.n_audio_ctx * 2 * d.n_text_state)
+    t = xkv.view(model.engine.tdtype).view(d.n_text_layer, W, -1)      # [L][W][K | V^T] chunks
     sel = t.index_select(1, torch.tensor(list(idx), device=t.device)).contiguous().view(torch.uint8).view(-1)
     sel.n_windows = len(idx)
     return sel

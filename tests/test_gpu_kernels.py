@@ -245,13 +245,17 @@ def test_layernorm(dtype):
 
 
 # --------------------------------------------------------------------------------------------------- attention
-def _attn(dtype, q, k, v, force):
+def _attn(dtype, q, k, v, force, vt_kp=0):
     lib = _lib()
     B, nq, Hd = q.shape
     nk = k.shape[1]
     H = Hd // 64
     o = torch.empty_like(q)
-    rc = lib.swx_test_attention(dtype, _p(q), Hd, _p(k), _p(v), Hd, _p(o), Hd, B, H, nq, nk, force, _stream())
+    if vt_kp:   # transposed cross-KV layout: [B][H][64][kp], zero padded
+        vt = torch.zeros(B, H, 64, vt_kp, dtype=v.dtype, device=v.device)
+        vt[..., :nk] = v.view(B, nk, H, 64).permute(0, 2, 3, 1)
+        v = vt.contiguous()
+    rc = lib.swx_test_attention(dtype, _p(q), Hd, _p(k), _p(v), Hd, _p(o), Hd, B, H, nq, nk, force, vt_kp, _stream())
     assert rc == 0, rc
     torch.cuda.synchronize()
     return o
@@ -280,6 +284,22 @@ def test_attention_kernels(B, H, nq, nk):
     qh, kh, vh = q.half(), k.half(), v.half()
     refh = _attn_ref(qh, kh, vh)
     for force in (1, 2):   # rowwise f16, flash MFMA f16
-        o = _attn(1, qh.cuda(), kh.cuda(), vh.cuda(), force)
-        err = (o.cpu().double() - refh).abs().max().item()
-        assert err < 6e-3, (force, err)
+        for kp in (0, 1536):
+            o = _attn(1, qh.cuda(), kh.cuda(), vh.cuda(), force, kp)
+            err = (o.cpu().double() - refh).abs().max().item()
+            assert err < 6e-3, (force, kp, err)
+    o = _attn(0, q.cuda(), k.cuda(), v.cuda(), 1, 1536)
+    assert (o.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("B,H,nq,nk", [(1, 1, 1, 1500), (3, 4, 5, 1500), (2, 2, 16, 1500), (1, 3, 7, 333)])
+def test_attention_decode_cross_kernel(B, H, nq, nk):
+    # the HBM-streaming decode-step kernel (<=16 queries, transposed V) vs f64 reference; fp16 P rounding: 6e-3
+    g = torch.Generator().manual_seed(B * 10 + nq)
+    q = torch.randn(B, nq, H * 64, generator=g).half()
+    k = torch.randn(B, nk, H * 64, generator=g).half()
+    v = torch.randn(B, nk, H * 64, generator=g).half()
+    ref = _attn_ref(q, k, v)
+    o = _attn(1, q.cuda(), k.cuda(), v.cuda(), 3, 1536)
+    err = (o.cpu().double() - ref).abs().max().item()
+    assert err < 6e-3, err
