@@ -153,6 +153,9 @@ int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_t *d_N, con
  *          4 cached self-attention 5 select/beam 6 mel 7 align-weights 8 dtw 9 layernorm
  * swx_prof_collect: out[cls*3+{0,1,2}] = {launches, total ms, total algorithmic work}; returns the class count */
 int swx_prof_enable(int on);
+/* A/B switches for tests (bit 0: run decode steps through the general per-op path instead of the fused split-K step);
+ * flags < 0 only queries.  Returns the previous value. */
+int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);
 
 /* ---- building blocks exported for the parity tests (same kernels the calls above launch) */

@@ -63,6 +63,7 @@ SYMBOLS = {
     "swx_dtw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                         c_void_p]),
     "swx_prof_enable": (c_int, [c_int]),
+    "swx_debug_flags": (c_int, [c_int]),
     "swx_prof_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
     "swx_test_gemm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                               c_int, c_int, c_int, c_void_p]),

@@ -403,13 +403,31 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
     sum = wave_sum(sum);
     __syncthreads();
     const float inv = 1.0f / sum;
-    float acc = 0.f;
-    for (int j = 0; j <= pos; ++j) {
+    // P.V : lane = (key group kg = lane>>3, 8-wide d chunk dc = lane&7): 16-byte V loads, 8 keys per wave instruction
+    const int kg = lane >> 3, dc = (lane & 7) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int j = kg; j <= pos; j += 8) {
         const int pr = anc ? anc[j] : r;
-        const T *vr = (const T *)a.vcache + ((size_t)pr * a.n_ctx + j) * a.d + h * DH;
-        acc = fmaf(ps[j] * inv, to_f32<T>(vr[lane]), acc);
+        const T *vr = (const T *)a.vcache + ((size_t)pr * a.n_ctx + j) * a.d + h * DH + dc;
+        float vv[8];
+        load8<T>(vr, vv);
+        const float pj = ps[j] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vv[e], acc[e]);
     }
-    ((T *)a.o)[((size_t)ri * a.n_new + i) * a.ldo + h * DH + lane] = from_f32<T>(acc);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8, 64);
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (kg == 0) {
+        T *op = (T *)a.o + ((size_t)ri * a.n_new + i) * a.ldo + h * DH + dc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = from_f32<T>(acc[e]);
+    }
 }
 
 // =============================================================================================== qk capture
@@ -480,10 +498,10 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
     dim3 g1(a.n_new, a.R);
     dim3 g2(a.n_new, a.H, a.R);
     if (dtype == SWX_F16) {
-        hipLaunchKernelGGL(kv_append_kernel<f16>, g1, dim3(256), 0, s, a, row_mul);
+        if (!a.skip_append) hipLaunchKernelGGL(kv_append_kernel<f16>, g1, dim3(256), 0, s, a, row_mul);
         hipLaunchKernelGGL(self_attn_cached<f16>, g2, dim3(64), 0, s, a, row_mul);
     } else {
-        hipLaunchKernelGGL(kv_append_kernel<float>, g1, dim3(256), 0, s, a, row_mul);
+        if (!a.skip_append) hipLaunchKernelGGL(kv_append_kernel<float>, g1, dim3(256), 0, s, a, row_mul);
         hipLaunchKernelGGL(self_attn_cached<float>, g2, dim3(64), 0, s, a, row_mul);
     }
     SWX_CHECK_LAUNCH();

@@ -185,18 +185,24 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
 // while the MFMAs of chunk c issue -- without it each k-step exposes a full memory round trip (measured 40 us per
 // launch at M=100 before, rocprof r01 v0).
 template <int MT>
-__global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
+__global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs, int64_t slab_stride, int ks2)
 {
-    constexpr int CH = MT <= 4 ? 4 : 2;
+    constexpr int CH = MT <= 2 ? 4 : (MT <= 4 ? 2 : 1);
     __shared__ f32x4 red[3][MT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const f16 *A = (const f16 *)g.A;
     const f16 *W = (const f16 *)g.W;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    const int kslice = g.K / 4;
+    // K is split over blockIdx.y (ks2 slices, partial sums go to f32 slabs) and then over the 4 waves
+    const int kslice = g.K / (4 * ks2);
     const int nks = kslice / 32;
-    const int kb = wave * kslice;
+    const int kb = (blockIdx.y * 4 + wave) * kslice;
+    if (ks2 > 1 || slabs) {
+        g.C = slabs + (size_t)blockIdx.y * slab_stride;
+        g.ldc = g.N;
+        g.epi = EPI_OUT_F32;
+    }
     const int n = n0 + fr;
     const bool nok = n < g.N;
     const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
@@ -262,7 +268,111 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
     }
 }
 
+// ------------------------------------------------------------------------------------------- split-K finish
+// One workgroup per output row: v = sum_k slab[k][row][:] (+bias, GELU, +residual) -> C ; optionally the LayerNorm
+// of the finished row -> ln_out (saves the separate LN launch and its extra pass), and for the fused QKV projection
+// the new K / V rows go straight into the self-attention cache at the row's current position.
+constexpr int FIN_MAXC = 20;   // columns per thread: N <= 256 * 20
+__global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict__ slabs, int ks2, int64_t slab_stride, int N,
+                                                         FinishArgs f)
+{
+    __shared__ float sh[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float v[FIN_MAXC];
+    const float *base = slabs + (size_t)row * N;
+#pragma unroll
+    for (int i = 0; i < FIN_MAXC; ++i) {
+        const int col = tid + 256 * i;
+        float a = 0.f;
+        if (col < N) {
+            for (int k = 0; k < ks2; ++k) a += base[(size_t)k * slab_stride + col];
+            if (f.epi & EPI_BIAS) a += f.bias[col];
+            if (f.epi & EPI_GELU) a = gelu_erf(a);
+            if (f.epi & EPI_RES) a += (float)((const f16 *)f.R)[(size_t)row * f.ldr + col];
+            const f16 h = (f16)a;
+            if (f.kcache && col >= f.d) {
+                const int pos = f.pos0[row];
+                if (col < 2 * f.d) ((f16 *)f.kcache)[((size_t)row * f.n_ctx + pos) * f.d + (col - f.d)] = h;
+                else ((f16 *)f.vcache)[((size_t)row * f.n_ctx + pos) * f.d + (col - 2 * f.d)] = h;
+            } else {
+                ((f16 *)f.C)[(size_t)row * f.ldc + col] = h;
+            }
+            a = (float)h;      // the LayerNorm below sees the stored (rounded) activation, like a separate LN launch would
+        }
+        v[i] = a;
+    }
+    if (!f.ln_out) return;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < FIN_MAXC; ++i) if (tid + 256 * i < N) s += v[i];
+    s = wave_sum(s);
+    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)N;
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < FIN_MAXC; ++i) if (tid + 256 * i < N) { const float t = v[i] - mean; q += t * t; }
+    q = wave_sum(q);
+    if ((tid & 63) == 0) sh[tid >> 6] = q;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)N + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < FIN_MAXC; ++i) {
+        const int col = tid + 256 * i;
+        if (col < N) ((f16 *)f.ln_out)[(size_t)row * f.ld_ln + col] = (f16)((v[i] - mean) * rstd * f.ln_g[col] + f.ln_b[col]);
+    }
+}
+
+int skinny_ks2(int N, int K)
+{
+    const int units = K / 128;                       // a wave's K slice must stay a multiple of 32
+    const int panels = (N + 15) / 16;
+    int want = 640 / panels;
+    if (want < 1) want = 1;
+    int ks2 = 1;
+    for (int c = 1; c <= units && c <= want; ++c) if (units % c == 0) ks2 = c;
+    return ks2;
+}
+
 }  // namespace
+
+size_t swx_skinny_slab_floats(int M, int N, int K)
+{
+    if (M <= 0 || M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC) return 0;
+    return (size_t)skinny_ks2(N, K) * M * N;
+}
+
+int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
+                           const FinishArgs &f, hipStream_t s)
+{
+    if (M <= 0 || N <= 0) return 0;
+    if (M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC || lda % 8 != 0 || ldw % 8 != 0) return -4;
+    const int ks2 = skinny_ks2(N, K);
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = EPI_OUT_F32; g.res_mod = 1;
+    const int64_t stride = (int64_t)M * N;
+    dim3 grid(cdiv(N, 16), ks2);
+    {
+        SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)N * K + (double)M * K) + (double)M * N * 2, s);
+        switch (cdiv(M, 16)) {
+            case 1: hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 2: hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 3: hipLaunchKernelGGL(gemm_f16_skinny<3>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 4: hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 5: hipLaunchKernelGGL(gemm_f16_skinny<5>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 6: hipLaunchKernelGGL(gemm_f16_skinny<6>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 7: hipLaunchKernelGGL(gemm_f16_skinny<7>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            default: hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+        }
+    }
+    {
+        SwxProfScope prof(PC_NORM, (double)ks2 * M * N * 4 + 4.0 * M * N, s);
+        hipLaunchKernelGGL(splitk_finish_f16, dim3(M), dim3(256), 0, s, slabs, ks2, stride, N, f);
+    }
+    SWX_CHECK_LAUNCH();
+    return 0;
+}
 
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
 {
@@ -277,14 +387,14 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             dim3 grid(cdiv(g.N, 16));
             const int mt = cdiv(g.M, 16);
             switch (mt) {
-                case 1: hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g); break;
-                case 2: hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g); break;
-                case 3: hipLaunchKernelGGL(gemm_f16_skinny<3>, grid, dim3(256), 0, s, g); break;
-                case 4: hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g); break;
-                case 5: hipLaunchKernelGGL(gemm_f16_skinny<5>, grid, dim3(256), 0, s, g); break;
-                case 6: hipLaunchKernelGGL(gemm_f16_skinny<6>, grid, dim3(256), 0, s, g); break;
-                case 7: hipLaunchKernelGGL(gemm_f16_skinny<7>, grid, dim3(256), 0, s, g); break;
-                default: hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g); break;
+                case 1: hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                case 2: hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                case 3: hipLaunchKernelGGL(gemm_f16_skinny<3>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                case 4: hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                case 5: hipLaunchKernelGGL(gemm_f16_skinny<5>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                case 6: hipLaunchKernelGGL(gemm_f16_skinny<6>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                case 7: hipLaunchKernelGGL(gemm_f16_skinny<7>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                default: hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
             }
         } else {
             SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);

@@ -25,6 +25,20 @@ struct GemmArgs {
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 
+// ---- decode-step GEMM = split-K weight streaming into f32 slabs + a finish kernel that reduces the slabs and applies
+//      bias / GELU / residual, optionally fused with the NEXT LayerNorm and with the scatter of new K/V into the cache
+struct FinishArgs {
+    const float *bias; int epi;          // EPI_BIAS | EPI_GELU | EPI_RES
+    const void *R; int64_t ldr;          // residual (compute dtype)
+    void *C; int64_t ldc;                // output (compute dtype); with kv scatter only columns [0, d) are written here
+    const float *ln_g, *ln_b; void *ln_out; int64_t ld_ln;   // fused LayerNorm of the finished row (null = off)
+    void *kcache, *vcache; const int32_t *pos0; int n_ctx, d;   // QKV scatter (null = off)
+};
+// slabs must hold swx_skinny_slab_floats(M, N, K) floats; returns <0 when the shape is not supported by this path
+size_t swx_skinny_slab_floats(int M, int N, int K);
+int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
+                           const FinishArgs &f, hipStream_t s);
+
 // ---- in-library kernel timing (HIP events on the launch stream), used by bench.py for the roofline object
 enum SwxProfClass { PC_GEMM_TILED = 0, PC_GEMM_SKINNY = 1, PC_ATTN_FLASH = 2, PC_ATTN_ROWWISE = 3, PC_SELF_ATTN = 4,
                     PC_SELECT = 5, PC_MEL = 6, PC_ALIGN = 7, PC_DTW = 8, PC_NORM = 9, PC_COUNT = 10 };
@@ -73,6 +87,7 @@ struct SelfAttnArgs {
     const int32_t *pos0;             // [R] position of the first new token of each row
     void *o; int64_t ldo;            // [R*n_new][d]
     int R, n_new, H, n_ctx, d;
+    int skip_append;                 // K/V of the new token were already scattered into the cache (split-K finish kernel)
 };
 // logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);

@@ -57,7 +57,7 @@ struct swx_model {
         size_t melT, h1, x, h, qkv, att, u, gmax, small_i32, zeros_i32;
         size_t tokens0, tokens1, anc0, anc1, pos0, sum_lp, sum_lp_next, row_done, win_done, win_done_prev, n_done;
         size_t fin_tokens, fin_score, fin_len, fin_count, cand_lp, cand_tok, logits, hid2;
-        size_t kcache, vcache, sk, sv, cap, mean, sd, suppress;
+        size_t kcache, vcache, sk, sv, cap, mean, sd, suppress, slabs;
         size_t total;
         int64_t rows_big, logits_rows;
     } L;
@@ -230,6 +230,12 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
     L.mean = take((size_t)Bmax * (n_align > 0 ? n_align : 1) * D.n_audio_ctx * 4);
     L.sd = take((size_t)Bmax * (n_align > 0 ? n_align : 1) * D.n_audio_ctx * 4);
     L.suppress = take((size_t)MAX_SUPPRESS * 4);
+    {
+        size_t mx = 0;
+        const int shapes[4][2] = {{3 * dt, dt}, {dt, dt}, {4 * dt, dt}, {dt, 4 * dt}};
+        for (auto &sh : shapes) { const size_t f = swx_skinny_slab_floats(128, sh[0], sh[1]); if (f > mx) mx = f; }
+        L.slabs = take(mx * 4 + 256);
+    }
     L.total = cur;
 }
 
@@ -238,6 +244,7 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 // ---------------------------------------------------------------------------------------------- profiler
 struct ProfRec { int cls; double work; hipEvent_t a, b; };
 bool g_prof_enabled = false;
+int g_debug_flags = 0;          // bit 0: disable the fused fast decode step (A/B testing)
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -293,8 +300,68 @@ struct FwdCfg {
     bool capture; int cap_row0, cap_rows, cap_ld_n;
 };
 
+// One decoder step (n_new == 1) for <= 128 rows in fp16: every projection is a split-K weight-streaming GEMM whose
+// finish kernel also applies the next LayerNorm / scatters the new K,V into the cache.  Leaves ln(x) of the LAST layer
+// (the model's final LayerNorm) in the `h` buffer.
+int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
+{
+    const swx_dims &D = m->dims;
+    const int d = D.n_text_state, H = D.n_text_head;
+    const size_t e = m->esz;
+    const int rows = f.W * f.rpw;
+    unsigned char *x = m->ws + m->L.x, *h = m->ws + m->L.h, *qkv = m->ws + m->L.qkv, *att = m->ws + m->L.att, *u = m->ws + m->L.u;
+    float *slabs = m->Wp<float>(m->L.slabs);
+    SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, rows, 1, m->arena + m->o_tok_emb,
+                      m->A<float>(m->o_dec_pos), d, x, s));
+    SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->dec[0].ln1_g), m->A<float>(m->dec[0].ln1_b), h, d, rows, d, s));
+    const int64_t chunk = xkv_chunk_elems(D);
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const LayerW &w = m->dec[l];
+        unsigned char *kc = f.kcache + (size_t)l * f.layer_stride, *vc = f.vcache + (size_t)l * f.layer_stride;
+        FinishArgs fq{};
+        fq.bias = m->A<float>(w.bqkv); fq.epi = EPI_BIAS; fq.C = qkv; fq.ldc = 3 * d;
+        fq.kcache = kc; fq.vcache = vc; fq.pos0 = f.pos0; fq.n_ctx = D.n_text_ctx; fq.d = d;
+        SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wqkv, d, rows, 3 * d, d, slabs, fq, s));
+        SelfAttnArgs sa{};
+        sa.qkv = qkv; sa.ldqkv = 3 * d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
+        sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
+        SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
+        FinishArgs fo{};
+        fo.bias = m->A<float>(w.bo); fo.epi = EPI_BIAS | EPI_RES; fo.R = x; fo.ldr = d; fo.C = x; fo.ldc = d;
+        fo.ln_g = m->A<float>(w.lnx_g); fo.ln_b = m->A<float>(w.lnx_b); fo.ln_out = h; fo.ld_ln = d;
+        SWX_TRY(swx_gemm_skinny_splitk(att, d, m->arena + w.wo, d, rows, d, d, slabs, fo, s));
+        FinishArgs fc{};
+        fc.bias = m->A<float>(w.bcq); fc.epi = EPI_BIAS; fc.C = qkv; fc.ldc = d;
+        SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wcq, d, rows, d, d, slabs, fc, s));
+        const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
+        AttnArgs ca{};
+        ca.q = qkv; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
+        ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
+        ca.B = f.W; ca.H = H; ca.nq = f.rpw; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw;
+        SWX_TRY(swx_attention(m->dtype, ca, 0, s));
+        FinishArgs fx{};
+        fx.bias = m->A<float>(w.bco); fx.epi = EPI_BIAS | EPI_RES; fx.R = x; fx.ldr = d; fx.C = x; fx.ldc = d;
+        fx.ln_g = m->A<float>(w.ln2_g); fx.ln_b = m->A<float>(w.ln2_b); fx.ln_out = h; fx.ld_ln = d;
+        SWX_TRY(swx_gemm_skinny_splitk(att, d, m->arena + w.wco, d, rows, d, d, slabs, fx, s));
+        FinishArgs f1{};
+        f1.bias = m->A<float>(w.b1); f1.epi = EPI_BIAS | EPI_GELU; f1.C = u; f1.ldc = 4 * d;
+        SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.w1, d, rows, 4 * d, d, slabs, f1, s));
+        FinishArgs f2{};
+        f2.bias = m->A<float>(w.b2); f2.epi = EPI_BIAS | EPI_RES; f2.R = x; f2.ldr = d; f2.C = x; f2.ldc = d;
+        const bool last = l + 1 == D.n_text_layer;
+        f2.ln_g = m->A<float>(last ? m->o_ln_g : m->dec[l + 1].ln1_g);
+        f2.ln_b = m->A<float>(last ? m->o_ln_b : m->dec[l + 1].ln1_b);
+        f2.ln_out = h; f2.ld_ln = d;
+        SWX_TRY(swx_gemm_skinny_splitk(u, 4 * d, m->arena + w.w2, 4 * d, rows, d, 4 * d, slabs, f2, s));
+    }
+    return 1;   // h holds the final LayerNorm of x
+}
+
 int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
+    if (!(g_debug_flags & 1) && m->dtype == SWX_F16 && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.W * f.rpw <= 128 &&
+        m->dims.n_text_state % 128 == 0 && swx_skinny_slab_floats(f.W * f.rpw, 3 * m->dims.n_text_state, m->dims.n_text_state) > 0)
+        return decoder_step_fast(m, f, s);
     const swx_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head;
     const size_t e = m->esz;
@@ -403,6 +470,13 @@ void swx_prof_end(hipStream_t s)
 
 // ================================================================================================== C ABI
 extern "C" {
+
+int swx_debug_flags(int flags)
+{
+    const int old = g_debug_flags;
+    if (flags >= 0) g_debug_flags = flags;
+    return old;
+}
 
 int swx_prof_enable(int on)
 {
@@ -762,9 +836,11 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
         g.tokens = b.tokens[cur]; g.ld_tok = b.TS; g.pos0 = b.pos0;
         g.kcache = f.kcache; g.vcache = f.vcache; g.layer_stride = layer_stride; g.cache_rows = m->max_rows;
         g.anc = use_anc ? b.anc[cur] : nullptr; g.xkv = (const unsigned char *)d_xkv; g.capture = false;
-        SWX_TRY(decoder_forward(m, g, s));
+        const int fr = decoder_forward(m, g, s);
+        if (fr < 0) return fr;
         unsigned char *hh = m->ws + m->L.h;
-        SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, M, d, s));
+        if (fr == 0)   // the fast step leaves ln(x) in h already
+            SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, M, d, s));
         SWX_TRY(logits_gemm(m, hh, d, M, b.logits, s));
     }
     const int G_out = swx_decode_gout(cfg);
