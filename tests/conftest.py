@@ -8,7 +8,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _limit_threads():
+    # the CPU oracle runs inside the GPU tests; xdist workers x 64 default torch threads thrash the host
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
+    _limit_threads()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver)")
     config.addinivalue_line("markers", "slow: long CPU test")
 
