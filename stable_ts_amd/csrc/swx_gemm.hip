@@ -36,12 +36,15 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs &g, int row, int c
 
 // ------------------------------------------------------------------------------------------------ tiled f16
 constexpr int BM = 128, BN = 128;
-constexpr int BK16 = 32, LD16 = BK16 + 8;   // halfs; 80-byte rows keep every fragment read 16-byte aligned
+constexpr int BK16 = 64, LD16 = BK16 + 8;   // halfs; 144-byte rows keep every fragment read 16-byte aligned
+constexpr int CLD = BN + 4;                 // f32 staging row of the epilogue
 
 __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(16))) f16 As[2][BM][LD16];
-    __shared__ __attribute__((aligned(16))) f16 Bs[2][BN][LD16];
+    // one allocation: [A tiles | B tiles] during the K loop, reused as the f32 C tile of the coalesced epilogue
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * BM * LD16 * 2];
+    f16 (*As)[BM][LD16] = (f16 (*)[BM][LD16])smem;
+    f16 (*Bs)[BN][LD16] = (f16 (*)[BN][LD16])(smem + 2 * BM * LD16 * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -54,55 +57,109 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f16x8 ra[2], rb[2];
+    f16x8 ra[4], rb[4];
     auto load_regs = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 8;
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
             const int gm = m0 + row, gn = n0 + row;
-            ra[i] = (gm < g.M) ? *(const f16x8 *)(A + (size_t)gm * g.lda + k0 + kc) : (f16x8)(f16)0;
-            rb[i] = (gn < g.N) ? *(const f16x8 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f16x8)(f16)0;
+            const bool kok = k0 + kc < g.K;          // K may end in the middle of a 64-wide step (K % 32 == 0)
+            ra[i] = (gm < g.M && kok) ? *(const f16x8 *)(A + (size_t)gm * g.lda + k0 + kc) : (f16x8)(f16)0;
+            rb[i] = (gn < g.N && kok) ? *(const f16x8 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f16x8)(f16)0;
         }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 8;
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
             *(f16x8 *)&As[buf][row][kc] = ra[i];
             *(f16x8 *)&Bs[buf][row][kc] = rb[i];
         }
     };
 
-    const int KT = g.K / BK16;
+    const int KT = (g.K + BK16 - 1) / BK16;
     load_regs(0);
     store_lds(0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < KT) load_regs((kt + 1) * BK16);
-        f16x8 a[4], b[4];
         const int fr = lane & 15, fk = (lane >> 4) * 8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *(const f16x8 *)&As[cur][wm * 64 + i * 16 + fr][fk];
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 a[4], b[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *(const f16x8 *)&Bs[cur][wn * 64 + j * 16 + fr][fk];
+            for (int i = 0; i < 4; ++i) a[i] = *(const f16x8 *)&As[cur][wm * 64 + i * 16 + fr][kk * 32 + fk];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) b[j] = *(const f16x8 *)&Bs[cur][wn * 64 + j * 16 + fr][kk * 32 + fk];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
         if (kt + 1 < KT) store_lds(cur ^ 1);
         __syncthreads();
     }
 
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const bool plain = !(g.epi & (EPI_STORE_VT | EPI_CBATCH | EPI_OUT_F32 | EPI_RESF32MOD)) && (g.ldc % 8 == 0) &&
+                       (!(g.epi & EPI_RES) || g.ldr % 8 == 0);
+    if (!plain) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
+        return;
+    }
+    // coalesced epilogue: accumulators -> f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32)
+    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 128 x 132 x 4 B = 67.6 KB <= 73.7 KB
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
+            for (int r = 0; r < 4; ++r) Cs[wm * 64 + i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = tid + 256 * it, row = c >> 4, c8 = (c & 15) * 8;
+        const int gm = m0 + row, gn = n0 + c8;
+        if (gm >= g.M || gn >= g.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Cs[row][c8 + e];
+        const bool full = gn + 8 <= g.N;
+        if (g.epi & EPI_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || gn + e < g.N) v[e] += g.bias[gn + e];
+        }
+        if (g.epi & EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
+        if (full) {
+            if (g.epi & EPI_RES) {
+                const f16x8 rv = *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+            *(f16x8 *)cp = o;
+        } else {
+            for (int e = 0; e < 8 && gn + e < g.N; ++e) {
+                float t = v[e];
+                if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
+                cp[e] = (f16)t;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ tiled f32
@@ -273,19 +330,46 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
 // of the finished row -> ln_out (saves the separate LN launch and its extra pass), and for the fused QKV projection
 // the new K / V rows go straight into the self-attention cache at the row's current position.
 constexpr int FIN_MAXC = 20;   // columns per thread: N <= 256 * 20
+// KS2 > 0: slab count known at compile time (every slab load of a thread is independent and in flight at once);
+// KS2 == 0: generic run-time count
+template <int KS2, int NC>
 __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict__ slabs, int ks2, int64_t slab_stride, int N,
                                                          FinishArgs f)
 {
     __shared__ float sh[4];
     const int row = blockIdx.x, tid = threadIdx.x;
-    float v[FIN_MAXC];
+    float v[NC];
     const float *base = slabs + (size_t)row * N;
+    if constexpr (KS2 > 0) {
+        float part[NC][KS2];
 #pragma unroll
-    for (int i = 0; i < FIN_MAXC; ++i) {
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int k = 0; k < KS2; ++k) {
+                const int col = tid + 256 * i;
+                part[i][k] = (col < N) ? base[(size_t)k * slab_stride + col] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < KS2; ++k) a += part[i][k];
+            v[i] = a;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            const int col = tid + 256 * i;
+            float a = 0.f;
+            if (col < N) for (int k = 0; k < ks2; ++k) a += base[(size_t)k * slab_stride + col];
+            v[i] = a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
         const int col = tid + 256 * i;
-        float a = 0.f;
+        float a = v[i];
         if (col < N) {
-            for (int k = 0; k < ks2; ++k) a += base[(size_t)k * slab_stride + col];
             if (f.epi & EPI_BIAS) a += f.bias[col];
             if (f.epi & EPI_GELU) a = gelu_erf(a);
             if (f.epi & EPI_RES) a += (float)((const f16 *)f.R)[(size_t)row * f.ldr + col];
@@ -304,7 +388,7 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
     if (!f.ln_out) return;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < FIN_MAXC; ++i) if (tid + 256 * i < N) s += v[i];
+    for (int i = 0; i < NC; ++i) if (tid + 256 * i < N) s += v[i];
     s = wave_sum(s);
     if ((tid & 63) == 0) sh[tid >> 6] = s;
     __syncthreads();
@@ -312,13 +396,13 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
     __syncthreads();
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < FIN_MAXC; ++i) if (tid + 256 * i < N) { const float t = v[i] - mean; q += t * t; }
+    for (int i = 0; i < NC; ++i) if (tid + 256 * i < N) { const float t = v[i] - mean; q += t * t; }
     q = wave_sum(q);
     if ((tid & 63) == 0) sh[tid >> 6] = q;
     __syncthreads();
     const float rstd = 1.0f / sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)N + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < FIN_MAXC; ++i) {
+    for (int i = 0; i < NC; ++i) {
         const int col = tid + 256 * i;
         if (col < N) ((f16 *)f.ln_out)[(size_t)row * f.ld_ln + col] = (f16)((v[i] - mean) * rstd * f.ln_g[col] + f.ln_b[col]);
     }
@@ -368,7 +452,17 @@ int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ld
     }
     {
         SwxProfScope prof(PC_NORM, (double)ks2 * M * N * 4 + 4.0 * M * N, s);
-        hipLaunchKernelGGL(splitk_finish_f16, dim3(M), dim3(256), 0, s, slabs, ks2, stride, N, f);
+        const int nc = cdiv(N, 256);
+#define SWX_FIN(KS, NC) hipLaunchKernelGGL((splitk_finish_f16<KS, NC>), dim3(M), dim3(256), 0, s, slabs, ks2, stride, N, f)
+        if (nc <= 5 && ks2 == 5) SWX_FIN(5, 5);
+        else if (nc <= 5 && ks2 == 8) SWX_FIN(8, 5);
+        else if (nc <= 5 && ks2 == 10) SWX_FIN(10, 5);
+        else if (nc <= 15 && ks2 == 2) SWX_FIN(2, 15);
+        else if (nc <= 20 && ks2 == 2) SWX_FIN(2, 20);
+        else if (nc <= 20 && ks2 == 1) SWX_FIN(1, 20);
+        else if (nc <= 5) SWX_FIN(0, 5);
+        else SWX_FIN(0, 20);
+#undef SWX_FIN
     }
     SWX_CHECK_LAUNCH();
     return 0;
@@ -378,7 +472,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
 {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (dtype == SWX_F16) {
-        if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;
+        if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;   // tiled: K % 32, skinny: K % 128
         const bool skinny_ok = g.M <= 128 && g.K % 128 == 0;
         const bool use_skinny = force_kernel == 2 ? skinny_ok : (force_kernel == 1 ? false : skinny_ok);
         if (force_kernel == 2 && !skinny_ok) return -4;
