@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
 template <int MT>
 __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs, int64_t slab_stride, int ks2)
 {
-    constexpr int CH = MT <= 2 ? 4 : (MT <= 4 ? 2 : 1);
+    constexpr int NKS_MAX = 10;      // k-steps (of 32) per wave: the launcher keeps K / (128 * ks2) <= 10
     __shared__ f32x4 red[3][MT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
@@ -263,6 +263,14 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
     const int n = n0 + fr;
     const bool nok = n < g.N;
     const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
+    const f16x8 zero8 = (f16x8)(f16)0;
+
+    // HBM side first: every weight fragment of this wave's K slice is put in flight at once (<= 10 x 1 KB per wave);
+    // the bandwidth-delay product of the chip (~10 MB) needs tens of KB outstanding per CU, which a double-buffered
+    // weight load cannot provide
+    f16x8 wf[NKS_MAX];
+#pragma unroll
+    for (int ks = 0; ks < NKS_MAX; ++ks) wf[ks] = (nok && ks < nks) ? *(const f16x8 *)(wp + ks * 32) : zero8;
 
     f32x4 acc[MT];
 #pragma unroll
@@ -275,34 +283,21 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
         aok[t] = m < g.M;
         ap[t] = A + (size_t)(aok[t] ? m : 0) * g.lda + kb + fk;
     }
-    const f16x8 zero8 = (f16x8)(f16)0;
-    auto load = [&](f16x8 (&wf)[CH], f16x8 (&af)[CH][MT], int ks0) {
+    // L2 side: activation fragments, two k-steps deep
+    f16x8 af[2][MT];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int ks = ks0 + c;
-            const bool kok = ks < nks;
-            wf[c] = (nok && kok) ? *(const f16x8 *)(wp + ks * 32) : zero8;
+    for (int t = 0; t < MT; ++t) af[0][t] = aok[t] ? *(const f16x8 *)(ap[t]) : zero8;
 #pragma unroll
-            for (int t = 0; t < MT; ++t) af[c][t] = (aok[t] && kok) ? *(const f16x8 *)(ap[t] + ks * 32) : zero8;
+    for (int ks = 0; ks < NKS_MAX; ++ks) {
+        if (ks < nks) {
+            if (ks + 1 < nks) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) af[(ks + 1) & 1][t] = aok[t] ? *(const f16x8 *)(ap[t] + (ks + 1) * 32) : zero8;
+            }
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks & 1][t], wf[ks], acc[t], 0, 0, 0);
         }
-    };
-    auto comp = [&](const f16x8 (&wf)[CH], const f16x8 (&af)[CH][MT]) {
-#pragma unroll
-        for (int c = 0; c < CH; ++c)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][t], wf[c], acc[t], 0, 0, 0);
-    };
-    f16x8 w0[CH], w1[CH], a0[CH][MT], a1[CH][MT];
-    const int nch = (nks + CH - 1) / CH;
-    load(w0, a0, 0);
-    int c = 0;
-    for (; c + 2 <= nch; c += 2) {
-        load(w1, a1, (c + 1) * CH);
-        comp(w0, a0);
-        if (c + 2 < nch) load(w0, a0, (c + 2) * CH);
-        comp(w1, a1);
     }
-    if (c < nch) comp(w0, a0);
 
     if (wave > 0) {
 #pragma unroll
@@ -414,9 +409,10 @@ int skinny_ks2(int N, int K)
     const int panels = (N + 15) / 16;
     int want = 640 / panels;
     if (want < 1) want = 1;
-    int ks2 = 1;
-    for (int c = 1; c <= units && c <= want; ++c) if (units % c == 0) ks2 = c;
-    return ks2;
+    int ks2 = 0;
+    for (int c = 1; c <= units; ++c)
+        if (units % c == 0 && units / c <= 10 && (ks2 == 0 || c <= want)) ks2 = c;    // smallest legal c, grown up to `want`
+    return ks2 ? ks2 : units;
 }
 
 }  // namespace
@@ -473,7 +469,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
     if (g.M <= 0 || g.N <= 0) return 0;
     if (dtype == SWX_F16) {
         if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;   // tiled: K % 32, skinny: K % 128
-        const bool skinny_ok = g.M <= 128 && g.K % 128 == 0;
+        const bool skinny_ok = g.M <= 128 && g.K % 128 == 0 && g.K / 128 <= 10;
         const bool use_skinny = force_kernel == 2 ? skinny_ok : (force_kernel == 1 ? false : skinny_ok);
         if (force_kernel == 2 && !skinny_ok) return -4;
         if (use_skinny) {
