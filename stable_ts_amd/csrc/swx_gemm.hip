@@ -320,6 +320,88 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
     }
 }
 
+// ------------------------------------------------------------------------------------------- panel-group f16
+// Decode-step GEMM, second generation.  Profile r01 v3 showed the 16-column-panel kernel above bound by L2->CU
+// ACTIVATION traffic (every panel re-reads the whole [M][K] activation: 3242 panels x 256 KB for the logits), not by
+// HBM.  Here a workgroup owns 64 output columns (one 16-column panel per wave) x one K slice (blockIdx.y); the
+// activation chunk [MT*16][64] of each step is staged ONCE per workgroup in LDS with coalesced full-line loads and
+// shared by the four waves (4x fewer, 2x wider L2 requests), while every wave streams its own weight fragments of the
+// whole slice from HBM up front.  Partial sums go to f32 slabs (deterministic split-K), finished by splitk_finish_f16.
+constexpr int PG_LD = 72;        // halfs per LDS row
+constexpr int PG_MAXIT = 5;      // 64-wide K chunks per workgroup slice
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int64_t slab_stride, int ks2)
+{
+    __shared__ __attribute__((aligned(16))) f16 As[2][MT * 16][PG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    const f16 *A = (const f16 *)g.A;
+    const f16 *W = (const f16 *)g.W;
+    const int kslice = g.K / ks2;
+    const int nit = kslice / 64;
+    const int kb = blockIdx.y * kslice;
+    const int n = blockIdx.x * 64 + wave * 16 + fr;
+    const bool nok = n < g.N;
+    const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
+    const f16x8 zero8 = (f16x8)(f16)0;
+
+    f16x8 wf[2 * PG_MAXIT];
+#pragma unroll
+    for (int ks = 0; ks < 2 * PG_MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int NCH = (MT * 16 * 8 + 255) / 256;      // 16-byte chunks of the activation tile per thread
+    f16x8 ra[NCH];
+    auto load_a = [&](int it) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 3, c8 = (idx & 7) * 8;
+            ra[j] = (row < g.M) ? *(const f16x8 *)(A + (size_t)row * g.lda + kb + it * 64 + c8) : zero8;
+        }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tid + 256 * j, row = idx >> 3, c8 = (idx & 7) * 8;
+            if (row < MT * 16) *(f16x8 *)&As[buf][row][c8] = ra[j];
+        }
+    };
+    load_a(0);
+    store_a(0);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PG_MAXIT; ++it) {
+        if (it < nit) {
+            const int cur = it & 1;
+            if (it + 1 < nit) load_a(it + 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const f16x8 a = *(const f16x8 *)&As[cur][t * 16 + fr][kk * 32 + fk];
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wf[it * 2 + kk], acc[t], 0, 0, 0);
+                }
+            if (it + 1 < nit) store_a(cur ^ 1);
+            __syncthreads();
+        }
+    }
+    // each wave owns its 16 columns for this K slice: plain f32 partials, no cross-wave reduction
+    float *out = slabs + (size_t)blockIdx.y * slab_stride;
+    const int col = blockIdx.x * 64 + wave * 16 + (lane & 15), row_l = (lane >> 4) * 4;
+    if (col < g.N) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + row_l + r;
+                if (row < g.M) out[(size_t)row * g.N + col] = acc[t][r];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- split-K finish
 // One workgroup per output row: v = sum_k slab[k][row][:] (+bias, GELU, +residual) -> C ; optionally the LayerNorm
 // of the finished row -> ln_out (saves the separate LN launch and its extra pass), and for the fused QKV projection
@@ -332,7 +414,7 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
                                                          FinishArgs f)
 {
     __shared__ float sh[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int row = blockIdx.x, tid = threadIdx.x + blockIdx.y * (256 * NC);   // blockIdx.y > 0 only without fused LN
     float v[NC];
     const float *base = slabs + (size_t)row * N;
     if constexpr (KS2 > 0) {
@@ -381,11 +463,12 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
         v[i] = a;
     }
     if (!f.ln_out) return;
+    const int wid = threadIdx.x >> 6;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) if (tid + 256 * i < N) s += v[i];
     s = wave_sum(s);
-    if ((tid & 63) == 0) sh[tid >> 6] = s;
+    if ((threadIdx.x & 63) == 0) sh[wid] = s;
     __syncthreads();
     const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)N;
     __syncthreads();
@@ -393,7 +476,7 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
 #pragma unroll
     for (int i = 0; i < NC; ++i) if (tid + 256 * i < N) { const float t = v[i] - mean; q += t * t; }
     q = wave_sum(q);
-    if ((tid & 63) == 0) sh[tid >> 6] = q;
+    if ((threadIdx.x & 63) == 0) sh[wid] = q;
     __syncthreads();
     const float rstd = 1.0f / sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)N + 1e-5f);
 #pragma unroll
@@ -401,6 +484,17 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
         const int col = tid + 256 * i;
         if (col < N) ((f16 *)f.ln_out)[(size_t)row * f.ld_ln + col] = (f16)((v[i] - mean) * rstd * f.ln_g[col] + f.ln_b[col]);
     }
+}
+
+int pg_ks2(int N, int K)
+{
+    const int units = K / 64;
+    const int panels = (N + 63) / 64;
+    int want = (320 + panels - 1) / panels;
+    int ks2 = 0;
+    for (int c = 1; c <= units; ++c)
+        if (units % c == 0 && units / c <= PG_MAXIT && (ks2 == 0 || c <= want)) ks2 = c;
+    return ks2;
 }
 
 int skinny_ks2(int N, int K)
@@ -420,7 +514,8 @@ int skinny_ks2(int N, int K)
 size_t swx_skinny_slab_floats(int M, int N, int K)
 {
     if (M <= 0 || M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC) return 0;
-    return (size_t)skinny_ks2(N, K) * M * N;
+    const int a = skinny_ks2(N, K), b = pg_ks2(N, K);
+    return (size_t)(a > b ? a : b) * M * N;
 }
 
 int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
@@ -428,36 +523,46 @@ int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ld
 {
     if (M <= 0 || N <= 0) return 0;
     if (M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC || lda % 8 != 0 || ldw % 8 != 0) return -4;
-    const int ks2 = skinny_ks2(N, K);
+    const int ks2 = pg_ks2(N, K);
+    if (ks2 <= 0) return -4;
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = EPI_OUT_F32; g.res_mod = 1;
     const int64_t stride = (int64_t)M * N;
-    dim3 grid(cdiv(N, 16), ks2);
+    dim3 grid(cdiv(N, 64), ks2);
     {
         SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)N * K + (double)M * K) + (double)M * N * 2, s);
         switch (cdiv(M, 16)) {
-            case 1: hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 2: hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 3: hipLaunchKernelGGL(gemm_f16_skinny<3>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 4: hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 5: hipLaunchKernelGGL(gemm_f16_skinny<5>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 6: hipLaunchKernelGGL(gemm_f16_skinny<6>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 7: hipLaunchKernelGGL(gemm_f16_skinny<7>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            default: hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 1: hipLaunchKernelGGL(gemm_f16_pg<1>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 2: hipLaunchKernelGGL(gemm_f16_pg<2>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 3: hipLaunchKernelGGL(gemm_f16_pg<3>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 4: hipLaunchKernelGGL(gemm_f16_pg<4>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 5: hipLaunchKernelGGL(gemm_f16_pg<5>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 6: hipLaunchKernelGGL(gemm_f16_pg<6>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            case 7: hipLaunchKernelGGL(gemm_f16_pg<7>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
+            default: hipLaunchKernelGGL(gemm_f16_pg<8>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
         }
     }
     {
         SwxProfScope prof(PC_NORM, (double)ks2 * M * N * 4 + 4.0 * M * N, s);
         const int nc = cdiv(N, 256);
-#define SWX_FIN(KS, NC) hipLaunchKernelGGL((splitk_finish_f16<KS, NC>), dim3(M), dim3(256), 0, s, slabs, ks2, stride, N, f)
-        if (nc <= 5 && ks2 == 5) SWX_FIN(5, 5);
-        else if (nc <= 5 && ks2 == 8) SWX_FIN(8, 5);
-        else if (nc <= 5 && ks2 == 10) SWX_FIN(10, 5);
-        else if (nc <= 15 && ks2 == 2) SWX_FIN(2, 15);
-        else if (nc <= 20 && ks2 == 2) SWX_FIN(2, 20);
-        else if (nc <= 20 && ks2 == 1) SWX_FIN(1, 20);
-        else if (nc <= 5) SWX_FIN(0, 5);
-        else SWX_FIN(0, 20);
+        // rows without a fused LayerNorm are split over blockIdx.y in 1280-column pieces (more workgroups, fewer erf per thread)
+        const bool split = !f.ln_out && nc > 5;
+        dim3 fg(M, split ? cdiv(N, 1280) : 1);
+#define SWX_FIN(KS, NC) hipLaunchKernelGGL((splitk_finish_f16<KS, NC>), fg, dim3(256), 0, s, slabs, ks2, stride, N, f)
+        if (split || nc <= 5) {
+            switch (ks2) {
+                case 1: SWX_FIN(1, 5); break;
+                case 2: SWX_FIN(2, 5); break;
+                case 4: SWX_FIN(4, 5); break;
+                case 5: SWX_FIN(5, 5); break;
+                case 8: SWX_FIN(8, 5); break;
+                case 10: SWX_FIN(10, 5); break;
+                case 16: SWX_FIN(16, 5); break;
+                default: SWX_FIN(0, 5); break;
+            }
+        } else {
+            SWX_FIN(0, 20);
+        }
 #undef SWX_FIN
     }
     SWX_CHECK_LAUNCH();
@@ -469,7 +574,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
     if (g.M <= 0 || g.N <= 0) return 0;
     if (dtype == SWX_F16) {
         if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;   // tiled: K % 32, skinny: K % 128
-        const bool skinny_ok = g.M <= 128 && g.K % 128 == 0 && g.K / 128 <= 10;
+        const bool skinny_ok = g.M <= 128 && g.K % 128 == 0 && g.K / 128 <= 10 && g.N <= 16384;   // vocabulary-sized N: tiled
         const bool use_skinny = force_kernel == 2 ? skinny_ok : (force_kernel == 1 ? false : skinny_ok);
         if (force_kernel == 2 && !skinny_ok) return -4;
         if (use_skinny) {

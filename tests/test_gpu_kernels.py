@@ -189,7 +189,7 @@ def test_gemm_f16_tiled_and_skinny(M, N, K):
     w = (torch.randn(N, K, generator=g) * 0.5).half().cuda()
     bias = torch.randn(N, generator=g).cuda()
     ref = (a.double() @ w.double().T + bias.double())
-    kinds = [1] + ([2] if (M <= 128 and K % 128 == 0) else [])
+    kinds = [1] + ([2] if (M <= 128 and K % 128 == 0 and K // 128 <= 10 and N <= 16384) else [])
     for force in kinds:
         c = _gemm(1, a, w, bias=bias, epi=1, force=force)
         err = (c.double() - ref).abs().max().item()
