@@ -58,8 +58,10 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i, key = c >> 3, dc = (c & 7) * 8;
             const int kg = kt0 + key;
-            f16x8 kv = (f16x8)(f16)0, vv = (f16x8)(f16)0;
-            if (kg < a.nk) kv = *(const f16x8 *)(K + (size_t)b * a.k_bs + (size_t)kg * a.ldkv + h * DH + dc);
+            // clamped addresses + select (no predicated loads: they become branches with early vmcnt(0) waits)
+            const int kgc = kg < a.nk ? kg : a.nk - 1;
+            f16x8 kv = *(const f16x8 *)(K + (size_t)b * a.k_bs + (size_t)kgc * a.ldkv + h * DH + dc), vv;
+            if (kg >= a.nk) kv = (f16x8)(f16)0;
             *(f16x8 *)&Ks[key][dc] = kv;
             if (a.vt_kp) {
                 // V already transposed in HBM ([H][64][kp], zero padded): chunk c -> d row c>>3, 8 keys at (c&7)*8
@@ -67,7 +69,8 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
                 vv = *(const f16x8 *)(V + (size_t)b * a.v_bs + ((size_t)h * DH + dr) * a.vt_kp + kt0 + kc);
                 *(f16x8 *)&Vt[dr][kc] = vv;
             } else {
-                if (kg < a.nk) vv = *(const f16x8 *)(V + (size_t)b * a.v_bs + (size_t)kg * a.ldkv + h * DH + dc);
+                vv = *(const f16x8 *)(V + (size_t)b * a.v_bs + (size_t)kgc * a.ldkv + h * DH + dc);
+                if (kg >= a.nk) vv = (f16x8)(f16)0;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) Vt[dc + e][key] = vv[e];
             }
@@ -186,9 +189,9 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = k0 + krow + 4 * t;
-            const f16 *kr = Kp + (size_t)(key < a.nk ? key : 0) * a.ldkv + g * 8;
-            kf[t][0] = (key < a.nk) ? *(const f16x8 *)(kr) : (f16x8)(f16)0;
-            kf[t][1] = (key < a.nk) ? *(const f16x8 *)(kr + 32) : (f16x8)(f16)0;
+            const f16 *kr = Kp + (size_t)(key < a.nk ? key : a.nk - 1) * a.ldkv + g * 8;   // clamped: loads are never predicated
+            kf[t][0] = *(const f16x8 *)(kr);              // rows past nk are masked to -inf below
+            kf[t][1] = *(const f16x8 *)(kr + 32);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) vf[t] = *(const f16x8 *)(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);

@@ -64,8 +64,11 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
             const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
             const int gm = m0 + row, gn = n0 + row;
             const bool kok = k0 + kc < g.K;          // K may end in the middle of a 64-wide step (K % 32 == 0)
-            ra[i] = (gm < g.M && kok) ? *(const f16x8 *)(A + (size_t)gm * g.lda + k0 + kc) : (f16x8)(f16)0;
-            rb[i] = (gn < g.N && kok) ? *(const f16x8 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f16x8)(f16)0;
+            const int kq = kok ? k0 + kc : 0;        // clamped addresses + select: no predicated loads
+            const f16x8 va = *(const f16x8 *)(A + (size_t)(gm < g.M ? gm : g.M - 1) * g.lda + kq);
+            const f16x8 vb = *(const f16x8 *)(W + (size_t)(gn < g.N ? gn : g.N - 1) * g.ldw + kq);
+            ra[i] = (gm < g.M && kok) ? va : (f16x8)(f16)0;
+            rb[i] = (gn < g.N && kok) ? vb : (f16x8)(f16)0;
         }
     };
     auto store_lds = [&](int buf) {
@@ -270,7 +273,10 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
     // weight load cannot provide
     f16x8 wf[NKS_MAX];
 #pragma unroll
-    for (int ks = 0; ks < NKS_MAX; ++ks) wf[ks] = (nok && ks < nks) ? *(const f16x8 *)(wp + ks * 32) : zero8;
+    for (int ks = 0; ks < NKS_MAX; ++ks) {
+        const f16x8 v = *(const f16x8 *)(wp + (ks < nks ? ks : nks - 1) * 32);
+        wf[ks] = (nok && ks < nks) ? v : zero8;
+    }
 
     f32x4 acc[MT];
 #pragma unroll
@@ -286,13 +292,13 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
     // L2 side: activation fragments, two k-steps deep
     f16x8 af[2][MT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) af[0][t] = aok[t] ? *(const f16x8 *)(ap[t]) : zero8;
+    for (int t = 0; t < MT; ++t) { const f16x8 v = *(const f16x8 *)(ap[t]); af[0][t] = aok[t] ? v : zero8; }
 #pragma unroll
     for (int ks = 0; ks < NKS_MAX; ++ks) {
         if (ks < nks) {
             if (ks + 1 < nks) {
 #pragma unroll
-                for (int t = 0; t < MT; ++t) af[(ks + 1) & 1][t] = aok[t] ? *(const f16x8 *)(ap[t] + (ks + 1) * 32) : zero8;
+                for (int t = 0; t < MT; ++t) { const f16x8 v = *(const f16x8 *)(ap[t] + (ks + 1) * 32); af[(ks + 1) & 1][t] = aok[t] ? v : zero8; }
             }
 #pragma unroll
             for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[ks & 1][t], wf[ks], acc[t], 0, 0, 0);
@@ -345,9 +351,14 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
     const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
     const f16x8 zero8 = (f16x8)(f16)0;
 
+    // loads are never predicated (clamped address + select): predication turns into branches and early vmcnt(0) waits
     f16x8 wf[2 * PG_MAXIT];
 #pragma unroll
-    for (int ks = 0; ks < 2 * PG_MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
+    for (int ks = 0; ks < 2 * PG_MAXIT; ++ks) {
+        const int kc = ks < 2 * nit ? ks : 2 * nit - 1;
+        const f16x8 v = *(const f16x8 *)(wp + kc * 32);
+        wf[ks] = (nok && ks < 2 * nit) ? v : zero8;
+    }
 
     f32x4 acc[MT];
 #pragma unroll
@@ -359,7 +370,8 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int idx = tid + 256 * j, row = idx >> 3, c8 = (idx & 7) * 8;
-            ra[j] = (row < g.M) ? *(const f16x8 *)(A + (size_t)row * g.lda + kb + it * 64 + c8) : zero8;
+            const f16x8 v = *(const f16x8 *)(A + (size_t)(row < g.M ? row : g.M - 1) * g.lda + kb + it * 64 + c8);
+            ra[j] = (row < g.M) ? v : zero8;
         }
     };
     auto store_a = [&](int buf) {
@@ -424,7 +436,8 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
 #pragma unroll
             for (int k = 0; k < KS2; ++k) {
                 const int col = tid + 256 * i;
-                part[i][k] = (col < N) ? base[(size_t)k * slab_stride + col] : 0.f;
+                part[i][k] = base[(size_t)k * slab_stride + (col < N ? col : N - 1)];   // clamped, never predicated: a
+                // predicated load becomes a branch + s_waitcnt vmcnt(0) per column group (serialised round trips)
             }
 #pragma unroll
         for (int i = 0; i < NC; ++i) {
