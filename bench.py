@@ -123,7 +123,8 @@ def main():
         res = step()
     torch.cuda.synchronize()
     par.barrier()
-    dt = par.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else None)
+    import torch.distributed as _dist
+    dt = par.max_over_ranks(time.perf_counter() - t0, device=dev if _dist.is_initialized() else None)
 
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     n_words = len(res.all_words()) if res is not None else 0
@@ -196,9 +197,8 @@ def main():
             signal.alarm(0)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    if _dist.is_initialized():
+        _dist.destroy_process_group()
 
 
 def cpu_baseline(args, sd, dims):

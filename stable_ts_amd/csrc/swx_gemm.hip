@@ -64,11 +64,9 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
             const int c = tid + 256 * i, row = c >> 3, kc = (c & 7) * 8;
             const int gm = m0 + row, gn = n0 + row;
             const bool kok = k0 + kc < g.K;          // K may end in the middle of a 64-wide step (K % 32 == 0)
-            const int kq = kok ? k0 + kc : 0;        // clamped addresses + select: no predicated loads
-            const f16x8 va = *(const f16x8 *)(A + (size_t)(gm < g.M ? gm : g.M - 1) * g.lda + kq);
-            const f16x8 vb = *(const f16x8 *)(W + (size_t)(gn < g.N ? gn : g.N - 1) * g.ldw + kq);
-            ra[i] = (gm < g.M && kok) ? va : (f16x8)(f16)0;
-            rb[i] = (gn < g.N && kok) ? vb : (f16x8)(f16)0;
+            // predicated loads here: the clamped-address form measured 10-15 % slower on this kernel (profiles r01 v5)
+            ra[i] = (gm < g.M && kok) ? *(const f16x8 *)(A + (size_t)gm * g.lda + k0 + kc) : (f16x8)(f16)0;
+            rb[i] = (gn < g.N && kok) ? *(const f16x8 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f16x8)(f16)0;
         }
     };
     auto store_lds = [&](int buf) {
@@ -351,14 +349,9 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
     const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
     const f16x8 zero8 = (f16x8)(f16)0;
 
-    // loads are never predicated (clamped address + select): predication turns into branches and early vmcnt(0) waits
     f16x8 wf[2 * PG_MAXIT];
 #pragma unroll
-    for (int ks = 0; ks < 2 * PG_MAXIT; ++ks) {
-        const int kc = ks < 2 * nit ? ks : 2 * nit - 1;
-        const f16x8 v = *(const f16x8 *)(wp + kc * 32);
-        wf[ks] = (nok && ks < 2 * nit) ? v : zero8;
-    }
+    for (int ks = 0; ks < 2 * PG_MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
 
     f32x4 acc[MT];
 #pragma unroll
@@ -370,8 +363,7 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int idx = tid + 256 * j, row = idx >> 3, c8 = (idx & 7) * 8;
-            const f16x8 v = *(const f16x8 *)(A + (size_t)(row < g.M ? row : g.M - 1) * g.lda + kb + it * 64 + c8);
-            ra[j] = (row < g.M) ? v : zero8;
+            ra[j] = (row < g.M) ? *(const f16x8 *)(A + (size_t)row * g.lda + kb + it * 64 + c8) : zero8;
         }
     };
     auto store_a = [&](int buf) {

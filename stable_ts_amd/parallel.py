@@ -18,7 +18,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("SWX_FORCE_DIST") == "1"     # exercise the RCCL code path with a single rank (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -39,14 +40,14 @@ def shard_windows(n_windows: int, rank: int, world: int) -> range:
 
 def broadcast_arena(arena: torch.Tensor, src: int = 0):
     """Weights: rank `src` loads/converts the checkpoint once, everyone else receives the packed arena over RCCL."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SWX_FORCE_DIST") == "1"):
         dist.broadcast(arena, src=src)
     return arena
 
 
 def gather_results(local: List[Any], dst: int = 0) -> Optional[List[Any]]:
     """Gather per-rank lists of picklable window records; returns the rank-ordered concatenation on `dst`."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and os.environ.get("SWX_FORCE_DIST") != "1"):
         return list(local)
     world = dist.get_world_size()
     out = [None] * world if dist.get_rank() == dst else None
@@ -57,12 +58,12 @@ def gather_results(local: List[Any], dst: int = 0) -> Optional[List[Any]]:
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SWX_FORCE_DIST") == "1"):
         dist.barrier()
 
 
 def max_over_ranks(value: float, device=None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and os.environ.get("SWX_FORCE_DIST") != "1"):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

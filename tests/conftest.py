@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def _limit_threads():
     # the CPU oracle runs inside the GPU tests; xdist workers x 64 default torch threads thrash the host
+    if not os.environ.get("PYTEST_XDIST_WORKER"):
+        return
     try:
         import torch
         torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
