@@ -822,7 +822,8 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
         if (cfg->beam) cur ^= 1;
         steps = i + 1;
         if (n_init + i + 1 > D.n_text_ctx) break;          // tokens.shape[-1] > n_ctx (decode.py:60)
-        if (steps % CHECK == 0 || steps == cfg->sample_len) {
+        // early-exit poll (one host sync); pointless while EOT is still suppressed by min_tokens
+        if ((steps % CHECK == 0 && steps >= cfg->min_tokens) || steps == cfg->sample_len) {
             er = hipMemcpyAsync(&h_done, b.n_done, 4, hipMemcpyDeviceToHost, s);
             if (er != hipSuccess) return -100 - (int)er;
             er = hipStreamSynchronize(s);

@@ -20,7 +20,12 @@ def audio2loudness(x: torch.Tensor) -> Optional[torch.Tensor]:
     """nonvad.py:16-39: |x| normalised by (1.75 x the 99.9th-percentile level), resampled to one value per 20 ms."""
     x = x.abs()
     k = int(x.numel() * 0.001)
-    thr = torch.topk(x, k).values[-1] if k else x.quantile(0.999, dim=-1)
+    if k:
+        # the k-th largest value (== torch.topk(x, k).values[-1], the reference's expression) by O(n) selection
+        xn = x.numpy()
+        thr = torch.tensor(np.partition(xn, xn.size - k)[xn.size - k])
+    else:
+        thr = x.quantile(0.999, dim=-1)
     units = round(x.shape[-1] / N_SAMPLES_PER_TOKEN) + 1
     if units <= 2:
         return None
@@ -91,7 +96,7 @@ class NonSpeechPredictor:
         self._ends: List[float] = []
 
     def predict(self, audio: torch.Tensor, offset: float = 0.0) -> dict:
-        audio = audio.detach().float().cpu()
+        audio = audio.detach().float().cpu().contiguous()
         mask = wav2mask(audio, self.q_levels, self.k_size)
         timings = mask2timing(mask, time_offset=offset)
         if timings is not None:

@@ -319,11 +319,17 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
 
     all_segments: List[dict] = []
 
+    # silence analysis is host-side vector code (CPU); keep one host copy of the recording for it
+    audio_host = audio.detach().float().cpu() if nonspeech is not None else None
+    pred_cache = {}
+
     def window_input(seek: int, prompt: List[int]):
         seg = audio[seek: seek + N_SAMPLES]
         item = dict(audio=seg, seek_sample=seek, prompt=prompt, ts_mask=None, silence=None, skip=False)
         if nonspeech is not None:
-            pred = nonspeech.predict(seg, offset=seek / SAMPLE_RATE)
+            pred = pred_cache.pop(seek, None)
+            if pred is None:
+                pred = nonspeech.predict(audio_host[seek: seek + N_SAMPLES], offset=seek / SAMPLE_RATE)
             item["silence"] = pred["timings"] if suppress_silence else None
             item["ts_mask"] = pred["mask"]
             item["skip"] = pred["is_silent"]
@@ -359,6 +365,12 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     if batch_size:
         # ---- window-parallel driver: fixed stride, no prompt carry-over
         seeks = list(range(0, total, N_SAMPLES))
+        if nonspeech is not None and len(seeks) > 1:
+            # the windows are known up front in this mode: analyse them concurrently (torch/numpy release the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=8) as pool:
+                preds = list(pool.map(lambda sk: nonspeech.predict(audio_host[sk: sk + N_SAMPLES], offset=sk / SAMPLE_RATE), seeks))
+            pred_cache.update(zip(seeks, preds))
         for b0 in range(0, len(seeks), batch_size):
             items = [window_input(s, list(initial_prompt_tokens)) for s in seeks[b0: b0 + batch_size]]
             live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]

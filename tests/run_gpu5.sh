@@ -2,7 +2,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( timeout 300 python -m pytest tests/test_gpu_kernels.py -m gpu -q -n 2 --timeout=300 2>&1 | tail -30 ) > gpurun_out/kernels.log
-( timeout 420 python -m pytest "tests/test_gpu_model.py::test_decode_f16_fast_step_equals_general_path" "tests/test_gpu_model.py::test_forward_logits" -m gpu -q -n 3 --timeout=400 2>&1 | tail -30 ) > gpurun_out/model.log
+( timeout 420 python -m pytest tests/test_gpu_golden.py "tests/test_gpu_model.py::test_decode_f16_fast_step_equals_general_path" -m gpu -q -n 3 --timeout=400 2>&1 | tail -30 ) > gpurun_out/model.log
 ( timeout 600 python bench.py --no-cpu-baseline 2> gpurun_out/bench.err | tail -5 ) > gpurun_out/bench.log
 ( SWX_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 1 --warmup 0 --minutes 1 --batch 2 --no-cpu-baseline --no-roofline 2>&1 | tail -4 ) > gpurun_out/dist1.log
 cd /tmp && ( timeout 400 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log
