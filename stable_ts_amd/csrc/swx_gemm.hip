@@ -11,6 +11,7 @@
 //                 streamed straight from HBM into MFMA fragments (no LDS), LDS reduction (HBM-bound decode steps)
 // Epilogue (f32): +bias, GELU(erf), +f32 residual indexed by row % res_mod (positional embedding), +T residual,
 // store as T or f32.
+#include <cstdlib>
 #include "swx_common.h"
 #include "swx_kernels.h"
 
@@ -495,7 +496,8 @@ int pg_ks2(int N, int K)
 {
     const int units = K / 64;
     const int panels = (N + 63) / 64;
-    int want = (320 + panels - 1) / panels;
+    static const int target = [] { const char *e = getenv("SWX_PG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 320; }();
+    int want = (target + panels - 1) / panels;     // workgroups wanted per launch (tunable for experiments)
     int ks2 = 0;
     for (int c = 1; c <= units; ++c)
         if (units % c == 0 && units / c <= PG_MAXIT && (ks2 == 0 || c <= want)) ks2 = c;
