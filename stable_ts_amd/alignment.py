@@ -55,7 +55,8 @@ def _words_from_text(text: str, tokenizer) -> List[WordToken]:
 
 
 def align(model, audio, text: Union[str, List[int], WhisperResult], language: str = None, *, token_step: int = 100,
-          tokenizer=None, batch_size: int = 1, **options) -> Optional[WhisperResult]:
+          tokenizer=None, batch_size: int = 1, regroup: Union[bool, str] = True,
+          **options) -> Optional[WhisperResult]:
     """Forced alignment.  ``text`` may be a string, a token list, or a WhisperResult (its text is re-aligned).
     Windows are consumed sequentially: each call aligns up to ``token_step`` tokens against the next <=30 s of audio and
     the seek moves to the end of the last word that ended before the window's final second."""
@@ -119,11 +120,14 @@ def align(model, audio, text: Union[str, List[int], WhisperResult], language: st
         done.append(dict(word=w.word, start=t, end=t, probability=0.0, tokens=w.tokens))
     seg = dict(start=done[0]["start"], end=done[-1]["end"], text="".join(w["word"] for w in done), seek=0.0,
                tokens=[t for w in done for t in w["tokens"]], words=done)
-    return WhisperResult(dict(segments=[seg], language=getattr(tokenizer, "language", language)), check_sorted=False)
+    result = WhisperResult(dict(segments=[seg], language=getattr(tokenizer, "language", language)), check_sorted=False)
+    if regroup:                                               # non_whisper/alignment.py:388-389
+        result.regroup(regroup)
+    return result
 
 
 def align_words(model, audio, result: Union[WhisperResult, List[dict]], language: str = None, *, tokenizer=None,
-                batch_size: int = 8, **options) -> WhisperResult:
+                batch_size: int = 8, regroup: Union[bool, str] = True, **options) -> WhisperResult:
     """alignment.py:219-368: re-align the words of each pre-timed segment independently (embarrassingly parallel:
     segments are batched `batch_size` at a time through one encoder / scoring pass)."""
     from .transcribe import load_audio
@@ -154,4 +158,7 @@ def align_words(model, audio, result: Union[WhisperResult, List[dict]], language
                        probability=w["probability"], tokens=w["tokens"]) for w in words]
             out_segments.append(dict(start=ws[0]["start"], end=ws[-1]["end"], text="".join(w["word"] for w in ws),
                                      seek=round(off, 3), tokens=[t for w in ws for t in w["tokens"]], words=ws))
-    return WhisperResult(dict(segments=out_segments, language=getattr(tokenizer, "language", language)), check_sorted=False)
+    out = WhisperResult(dict(segments=out_segments, language=getattr(tokenizer, "language", language)), check_sorted=False)
+    if regroup:                                               # non_whisper/alignment.py:472
+        out.regroup(regroup)
+    return out

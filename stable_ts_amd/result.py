@@ -1,40 +1,127 @@
-"""Result containers returned by transcribe()/align().
+"""Result containers returned by transcribe()/align(): WordTiming, Segment, WhisperResult.
 
-The reference's result model (stable_whisper/result.py: WordTiming :74-257, Segment :277-925, WhisperResult
-:928-3102) is pure-Python post-processing that SURVEY.md 8f ranks as "next-1" (regroup DSL, silence snapping, splitting
-and merging).  This module carries the part the hot path produces and consumers read: the same field names and the
-same ``to_dict()`` JSON schema (result.py:1398-1406), ordering checks, and word/segment accessors.
+Mirrors the reference's result model where consumers touch it (stable_whisper/result.py: WordTiming :74-257, Segment
+:277-925, WhisperResult :928-3102): the same field names, the same ``to_dict()`` JSON schema (:192-204, :596-626,
+:1398-1406), millisecond rounding of every stored timestamp (:38-41), lock flags, ordering checks, and the regrouping
+methods (``split_by_*``, ``merge_by_*``, ``clamp_max``, ``lock``, ``pad``, ``regroup`` and its string DSL).  The
+regrouping algorithms themselves live in :mod:`stable_ts_amd.regroup` as functions over the segment list; the methods
+here are the reference-named entry points that record ``regroup_history``.
+
+Pure host-side list surgery after the GPU hot path (SURVEY.md 8f "next-1"); there is nothing here for the GPU to do.
 """
 import json
 import warnings
 from typing import Iterator, List, Optional, Union
 
 
+def _ms(ts):
+    """result.py:38-41: timestamps are stored rounded to the millisecond (0 / None pass through)."""
+    return round(ts, 3) if ts else ts
+
+
+def _blend(a, b):
+    """result.py:21-31 for scalars: merged-segment statistics are the mean of the pair, None is contagious."""
+    if a is None:
+        return None
+    return None if b is None else (a + b) / 2
+
+
 class WordTiming:
+    __slots__ = ("word", "_start", "_end", "probability", "tokens", "left_locked", "right_locked", "id", "segment")
+
     def __init__(self, word: str, start: float, end: float, probability: Optional[float] = None,
-                 tokens: Optional[List[int]] = None, segment_id: Optional[int] = None, id: Optional[int] = None, **_):
+                 tokens: Optional[List[int]] = None, left_locked: bool = False, right_locked: bool = False,
+                 segment_id: Optional[int] = None, id: Optional[int] = None, segment: Optional["Segment"] = None, **_):
         self.word = word
-        self.start = float(start)
-        self.end = float(end)
+        self._start = _ms(start)
+        self._end = _ms(end)
         self.probability = probability
         self.tokens = tokens
-        self.segment_id = segment_id
+        self.left_locked = bool(left_locked)
+        self.right_locked = bool(right_locked)
         self.id = id
+        self.segment = segment
+
+    # -- timestamps (rounded on every store, result.py:160-172)
+    @property
+    def start(self):
+        return self._start
+
+    @start.setter
+    def start(self, v):
+        self._start = _ms(v)
 
     @property
-    def duration(self) -> float:
-        return round(self.end - self.start, 3)
+    def end(self):
+        return self._end
 
-    def offset_time(self, offset: float):
-        self.start = round(self.start + offset, 3)
-        self.end = round(self.end + offset, 3)
+    @end.setter
+    def end(self, v):
+        self._end = _ms(v)
 
-    def to_dict(self) -> dict:
-        return dict(word=self.word, start=self.start, end=self.end, probability=self.probability, tokens=self.tokens,
-                    segment_id=self.segment_id, id=self.id)
+    @property
+    def duration(self):
+        return _ms(self._end - self._start)
+
+    @property
+    def segment_id(self):
+        return None if self.segment is None else self.segment.id
+
+    def __len__(self):
+        return len(self.word)
 
     def __repr__(self):
-        return f"WordTiming({self.word!r}, {self.start}, {self.end})"
+        return f'WordTiming(start={self.start}, end={self.end}, word="{self.word}")'
+
+    def copy(self, copy_tokens: bool = False) -> "WordTiming":
+        toks = self.tokens
+        if toks is not None and copy_tokens:
+            toks = list(toks)
+        return WordTiming(self.word, self._start, self._end, self.probability, toks, self.left_locked,
+                          self.right_locked, id=self.id)
+
+    def joined(self, other: "WordTiming") -> "WordTiming":
+        """result.py:111-127 (``a + b``): text concatenated, span = union, probability averaged, tokens chained."""
+        w = WordTiming(self.word + other.word, min(self.start, other.start), max(self.end, other.end),
+                       _blend(self.probability, other.probability),
+                       None if self.tokens is None or other.tokens is None else list(self.tokens) + list(other.tokens),
+                       self.left_locked or other.left_locked, self.right_locked or other.right_locked,
+                       id=self.id, segment=self.segment)
+        return w
+
+    __add__ = joined
+
+    def offset_time(self, offset: float):
+        self.start = self._start + offset
+        self.end = self._end + offset
+
+    def rescale_time(self, factor: float):
+        self.start = self._start * factor
+        self.end = self._end * factor
+
+    def lock_left(self):
+        self.left_locked = True
+
+    def lock_right(self):
+        self.right_locked = True
+
+    def lock_both(self):
+        self.left_locked = self.right_locked = True
+
+    def unlock_both(self):
+        self.left_locked = self.right_locked = False
+
+    def clamp_max(self, max_dur: float, clip_start: bool = False):
+        """result.py:231-244: shorten an over-long word from one side."""
+        if self.duration > max_dur:
+            if clip_start:
+                self.start = round(self._end - max_dur, 3)
+            else:
+                self.end = round(self._start + max_dur, 3)
+
+    def to_dict(self) -> dict:
+        return dict(word=self.word, start=self.start, end=self.end, probability=self.probability,
+                    tokens=None if self.tokens is None else list(self.tokens), segment_id=self.segment_id, id=self.id)
 
 
 class Segment:
@@ -42,60 +129,168 @@ class Segment:
                  seek: Optional[float] = None, tokens: Optional[List[int]] = None, temperature: Optional[float] = None,
                  avg_logprob: Optional[float] = None, compression_ratio: Optional[float] = None,
                  no_speech_prob: Optional[float] = None, words: Optional[List[Union[WordTiming, dict]]] = None,
-                 id: Optional[int] = None, **_):
-        self._start, self._end, self._text = start, end, text
+                 id: Optional[int] = None, result: Optional["WhisperResult"] = None, **_):
+        if words:                                   # with words, start/end/text/tokens are views of the words
+            start = end = text = tokens = None
+        self._default_start = _ms(start) if start else 0.0
+        self._default_end = _ms(end) if end else 0.0
+        self._default_text = text or ""
+        self._default_tokens = tokens or []
         self.seek = seek
-        self.tokens = tokens
         self.temperature = temperature
         self.avg_logprob = avg_logprob
         self.compression_ratio = compression_ratio
         self.no_speech_prob = no_speech_prob
         self.id = id
+        self.result = result
         self.words: Optional[List[WordTiming]] = None
         if words is not None:
             self.words = [w if isinstance(w, WordTiming) else WordTiming(**w) for w in words]
-            for i, w in enumerate(self.words):
-                w.segment_id, w.id = id, i
+            self.reassign_ids()
 
+    # -- views
     @property
     def has_words(self) -> bool:
         return bool(self.words)
 
     @property
-    def start(self) -> float:
-        return self.words[0].start if self.has_words else self._start
+    def ori_has_words(self) -> bool:
+        return self.words is not None
 
     @property
-    def end(self) -> float:
-        return self.words[-1].end if self.has_words else self._end
+    def start(self):
+        return self.words[0].start if self.words else self._default_start
+
+    @start.setter
+    def start(self, v):
+        if self.words:
+            self.words[0].start = v
+        else:
+            self._default_start = _ms(v)
+
+    @property
+    def end(self):
+        return self.words[-1].end if self.words else self._default_end
+
+    @end.setter
+    def end(self, v):
+        if self.words:
+            self.words[-1].end = v
+        else:
+            self._default_end = _ms(v)
 
     @property
     def text(self) -> str:
-        return "".join(w.word for w in self.words) if self.has_words else self._text
+        return "".join(w.word for w in self.words) if self.words else self._default_text
 
     @property
-    def duration(self) -> float:
+    def tokens(self) -> List[int]:
+        if self.words and self.words[0].tokens:
+            return [t for w in self.words for t in w.tokens]
+        return self._default_tokens
+
+    @property
+    def duration(self):
         return self.end - self.start
+
+    @property
+    def left_locked(self) -> bool:
+        return bool(self.words) and self.words[0].left_locked
+
+    @property
+    def right_locked(self) -> bool:
+        return bool(self.words) and self.words[-1].right_locked
+
+    def word_count(self) -> int:
+        return len(self.words) if self.words else -1
+
+    def char_count(self) -> int:
+        return sum(len(w.word) for w in self.words) if self.words else len(self.text)
+
+    def __getitem__(self, i) -> WordTiming:
+        if self.words is None:
+            raise ValueError("segment contains no words")
+        return self.words[i]
+
+    def __repr__(self):
+        return f'Segment(start={self.start}, end={self.end}, text="{self.text}")'
+
+    # -- construction helpers used by the regrouping functions
+    def spawn(self, words: Optional[List[WordTiming]]) -> "Segment":
+        """A segment that inherits this one's decode statistics and owns ``words`` (result.py:356-389 with new_words)."""
+        s = Segment(seek=self.seek, temperature=self.temperature, avg_logprob=self.avg_logprob,
+                    compression_ratio=self.compression_ratio, no_speech_prob=self.no_speech_prob, id=self.id)
+        s.words = words
+        return s
+
+    def copy(self, copy_words: bool = True) -> "Segment":
+        s = self.spawn(None if self.words is None else
+                       ([w.copy(copy_tokens=True) for w in self.words] if copy_words else self.words))
+        s._default_start, s._default_end = self._default_start, self._default_end
+        s._default_text, s._default_tokens = self._default_text, list(self._default_tokens)
+        if copy_words:
+            s.reassign_ids()
+        return s
+
+    def reassign_ids(self, start: Optional[int] = None):
+        if self.words:
+            for i, w in enumerate(self.words[start:], start or 0):
+                w.segment, w.id = self, i
+
+    def lock_left(self):
+        if self.words:
+            self.words[0].lock_left()
+
+    def lock_right(self):
+        if self.words:
+            self.words[-1].lock_right()
+
+    def lock_both(self):
+        self.lock_left()
+        self.lock_right()
+
+    def unlock_all_words(self):
+        for w in self.words or ():
+            w.unlock_both()
 
     def offset_time(self, offset: float):
         if self.seek is not None:
-            self.seek = round(self.seek + offset, 3)
-        if self.has_words:
+            self.seek += offset
+        if self.words:
             for w in self.words:
                 w.offset_time(offset)
         else:
-            self._start = round(self._start + offset, 3)
-            self._end = round(self._end + offset, 3)
+            self.start = self.start + offset
+            self.end = self.end + offset
+
+    def rescale_time(self, factor: float):
+        if self.seek is not None:
+            self.seek *= factor
+        if self.words:
+            for w in self.words:
+                w.rescale_time(factor)
+        else:
+            self.start = self.start * factor
+            self.end = self.end * factor
+
+    def convert_to_segment_level(self):
+        """result.py:918-925: freeze the word-derived fields and drop the words."""
+        if self.words:
+            self._default_text, self._default_tokens = self.text, self.tokens
+            self._default_start, self._default_end = self.start, self.end
+            self.words = None
 
     def to_dict(self) -> dict:
-        d = dict(start=self.start, end=self.end, text=self.text, seek=self.seek, tokens=self.tokens,
-                 temperature=self.temperature, avg_logprob=self.avg_logprob, compression_ratio=self.compression_ratio,
-                 no_speech_prob=self.no_speech_prob, id=self.id)
-        d["words"] = [w.to_dict() for w in self.words] if self.words is not None else None
+        toks = self.tokens
+        d = dict(start=self.start, end=self.end, text=self.text, seek=self.seek,
+                 tokens=None if toks is None else list(toks), temperature=self.temperature,
+                 avg_logprob=self.avg_logprob, compression_ratio=self.compression_ratio,
+                 no_speech_prob=self.no_speech_prob)
+        if self.words:
+            d["words"] = [w.to_dict() for w in self.words]
+        elif self.words is not None:
+            d["words"] = []
         return d
-
-    def __repr__(self):
-        return f"Segment({self.start}, {self.end}, {self.text!r})"
 
 
 class UnsortedException(Exception):
@@ -104,31 +299,53 @@ class UnsortedException(Exception):
 
 class WhisperResult:
     def __init__(self, result: Union[dict, list, str], force_order: bool = False, check_sorted: bool = True):
+        self.path = None
         if isinstance(result, str):
+            self.path = result
             with open(result, "r", encoding="utf-8") as f:
                 result = json.load(f)
-        if isinstance(result, list):
-            result = dict(segments=result)
+        result = self._as_dict(result)
         self.ori_dict = result.get("ori_dict") or result
-        self.language = result.get("language")
-        self.unfinished_start = result.get("unfinished_start", -1.0)
-        self.nonspeech_sections = result.get("nonspeech_sections", [])
-        segs = result.get("segments") or []
+        self.language = self.ori_dict.get("language")
+        self._regroup_history = result.get("regroup_history", "")
+        self._nonspeech_sections = result.get("nonspeech_sections") or []
+        segs = result.get("segments", self.ori_dict.get("segments")) or []
         self.segments: List[Segment] = [s if isinstance(s, Segment) else Segment(**s) for s in segs]
-        self._text = result.get("text")
-        self.reassign_ids()
+        self._forced_order = force_order
+        self._ignore_special_periods = False
+        self.unfinished_start = result.get("unfinished", result.get("unfinished_start", -1.0))
         if force_order:
             self.force_order()
         if check_sorted:
             self.raise_for_unsorted()
-        self.remove_no_word_segments()
+        self.remove_no_word_segments(any(s.has_words for s in self.segments))
+
+    @staticmethod
+    def _as_dict(result) -> dict:
+        """result.py:966-996: accept a dict, a list of segment dicts, or a list of word-dict lists."""
+        if isinstance(result, dict):
+            return result
+        if not isinstance(result, list):
+            raise TypeError(f"Expect result to be list but got {type(result)}")
+        if not result or not result[0]:
+            return {}
+        if isinstance(result[0], list):
+            return dict(segments=[dict(start=ws[0]["start"], end=ws[-1]["end"], text="".join(w["word"] for w in ws),
+                                       words=ws) for ws in result if ws])
+        if isinstance(result[0], (dict, Segment)):
+            return dict(segments=result)
+        raise NotImplementedError(f"Got list of {type(result[0])} but expects list of list/dict")
 
     # -- container protocol
     def __len__(self):
         return len(self.segments)
 
-    def __getitem__(self, i):
+    def __getitem__(self, i) -> Segment:
         return self.segments[i]
+
+    def __delitem__(self, i):
+        del self.segments[i]
+        self.reassign_ids(True, start=i)
 
     def __iter__(self) -> Iterator[Segment]:
         return iter(self.segments)
@@ -144,43 +361,79 @@ class WhisperResult:
     def text(self) -> str:
         return "".join(s.text for s in self.segments)
 
+    @property
+    def duration(self):
+        return _ms(self.segments[-1].end - self.segments[0].start) if self.segments else 0.0
+
+    @property
+    def regroup_history(self) -> str:
+        return self._regroup_history
+
+    @property
+    def nonspeech_sections(self) -> list:
+        return self._nonspeech_sections
+
+    @nonspeech_sections.setter
+    def nonspeech_sections(self, v):
+        self._nonspeech_sections = list(v or [])
+
+    def update_nonspeech_sections(self, silent_starts, silent_ends, overwrite: bool = True):
+        secs = [dict(start=round(s, 3), end=round(e, 3)) for s, e in zip(silent_starts, silent_ends)]
+        if overwrite:
+            self._nonspeech_sections = secs
+        else:
+            self._nonspeech_sections.extend(secs)
+
     def all_words(self) -> List[WordTiming]:
         return [w for s in self.segments for w in (s.words or [])]
 
+    def all_words_or_segments(self):
+        return self.all_words() if self.has_words else self.segments
+
     def all_tokens(self) -> List[int]:
+        if self.has_words:
+            return [t for w in self.all_words() for t in (w.tokens or [])]
         return [t for s in self.segments for t in (s.tokens or [])]
 
-    def reassign_ids(self):
-        for i, s in enumerate(self.segments):
-            s.id = i
-            for j, w in enumerate(s.words or []):
-                w.segment_id, w.id = i, j
+    def reassign_ids(self, only_segments: bool = False, start: Optional[int] = None):
+        for i, s in enumerate(self.segments[start:], start or 0):
+            s.id, s.result = i, self
+            if not only_segments:
+                s.reassign_ids()
 
-    def remove_no_word_segments(self):
-        """result.py:948: segments that were given a (now empty) word list are dropped."""
-        self.segments = [s for s in self.segments if s.words is None or len(s.words) > 0]
-        self.reassign_ids()
+    def remove_no_word_segments(self, ignore_ori: bool = False, reassign_ids: bool = True):
+        """result.py:1334-1339: segments that were given a (now empty) word list are dropped."""
+        self.segments = [s for s in self.segments if not ((ignore_ori or s.ori_has_words) and not s.has_words)]
+        if reassign_ids:
+            self.reassign_ids()
 
     def force_order(self):
-        prev_end = 0.0
-        for s in self.segments:
-            if s.has_words:
-                continue
-            if s._start < prev_end:
-                s._start = prev_end
-            if s._end < s._start:
-                s._end = s._start
-            prev_end = s._end
+        """result.py:998-1018: clip starts to the previous end so the sequence is non-decreasing."""
+        parts = self.all_words_or_segments()
+        prev_end = 0
+        for i, p in enumerate(parts, 1):
+            if p.start < prev_end:
+                p.start = prev_end
+            if p.start > p.end:
+                if prev_end > p.end:
+                    warnings.warn("Multiple consecutive timestamps are out of order. Some parts will have no duration.")
+                    p.start = p.end
+                    for q in reversed(parts[:i - 1]):
+                        if q.end > p.end:
+                            q.end = p.end
+                        if q.start > p.end:
+                            q.start = p.end
+                elif p.start != prev_end:
+                    p.start = prev_end
+                else:
+                    p.end = p.start if i == len(parts) else parts[i].start
+            prev_end = p.end
 
     def raise_for_unsorted(self):
         """result.py:1020-1056: every timestamp must be non-decreasing."""
         stamps = []
-        for s in self.segments:
-            if s.has_words:
-                for w in s.words:
-                    stamps.extend([w.start, w.end])
-            else:
-                stamps.extend([s.start, s.end])
+        for p in self.all_words_or_segments():
+            stamps.extend((p.start, p.end))
         for a, b in zip(stamps[:-1], stamps[1:]):
             if b < a:
                 raise UnsortedException(f"timestamps are not in ascending order: {a} -> {b}")
@@ -189,22 +442,217 @@ class WhisperResult:
         for s in self.segments:
             s.offset_time(offset)
 
+    def rescale_time(self, factor: float):
+        for s in self.segments:
+            s.rescale_time(factor)
+
     def add_segments(self, other: "WhisperResult"):
+        """Append another result's segments (chunked / sharded transcription)."""
         self.segments.extend(other.segments)
         self.reassign_ids()
 
-    def to_dict(self) -> dict:
+    def to_dict(self, keep_orig: bool = True) -> dict:
+        ori = self.ori_dict if keep_orig else {}
         return dict(text=self.text, segments=[s.to_dict() for s in self.segments], language=self.language,
-                    ori_dict=self.ori_dict if isinstance(self.ori_dict, dict) and self.ori_dict is not self.__dict__ else None,
-                    nonspeech_sections=self.nonspeech_sections, unfinished_start=self.unfinished_start)
+                    ori_dict=ori, regroup_history=self._regroup_history,
+                    nonspeech_sections=self._nonspeech_sections, unfinished=self.unfinished_start)
 
     def save_as_json(self, path: str):
-        d = self.to_dict()
+        d = self.to_dict(keep_orig=False)
         d.pop("ori_dict", None)
         with open(path, "w", encoding="utf-8") as f:
             json.dump(d, f, allow_nan=True)
 
-    def regroup(self, *_, **__):
-        warnings.warn("regroup() is post-processing outside this round's hot-path scope (SURVEY.md 8f next-1); "
-                      "segments are returned as decoded")
+    def reset(self):
+        """result.py:3082-3092: back to the segments this result was created with."""
+        self.language = self.ori_dict.get("language")
+        self._regroup_history = ""
+        self.segments = [Segment(**s) for s in (self.ori_dict.get("segments") or [])]
+        if self._forced_order:
+            self.force_order()
+        self.remove_no_word_segments(any(s.has_words for s in self.segments))
+
+    # -- regrouping entry points (bodies in regroup.py)
+    def _log(self, entry: str):
+        if entry:
+            self._regroup_history += ("_" if self._regroup_history else "") + entry
+
+    def ignore_special_periods(self, enable: bool = True):
+        self._ignore_special_periods = enable
+        self._log(f"isp={int(enable)}")
         return self
+
+    def split_by_gap(self, max_gap: float = 0.1, lock: bool = False, newline: bool = False,
+                     ignore_special_periods: bool = False):
+        from . import regroup as R
+        isp = self._ignore_special_periods or ignore_special_periods
+        R.split_segments(self, lambda s: R.gap_cuts(s, max_gap), lock=lock, newline=newline, skip_special_periods=isp)
+        self._log(f"sg={max_gap}+{int(lock)}+{int(newline)}+{int(isp)}")
+        return self
+
+    def split_by_punctuation(self, punctuation, lock: bool = False, newline: bool = False,
+                             min_words: Optional[int] = None, min_chars: Optional[int] = None,
+                             min_dur: Optional[float] = None, ignore_special_periods: bool = False):
+        from . import regroup as R
+        eligible = None
+        if any((min_words, min_chars, min_dur)):
+            eligible = {id(s) for s in self.segments
+                        if (min_words and len(s.words or ()) >= min_words) or (min_chars and s.char_count() >= min_chars)
+                        or (min_dur and s.duration >= min_dur)}
+        isp = self._ignore_special_periods or ignore_special_periods
+        R.split_segments(self, lambda s: R.punctuation_cuts(s, punctuation)
+                         if eligible is None or id(s) in eligible else [],
+                         lock=lock, newline=newline, skip_special_periods=isp)
+        self._log(f"sp={R.punctuation_str(punctuation)}+{int(lock)}+{int(newline)}+{min_words or ''}"
+                  f"+{min_chars or ''}+{min_dur or ''}+{int(isp)}")
+        return self
+
+    def split_by_length(self, max_chars: int = None, max_words: int = None, even_split: bool = True,
+                        force_len: bool = False, lock: bool = False, include_lock: bool = False,
+                        newline: bool = False, ignore_special_periods: bool = False):
+        from . import regroup as R
+        if force_len:
+            self.merge_all_segments(record=False)
+        isp = self._ignore_special_periods or ignore_special_periods
+        R.split_segments(self, lambda s: R.length_cuts(s, max_chars, max_words, even_split, include_lock),
+                         lock=lock, newline=newline, skip_special_periods=isp)
+        self._log(f"sl={max_chars or ''}+{max_words or ''}+{int(even_split)}+{int(force_len)}"
+                  f"+{int(lock)}+{int(include_lock)}+{int(newline)}+{int(isp)}")
+        return self
+
+    def split_by_duration(self, max_dur: float, even_split: bool = True, force_len: bool = False, lock: bool = False,
+                          include_lock: bool = False, newline: bool = False, ignore_special_periods: bool = False):
+        from . import regroup as R
+        if force_len:
+            self.merge_all_segments(record=False)
+        isp = self._ignore_special_periods or ignore_special_periods
+        R.split_segments(self, lambda s: R.duration_cuts(s, max_dur, even_split, include_lock),
+                         lock=lock, newline=newline, skip_special_periods=isp)
+        self._log(f"sd={max_dur}+{int(even_split)}+{int(force_len)}+{int(lock)}+{int(include_lock)}+{int(newline)}"
+                  f"+{int(isp)}")
+        return self
+
+    def merge_by_gap(self, min_gap: float = 0.1, max_words: int = None, max_chars: int = None,
+                     is_sum_max: bool = False, lock: bool = False, newline: bool = False):
+        from . import regroup as R
+        R.merge_segments(self, R.gap_joins(self, min_gap), max_words=max_words, max_chars=max_chars,
+                         is_sum_max=is_sum_max, lock=lock, newline=newline)
+        self._log(f"mg={min_gap}+{max_words or ''}+{max_chars or ''}+{int(is_sum_max)}+{int(lock)}+{int(newline)}")
+        return self
+
+    def merge_by_punctuation(self, punctuation, max_words: int = None, max_chars: int = None,
+                             is_sum_max: bool = False, lock: bool = False, newline: bool = False):
+        from . import regroup as R
+        R.merge_segments(self, R.punctuation_joins(self, punctuation), max_words=max_words, max_chars=max_chars,
+                         is_sum_max=is_sum_max, lock=lock, newline=newline)
+        self._log(f"mp={R.punctuation_str(punctuation)}+{max_words or ''}+{max_chars or ''}+{int(is_sum_max)}"
+                  f"+{int(lock)}+{int(newline)}")
+        return self
+
+    def merge_all_segments(self, record: bool = True):
+        from . import regroup as R
+        R.merge_all(self)
+        if record and self.segments:
+            self._log("ms")
+        return self
+
+    def clamp_max(self, medium_factor: float = 2.5, max_dur: float = None, clip_start: Optional[bool] = None,
+                  verbose: bool = False):
+        from . import regroup as R
+        if not (medium_factor or max_dur):
+            raise ValueError("At least one of following arguments requires non-zero value: medium_factor; max_dur")
+        if not self.has_words:
+            warnings.warn("Cannot clamp due to missing/no word-timestamps")
+            return self
+        R.clamp_word_durations(self, medium_factor, max_dur, clip_start)
+        self._log(f"cm={medium_factor}+{max_dur or ''}+{clip_start or ''}+{int(verbose)}")
+        return self
+
+    def lock(self, startswith=None, endswith=None, right: bool = True, left: bool = False,
+             case_sensitive: bool = False, strip: bool = True):
+        from . import regroup as R
+        assert startswith is not None or endswith is not None, "Must specify [startswith] or/and [endswith]."
+        pre, suf = R.lock_matching(self, startswith, endswith, right, left, case_sensitive, strip)
+        self._log(f"l={'/'.join(pre)}+{'/'.join(suf)}+{int(right)}+{int(left)}+{int(case_sensitive)}+{int(strip)}")
+        return self
+
+    def unlock_all_segments(self):
+        for s in self.segments:
+            s.unlock_all_words()
+        return self
+
+    def pad(self, start_pad: Optional[float] = None, end_pad: Optional[float] = None, max_dur: Optional[float] = None,
+            max_end: Optional[float] = None, word_level: bool = False):
+        from . import regroup as R
+        if not (start_pad or end_pad):
+            warnings.warn("No ``start_pad`` or ``end_pad`` given.", stacklevel=2)
+            return self
+        word_level = bool(word_level and self.has_words)
+        R.pad_parts(self.all_words() if word_level else self.segments, start_pad, end_pad, max_dur, max_end)
+        self._log(f"p={start_pad or ''}+{end_pad or ''}+{max_dur or ''}+{max_end or ''}+{int(word_level)}")
+        return self
+
+    def convert_to_segment_level(self):
+        for s in self.segments:
+            s.convert_to_segment_level()
+        self._log("csl")
+        return self
+
+    def remove_word(self, word, reassign_ids: bool = True, verbose: bool = True, record: bool = True):
+        """result.py:2149-2194.  ``word`` is a WordTiming, a (segment, word) index pair or "seg,word"."""
+        if isinstance(word, WordTiming):
+            if self.segments[word.segment_id].words[word.id] is not word:
+                self.reassign_ids()
+                if self.segments[word.segment_id].words[word.id] is not word:
+                    raise ValueError("word not in result")
+            si, wi = word.segment_id, word.id
+        else:
+            si, wi = map(int, word.split(",")) if isinstance(word, str) else word
+        if verbose:
+            print(f"Removed: {self.segments[si].words[wi].to_dict()}")
+        del self.segments[si].words[wi]
+        if not reassign_ids:
+            return self
+        if self.segments[si].has_words:
+            self.segments[si].reassign_ids()
+        else:
+            self.remove_no_word_segments()
+        if record:
+            self._log(f"rw={si},{wi}+{int(reassign_ids)}+{int(verbose)}")
+        return self
+
+    def remove_segment(self, segment, reassign_ids: bool = True, verbose: bool = True, record: bool = True):
+        """result.py:2196-2236."""
+        if isinstance(segment, Segment):
+            if self.segments[segment.id] is not segment:
+                self.reassign_ids()
+                if self.segments[segment.id] is not segment:
+                    raise ValueError("segment not in result")
+            segment = segment.id
+        if verbose:
+            print(f"Removed: [id:{segment}] {self.segments[segment]!r}")
+        del self.segments[segment]
+        if not reassign_ids:
+            return self
+        self.reassign_ids(True, start=segment)
+        if record:
+            self._log(f"rs={segment}+{int(reassign_ids)}+{int(verbose)}")
+        return self
+
+    def regroup(self, regroup_algo: Union[str, bool, None] = None, verbose: bool = False, only_show: bool = False):
+        """result.py:2893-2978: run a regrouping program (``True``/``None`` = the default algorithm 'da')."""
+        from . import regroup as R
+        if regroup_algo is False:
+            return self
+        if regroup_algo is None or regroup_algo is True:
+            regroup_algo = "da"
+        for method, kwargs, shown in R.parse_regroup_algo(self, regroup_algo, include_str=verbose or only_show):
+            if shown:
+                print(shown)
+            if not only_show:
+                method(**kwargs)
+        return self
+
+    def parse_regroup_algo(self, regroup_algo: str, include_str: bool = True):
+        from . import regroup as R
+        return R.parse_regroup_algo(self, regroup_algo, include_str)

@@ -9,7 +9,7 @@ Two drivers share one per-batch routine:
   * sequential (default): identical control flow to the reference, one window per iteration;
   * ``batch_size=N`` (window-parallel): fixed 30-s stride, no prompt carry-over, N windows per GPU batch -- the mode
     SURVEY.md 8e describes for throughput / sharding; its oracle is "the reference run on each 30-s clip separately".
-Out of scope here: ffmpeg/yt-dlp audio I/O, denoisers, VAD models, resume, the regroup DSL.
+Out of scope here: ffmpeg/yt-dlp audio I/O, denoisers, VAD models, resume.
 """
 import warnings
 import wave
