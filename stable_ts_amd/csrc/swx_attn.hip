@@ -22,6 +22,14 @@
 
 namespace {
 
+// 16-byte global load; NT = streamed once (cross-attention K / V^T: 4.9 GB per decode step, never re-used in cache)
+template <bool NT>
+__device__ __forceinline__ f16x8 ldg8(const f16 *p)
+{
+    if constexpr (NT) return __builtin_nontemporal_load((const f16x8 *)p);
+    else return *(const f16x8 *)p;
+}
+
 constexpr int DH = 64;
 
 // ================================================================================================ flash f16
@@ -157,6 +165,7 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
 //   S^T[16 keys][16 q] = K-frag . Q^T        (K rows gathered so that a lane ends up holding 8 CONSECUTIVE keys)
 //   O^T[64 d][16 q]   += V^T-frag . P^T      (V^T rows are key-contiguous: 16-byte loads again)
 // 4 waves split the keys (32-key blocks, round-robin) with a private online softmax each and merge through LDS once.
+template <bool NT, bool QSLAB>
 __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 {
     __shared__ float sm_m[4][16], sm_l[4][16];
@@ -169,7 +178,30 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     const f16 *Vp = (const f16 *)a.v + (size_t)b * a.v_bs + (size_t)h * DH * a.vt_kp;
 
     f16x8 qf[2];
-    {
+    if constexpr (QSLAB) {
+        // q of this (window, head) finished here from the split-K partials of the query projection (same summation
+        // order and f16 rounding as splitk_finish_f16, so the result is bit-identical to the separate finish launch)
+        const SlabRef sr = a.qs;
+        const float *sp = sr.slabs + ((size_t)b * a.q_rows_per_batch + (qn < a.nq ? qn : 0)) * sr.N + h * DH + g * 8;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = 0; k < sr.ks2; ++k) {
+            const float *p = sp + (size_t)k * sr.stride;
+            const f32x4 v0 = *(const f32x4 *)(p), v1 = *(const f32x4 *)(p + 4), v2 = *(const f32x4 *)(p + 32), v3 = *(const f32x4 *)(p + 36);
+            acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3;
+        }
+        const float *bp = sr.bias + h * DH + g * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qf[0][e] = (f16)(acc[0][e] + bp[e]);
+            qf[0][4 + e] = (f16)(acc[1][e] + bp[4 + e]);
+            qf[1][e] = (f16)(acc[2][e] + bp[32 + e]);
+            qf[1][4 + e] = (f16)(acc[3][e] + bp[36 + e]);
+        }
+        if (qn >= a.nq) { qf[0] = (f16x8)(f16)0; qf[1] = (f16x8)(f16)0; }
+    } else {
         const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qn < a.nq ? qn : 0)) * a.ldq + h * DH + g * 8;
         qf[0] = (qn < a.nq) ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
         qf[1] = (qn < a.nq) ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
@@ -190,11 +222,11 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         for (int t = 0; t < 2; ++t) {
             const int key = k0 + krow + 4 * t;
             const f16 *kr = Kp + (size_t)(key < a.nk ? key : a.nk - 1) * a.ldkv + g * 8;   // clamped: loads are never predicated
-            kf[t][0] = *(const f16x8 *)(kr);              // rows past nk are masked to -inf below
-            kf[t][1] = *(const f16x8 *)(kr + 32);
+            kf[t][0] = ldg8<NT>(kr);                      // rows past nk are masked to -inf below
+            kf[t][1] = ldg8<NT>(kr + 32);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vf[t] = *(const f16x8 *)(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);
+        for (int t = 0; t < 4; ++t) vf[t] = ldg8<NT>(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);
 
         f32x4 s[2];
 #pragma unroll
@@ -433,6 +465,168 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
     }
 }
 
+// ------------------------------------------------------------------------------------------ fused decode step
+// One wave per (row, head) of a single-token decode step, f16.  Replaces THREE launches of the generic path (split-K
+// finish of the QKV projection, kv_append, self_attn_cached): the wave finishes its own 3 x 64 columns from the f32
+// partial slabs (same summation order / f16 rounding as splitk_finish_f16), appends the new K/V to the cache, and attends.
+// The dependent-load chain is 3 round trips instead of 5: {pos0} -> {ancestor ids, slabs} -> {K rows, V fragments} ->
+// math; the V fragments of the first 128 positions are requested together with the K rows (ancestor ids travel between
+// lanes by ds_bpermute).  Arithmetic order is the generic kernel's, so both paths agree bit for bit.
+__global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
+{
+    constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
+    __shared__ float qs[DH], kn[DH], vn[DH];
+    __shared__ float ps[512];
+    const int lane = threadIdx.x, h = blockIdx.x, r = blockIdx.y;
+    const int d = a.d;
+    const int pos = a.pos0[r];
+    const int32_t *anc = a.anc ? a.anc + (size_t)r * a.n_ctx : nullptr;
+    const f16 *kc = (const f16 *)a.kcache, *vc = (const f16 *)a.vcache;
+    const int j0 = lane, j1 = lane + 64;
+    const bool has0 = j0 < pos, has1 = j1 < pos;           // strictly older positions live in the cache
+    // ancestor ids: clamped unconditional loads + select (a predicated load would cost its own round trip)
+    const int32_t *ap = anc ? anc : a.pos0;
+    const int t0 = ap[(anc && has0) ? j0 : 0], t1 = ap[(anc && has1) ? j1 : 0];
+    const int pr0 = (anc && has0) ? t0 : r, pr1 = (anc && has1) ? t1 : r;
+    // ---- finish q | k | v of this head from the split-K partials
+    {
+        const SlabRef sr = a.qkvs;
+        const float *sp = sr.slabs + (size_t)r * sr.N + h * DH + lane;
+        float q = 0.f, k = 0.f, v = 0.f;
+#pragma unroll 4
+        for (int s = 0; s < sr.ks2; ++s) {
+            const float *p = sp + (size_t)s * sr.stride;
+            q += p[0]; k += p[d]; v += p[2 * d];
+        }
+        q += sr.bias[h * DH + lane]; k += sr.bias[d + h * DH + lane]; v += sr.bias[2 * d + h * DH + lane];
+        const f16 qh = (f16)q, kh = (f16)k, vh = (f16)v;
+        const size_t at = ((size_t)r * a.n_ctx + pos) * d + h * DH + lane;
+        ((f16 *)a.kcache)[at] = kh;
+        ((f16 *)a.vcache)[at] = vh;
+        qs[lane] = (float)qh; kn[lane] = (float)kh; vn[lane] = (float)vh;
+    }
+    // ---- K rows of positions lane, lane + 64 and the V fragments of positions < 128: one batch of loads
+    f16x8 k0[8], k1[8];
+    {
+        const f16 *kr0 = kc + ((size_t)(has0 ? pr0 : r) * a.n_ctx + (has0 ? j0 : 0)) * d + h * DH;   // clamped, never predicated
+#pragma unroll
+        for (int e = 0; e < 8; ++e) k0[e] = *(const f16x8 *)(kr0 + 8 * e);
+        if (pos > 64) {
+            const f16 *kr1 = kc + ((size_t)(has1 ? pr1 : r) * a.n_ctx + (has1 ? j1 : 0)) * d + h * DH;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) k1[e] = *(const f16x8 *)(kr1 + 8 * e);
+        }
+    }
+    const int kg = lane >> 3, dc = (lane & 7) * 8;
+    f16x8 vpre[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        if (i * 8 < pos) {                                  // uniform: some key of this group of 8 is in the cache
+            const int j = kg + 8 * i;
+            const int src = j & 63;
+            const int pa = __shfl(pr0, src, 64), pb = __shfl(pr1, src, 64);
+            const int prj = j < 64 ? pa : pb;
+            const bool ok = j < pos;
+            vpre[i] = *(const f16x8 *)(vc + ((size_t)(ok ? prj : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
+        }
+    }
+    __syncthreads();                                        // qs / kn / vn visible
+    // ---- scores (each lane owns whole keys; the new key comes from LDS)
+    auto dot_regs = [&](const f16x8 *kk) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[c * 8 + e], (float)kk[c][e], acc);
+        return acc;
+    };
+    auto dot_new = [&]() {
+        float acc = 0.f;
+        for (int e = 0; e < DH; ++e) acc = fmaf(qs[e], kn[e], acc);
+        return acc;
+    };
+    float mx = -__builtin_inff();
+    if (j0 <= pos) {
+        const float sc = (has0 ? dot_regs(k0) : dot_new()) * 0.125f;
+        ps[j0] = sc; mx = fmaxf(mx, sc);
+    }
+    if (pos >= 64 && j1 <= pos) {
+        const float sc = (has1 ? dot_regs(k1) : dot_new()) * 0.125f;
+        ps[j1] = sc; mx = fmaxf(mx, sc);
+    }
+    for (int j = lane + 128; j <= pos; j += 64) {
+        float acc;
+        if (j < pos) {
+            const int pr = anc ? anc[j] : r;
+            const f16 *kr = kc + ((size_t)pr * a.n_ctx + j) * d + h * DH;
+            acc = 0.f;
+#pragma unroll 2
+            for (int d0 = 0; d0 < DH; d0 += 8) {
+                float kv[8];
+                load8<f16>(kr + d0, kv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(qs[d0 + e], kv[e], acc);
+            }
+        } else {
+            acc = dot_new();
+        }
+        acc *= 0.125f;
+        ps[j] = acc; mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j <= pos; j += 64) { const float e = expf(ps[j] - mx); ps[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    // ---- P.V : lane = (key group kg, 8-wide d chunk dc); keys in ascending order per lane like the generic kernel
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int j = kg + 8 * i;
+        if (i * 8 <= pos && j <= pos) {
+            float vv[8];
+            if (j < pos) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = (float)vpre[i][e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[e] = vn[dc + e];
+            }
+            const float pj = ps[j] * inv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vv[e], acc[e]);
+        }
+    }
+    for (int j = kg + 8 * PF; j <= pos; j += 8) {
+        float vv[8];
+        if (j < pos) {
+            const int pr = anc ? anc[j] : r;
+            load8<f16>(vc + ((size_t)pr * a.n_ctx + j) * d + h * DH + dc, vv);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vv[e] = vn[dc + e];
+        }
+        const float pj = ps[j] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vv[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += __shfl_xor(acc[e], 8, 64);
+        acc[e] += __shfl_xor(acc[e], 16, 64);
+        acc[e] += __shfl_xor(acc[e], 32, 64);
+    }
+    if (kg == 0) {
+        f16 *op = (f16 *)a.o + (size_t)r * a.ldo + h * DH + dc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = (f16)acc[e];
+    }
+}
+
+
 // =============================================================================================== qk capture
 template <typename T>
 __global__ __launch_bounds__(256) void qk_capture_kernel(const T *__restrict__ q, int64_t ldq, int q_rows_per_w, int row0,
@@ -472,9 +666,16 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     const size_t esz = dtype == SWX_F16 ? 2 : 4;
     const bool dec = (dtype == SWX_F16) && a.vt_kp > 0 && a.nq <= 16 && a.nk >= 128 && (force_kernel == 3 || force_kernel == 0);
     if (force_kernel == 3 && !dec) return -5;
+    if (a.qs.slabs && !dec) return -5;         // only the decode kernel finishes q from slabs
     if (dec) {
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
-        hipLaunchKernelGGL(attn_decode_cross_f16, dim3(a.H, a.B), dim3(256), 0, s, a);
+        const bool nt = (swx_flags() & SWX_FLAG_NT_XKV) != 0, qsl = a.qs.slabs != nullptr;
+        if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias)) return -5;
+        dim3 gd(a.H, a.B);
+        if (nt && qsl) hipLaunchKernelGGL((attn_decode_cross_f16<true, true>), gd, dim3(256), 0, s, a);
+        else if (nt) hipLaunchKernelGGL((attn_decode_cross_f16<true, false>), gd, dim3(256), 0, s, a);
+        else if (qsl) hipLaunchKernelGGL((attn_decode_cross_f16<false, true>), gd, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_decode_cross_f16<false, false>), gd, dim3(256), 0, s, a);
     } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
@@ -498,6 +699,12 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
     if (a.R <= 0 || a.n_new <= 0) return 0;
     if (a.n_ctx > 512) return -5;
     SwxProfScope prof(PC_SELF_ATTN, 0.0, s);
+    if (a.qkvs.slabs) {
+        if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.qkvs.bias || a.qkvs.N != 3 * a.d) return -5;
+        hipLaunchKernelGGL(self_attn_fused_f16, dim3(a.H, a.R), dim3(64), 0, s, a);
+        SWX_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 g1(a.n_new, a.R);
     dim3 g2(a.n_new, a.H, a.R);
     if (dtype == SWX_F16) {

@@ -333,9 +333,9 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
 // shared by the four waves (4x fewer, 2x wider L2 requests), while every wave streams its own weight fragments of the
 // whole slice from HBM up front.  Partial sums go to f32 slabs (deterministic split-K), finished by splitk_finish_f16.
 constexpr int PG_LD = 72;        // halfs per LDS row
-constexpr int PG_MAXIT = 5;      // 64-wide K chunks per workgroup slice
-template <int MT>
-__global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int64_t slab_stride, int ks2)
+constexpr int PG_MAXIT = 10;     // 64-wide K chunks per workgroup slice, upper bound (launcher picks the <= 5 or <= 10 build)
+template <int MT, int MAXIT>
+__global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int64_t slab_stride, int ks2, int flags)
 {
     __shared__ __attribute__((aligned(16))) f16 As[2][MT * 16][PG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,9 +350,16 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
     const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
     const f16x8 zero8 = (f16x8)(f16)0;
 
-    f16x8 wf[2 * PG_MAXIT];
+    // the weights are read exactly once per decode step (1.6 GB per step >> MALL): optionally streamed non-temporally
+    f16x8 wf[2 * MAXIT];
+    if (flags & SWX_FLAG_NT_WEIGHTS) {
 #pragma unroll
-    for (int ks = 0; ks < 2 * PG_MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
+        for (int ks = 0; ks < 2 * MAXIT; ++ks)
+            wf[ks] = (nok && ks < 2 * nit) ? __builtin_nontemporal_load((const f16x8 *)(wp + ks * 32)) : zero8;
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 2 * MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
+    }
 
     f32x4 acc[MT];
 #pragma unroll
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
     store_a(0);
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < PG_MAXIT; ++it) {
+    for (int it = 0; it < MAXIT; ++it) {
         if (it < nit) {
             const int cur = it & 1;
             if (it + 1 < nit) load_a(it + 1);
@@ -397,13 +404,25 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
     float *out = slabs + (size_t)blockIdx.y * slab_stride;
     const int col = blockIdx.x * 64 + wave * 16 + (lane & 15), row_l = (lane >> 4) * 4;
     if (col < g.N) {
+        if (flags & SWX_FLAG_SC1_SLABS) {
+            // write-through: the partials reach memory while the kernel runs instead of as one dirty-L2 write-back at
+            // the kernel boundary (MI355X_MICROARCH.md "boundary" / "publish-large" rows)
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = t * 16 + row_l + r;
-                if (row < g.M) out[(size_t)row * g.N + col] = acc[t][r];
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int row = t * 16 + row_l + r;
+                    if (row < g.M) __hip_atomic_store(&out[(size_t)row * g.N + col], acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        } else {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = t * 16 + row_l + r;
+                    if (row < g.M) out[(size_t)row * g.N + col] = acc[t][r];
+                }
+        }
     }
 }
 
@@ -525,30 +544,46 @@ size_t swx_skinny_slab_floats(int M, int N, int K)
     return (size_t)(a > b ? a : b) * M * N;
 }
 
-int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
-                           const FinishArgs &f, hipStream_t s)
+int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
+                hipStream_t s)
 {
-    if (M <= 0 || N <= 0) return 0;
+    if (M <= 0 || N <= 0) return -4;
     if (M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC || lda % 8 != 0 || ldw % 8 != 0) return -4;
     const int ks2 = pg_ks2(N, K);
     if (ks2 <= 0) return -4;
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = EPI_OUT_F32; g.res_mod = 1;
     const int64_t stride = (int64_t)M * N;
+    const int flags = swx_flags();
     dim3 grid(cdiv(N, 64), ks2);
-    {
-        SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)N * K + (double)M * K) + (double)M * N * 2, s);
-        switch (cdiv(M, 16)) {
-            case 1: hipLaunchKernelGGL(gemm_f16_pg<1>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 2: hipLaunchKernelGGL(gemm_f16_pg<2>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 3: hipLaunchKernelGGL(gemm_f16_pg<3>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 4: hipLaunchKernelGGL(gemm_f16_pg<4>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 5: hipLaunchKernelGGL(gemm_f16_pg<5>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 6: hipLaunchKernelGGL(gemm_f16_pg<6>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            case 7: hipLaunchKernelGGL(gemm_f16_pg<7>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-            default: hipLaunchKernelGGL(gemm_f16_pg<8>, grid, dim3(256), 0, s, g, slabs, stride, ks2); break;
-        }
+    SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)N * K + (double)M * K) + (double)M * N * 2, s);
+    const bool deep = K / (64 * ks2) > 5;     // K slice per workgroup in 64-wide chunks: <= 5 (default tuning) or <= 10
+#define SWX_PG(MT) do { if (deep) hipLaunchKernelGGL((gemm_f16_pg<MT, 10>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
+                        else hipLaunchKernelGGL((gemm_f16_pg<MT, 5>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); } while (0)
+    switch (cdiv(M, 16)) {
+        case 1: SWX_PG(1); break;
+        case 2: SWX_PG(2); break;
+        case 3: SWX_PG(3); break;
+        case 4: SWX_PG(4); break;
+        case 5: SWX_PG(5); break;
+        case 6: SWX_PG(6); break;
+        case 7: SWX_PG(7); break;
+        default: SWX_PG(8); break;
     }
+#undef SWX_PG
+    if (ref) { ref->slabs = slabs; ref->ks2 = ks2; ref->stride = stride; ref->N = N; ref->bias = nullptr; }
+    return 0;
+}
+
+int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
+                           const FinishArgs &f, hipStream_t s)
+{
+    if (M <= 0 || N <= 0) return 0;
+    SlabRef ref{};
+    const int rc = swx_gemm_pg(A, lda, W, ldw, M, N, K, slabs, &ref, s);
+    if (rc < 0) return rc;
+    const int ks2 = ref.ks2;
+    const int64_t stride = ref.stride;
     {
         SwxProfScope prof(PC_NORM, (double)ks2 * M * N * 4 + 4.0 * M * N, s);
         const int nc = cdiv(N, 256);

@@ -25,6 +25,18 @@ struct GemmArgs {
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 
+// ---- run-time experiment switches (swx_debug_flags(); initial value from the environment variable SWX_FLAGS)
+#define SWX_FLAG_NO_FAST_STEP 1     // decode steps go through the generic per-op path (A/B reference for the fused step)
+#define SWX_FLAG_NT_WEIGHTS 2       // decode-step GEMM: non-temporal loads for the streamed weights (each read once per step)
+#define SWX_FLAG_SC1_SLABS 4        // decode-step GEMM: write-through (agent-scope) stores for the split-K partial slabs
+#define SWX_FLAG_NT_XKV 8           // decode cross-attention: non-temporal loads for K / V^T
+#define SWX_FLAG_FUSE_ATTN_Q 16     // self-/cross-attention read q (k, v) straight from the split-K slabs (no finish launch)
+int swx_flags();
+
+// split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:
+// value[row][col] = bias[col] + sum_{k < ks2} slabs[k * stride + row * N + col]
+struct SlabRef { const float *slabs; int ks2; int64_t stride; int N; const float *bias; };
+
 // ---- decode-step GEMM = split-K weight streaming into f32 slabs + a finish kernel that reduces the slabs and applies
 //      bias / GELU / residual, optionally fused with the NEXT LayerNorm and with the scatter of new K/V into the cache
 struct FinishArgs {
@@ -38,6 +50,9 @@ struct FinishArgs {
 size_t swx_skinny_slab_floats(int M, int N, int K);
 int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
                            const FinishArgs &f, hipStream_t s);
+// the weight-streaming half alone: leaves the partial sums in `slabs` and describes them in *ref (bias is the caller's)
+int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
+                hipStream_t s);
 
 // ---- in-library kernel timing (HIP events on the launch stream), used by bench.py for the roofline object
 enum SwxProfClass { PC_GEMM_TILED = 0, PC_GEMM_SKINNY = 1, PC_ATTN_FLASH = 2, PC_ATTN_ROWWISE = 3, PC_SELF_ATTN = 4,
@@ -75,6 +90,7 @@ struct AttnArgs {
     void *o; int64_t ldo;
     int B, H, nq, nk;
     int q_rows_per_batch;            // rows of q per batch item (== nq unless grouped)
+    SlabRef qs;                      // qs.slabs != null: q = f16(bias + sum of slabs) instead of a.q (decode cross-attention only)
 };
 #define SWX_VT_KP 1536               // padded key count of the transposed cross-attention V (64-key tiles never run off a row)
 // dense (non-causal) attention over nk keys: encoder self-attention and cross-attention
@@ -88,6 +104,8 @@ struct SelfAttnArgs {
     void *o; int64_t ldo;            // [R*n_new][d]
     int R, n_new, H, n_ctx, d;
     int skip_append;                 // K/V of the new token were already scattered into the cache (split-K finish kernel)
+    SlabRef qkvs;                    // qkvs.slabs != null (n_new == 1, f16): q|k|v of the new token come from the split-K slabs;
+                                     // the kernel finishes them, appends k/v to the cache and attends in ONE launch
 };
 // logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
 #include "swx_common.h"
 #include "swx_kernels.h"
 #include "swx_decode.h"
@@ -244,7 +245,9 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 // ---------------------------------------------------------------------------------------------- profiler
 struct ProfRec { int cls; double work; hipEvent_t a, b; };
 bool g_prof_enabled = false;
-int g_debug_flags = 0;          // bit 0: disable the fused fast decode step (A/B testing)
+// experiment switches (SWX_FLAG_* in swx_kernels.h); the environment variable SWX_FLAGS overrides the built-in default
+#define SWX_DEFAULT_FLAGS 0
+int g_debug_flags = [] { const char *e = getenv("SWX_FLAGS"); return e ? atoi(e) : SWX_DEFAULT_FLAGS; }();
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -315,16 +318,23 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
                       m->A<float>(m->o_dec_pos), d, x, s));
     SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->dec[0].ln1_g), m->A<float>(m->dec[0].ln1_b), h, d, rows, d, s));
     const int64_t chunk = xkv_chunk_elems(D);
+    // cross-attention rows of a window are its f.rpw consecutive rows: q row (b, qn) = b * rpw + qn, as the slabs are laid out
+    const bool fuse_q = (g_debug_flags & SWX_FLAG_FUSE_ATTN_Q) && f.rpw <= 16 && D.n_audio_ctx >= 128;
     for (int l = 0; l < D.n_text_layer; ++l) {
         const LayerW &w = m->dec[l];
         unsigned char *kc = f.kcache + (size_t)l * f.layer_stride, *vc = f.vcache + (size_t)l * f.layer_stride;
         FinishArgs fq{};
         fq.bias = m->A<float>(w.bqkv); fq.epi = EPI_BIAS; fq.C = qkv; fq.ldc = 3 * d;
         fq.kcache = kc; fq.vcache = vc; fq.pos0 = f.pos0; fq.n_ctx = D.n_text_ctx; fq.d = d;
-        SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wqkv, d, rows, 3 * d, d, slabs, fq, s));
         SelfAttnArgs sa{};
         sa.qkv = qkv; sa.ldqkv = 3 * d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
+        if (fuse_q) {       // the attention kernel finishes q|k|v from the partial slabs itself (no finish launch)
+            SWX_TRY(swx_gemm_pg(h, d, m->arena + w.wqkv, d, rows, 3 * d, d, slabs, &sa.qkvs, s));
+            sa.qkvs.bias = fq.bias;
+        } else {
+            SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wqkv, d, rows, 3 * d, d, slabs, fq, s));
+        }
         SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
         FinishArgs fo{};
         fo.bias = m->A<float>(w.bo); fo.epi = EPI_BIAS | EPI_RES; fo.R = x; fo.ldr = d; fo.C = x; fo.ldc = d;
@@ -332,9 +342,14 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
         SWX_TRY(swx_gemm_skinny_splitk(att, d, m->arena + w.wo, d, rows, d, d, slabs, fo, s));
         FinishArgs fc{};
         fc.bias = m->A<float>(w.bcq); fc.epi = EPI_BIAS; fc.C = qkv; fc.ldc = d;
-        SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wcq, d, rows, d, d, slabs, fc, s));
         const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
         AttnArgs ca{};
+        if (fuse_q) {
+            SWX_TRY(swx_gemm_pg(h, d, m->arena + w.wcq, d, rows, d, d, slabs, &ca.qs, s));
+            ca.qs.bias = fc.bias;
+        } else {
+            SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wcq, d, rows, d, d, slabs, fc, s));
+        }
         ca.q = qkv; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
         ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
         ca.B = f.W; ca.H = H; ca.nq = f.rpw; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw;
@@ -359,7 +374,7 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
 
 int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
-    if (!(g_debug_flags & 1) && m->dtype == SWX_F16 && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.W * f.rpw <= 128 &&
+    if (!(g_debug_flags & SWX_FLAG_NO_FAST_STEP) && m->dtype == SWX_F16 && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.W * f.rpw <= 128 &&
         m->dims.n_text_state % 128 == 0 && swx_skinny_slab_floats(f.W * f.rpw, 3 * m->dims.n_text_state, m->dims.n_text_state) > 0)
         return decoder_step_fast(m, f, s);
     const swx_dims &D = m->dims;
@@ -456,6 +471,7 @@ __global__ void score_targets_kernel(const int32_t *__restrict__ tokens, int max
 }  // namespace
 
 bool swx_prof_on() { return g_prof_enabled; }
+int swx_flags() { return g_debug_flags; }
 void swx_prof_begin(int cls, double work, hipStream_t s)
 {
     ProfRec r{cls, work, prof_event(), prof_event()};

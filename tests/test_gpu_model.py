@@ -238,6 +238,38 @@ def test_decode_f16_fast_step_equals_general_path(name, beam):
     assert np.allclose(fast["no_speech_prob"], slow["no_speech_prob"], rtol=2e-2, atol=1e-6)
 
 
+@pytest.mark.parametrize("name,beam", [("tiny.en", False), ("base.en", True)])
+@pytest.mark.parametrize("flags", [16, 2 | 4 | 8, 2 | 4 | 8 | 16])
+def test_decode_f16_step_switches_are_bit_identical(name, beam, flags):
+    # SWX_FLAG_* experiment switches of the fused decode step: non-temporal weight / cross-KV loads (2, 8), write-through
+    # partial slabs (4) and attention kernels that finish q|k|v from the split-K slabs themselves (16).  None of them
+    # changes the arithmetic or its order, so tokens and sums of log-probabilities must be IDENTICAL to the default step.
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 83, B=3)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=40,
+                                                     beam_size=5 if beam else None))
+    kw = dict(n_group=task.n_group, beam=beam, sample_len=40, sot_index=task.sot_index, min_tokens=40,
+              **_tok_cfg(task.tokenizer, task))
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    old = lib.swx_debug_flags(0)
+    try:
+        base = eng.decode(xkv, [list(task.initial_tokens)] * 3, **kw)
+        lib.swx_debug_flags(flags)
+        alt = eng.decode(xkv, [list(task.initial_tokens)] * 3, **kw)
+    finally:
+        lib.swx_debug_flags(old)
+    assert np.array_equal(np.asarray(base["lens"]), np.asarray(alt["lens"]))
+    sb = base["sample_begin"]
+    for w in range(base["tokens"].shape[0]):
+        for g in range(base["tokens"].shape[1]):
+            n = sb + int(base["lens"][w, g])
+            assert base["tokens"][w, g, :n].tolist() == alt["tokens"][w, g, :n].tolist(), (w, g)
+    assert np.array_equal(np.asarray(base["sum_logprobs"]), np.asarray(alt["sum_logprobs"]))
+    assert np.array_equal(np.asarray(base["no_speech_prob"]), np.asarray(alt["no_speech_prob"]))
+
+
 @pytest.mark.parametrize("name,heads", [("tiny.en", HEADS_TINY), ("base.en", None)])
 def test_score_alignment_dtw_strict(name, heads):
     m, eng = _oracle(name, heads=heads), _engine(name, "f32", heads=heads)
