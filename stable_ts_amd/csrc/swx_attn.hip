@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
 //   S^T[16 keys][16 q] = K-frag . Q^T        (K rows gathered so that a lane ends up holding 8 CONSECUTIVE keys)
 //   O^T[64 d][16 q]   += V^T-frag . P^T      (V^T rows are key-contiguous: 16-byte loads again)
 // 4 waves split the keys (32-key blocks, round-robin) with a private online softmax each and merge through LDS once.
-template <bool NT, bool QSLAB>
+template <bool NT, bool QSLAB, bool PIPE>
 __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 {
     __shared__ float sm_m[4][16], sm_l[4][16];
@@ -214,26 +214,29 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     // A-row i of S^T tile t  <->  key k0 + (i>>2)*8 + (i&3) + 4t, so that lane (q, g) owns keys k0 + g*8 + 0..7
     const int krow = (qn >> 2) * 8 + (qn & 3);
 
-#pragma unroll 2
-    for (int cb = wave; cb < nblk; cb += 4) {
-        const int k0 = cb << 5;
-        f16x8 kf[2][2], vf[4];
+    // Key blocks are double-buffered in registers by hand: the K / V^T fragments of this wave's NEXT block are requested
+    // before the current block's MFMAs and softmax, so 16 KB per wave stay in flight and the loop never drains to
+    // vmcnt(0) (the plain loop compiled to load -> wait -> compute per block: two exposed round trips per 32 keys).
+    auto load_blk = [&](int cb, f16x8 (&kf)[4], f16x8 (&vf)[4]) {
+        const int k0 = (cb < nblk ? cb : nblk - 1) << 5;    // tail prefetch re-reads the last block: loads are never predicated
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int key = k0 + krow + 4 * t;
-            const f16 *kr = Kp + (size_t)(key < a.nk ? key : a.nk - 1) * a.ldkv + g * 8;   // clamped: loads are never predicated
-            kf[t][0] = ldg8<NT>(kr);                      // rows past nk are masked to -inf below
-            kf[t][1] = ldg8<NT>(kr + 32);
+            const f16 *kr = Kp + (size_t)(key < a.nk ? key : a.nk - 1) * a.ldkv + g * 8;   // rows past nk are masked to -inf below
+            kf[2 * t] = ldg8<NT>(kr);
+            kf[2 * t + 1] = ldg8<NT>(kr + 32);
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) vf[t] = ldg8<NT>(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);
-
+    };
+    auto compute_blk = [&](int cb, const f16x8 (&kf)[4], const f16x8 (&vf)[4]) {
+        const int k0 = cb << 5;
         f32x4 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][0], qf[0], s[t], 0, 0, 0);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][1], qf[1], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * t], qf[0], s[t], 0, 0, 0);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * t + 1], qf[1], s[t], 0, 0, 0);
         }
         float tmax = -__builtin_inff();
 #pragma unroll
@@ -267,6 +270,28 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         for (int t = 0; t < 4; ++t) {
             o[t][0] *= alpha; o[t][1] *= alpha; o[t][2] *= alpha; o[t][3] *= alpha;
             o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t], pb, o[t], 0, 0, 0);
+        }
+    };
+    if constexpr (PIPE) {
+        // straight-line pair body (no exit between the two halves, or the optimizer sinks the prefetch below the first
+        // compute).  The second block of the last pair may lie past nblk: its keys are all masked, which leaves
+        // (m_run, l_run, o) unchanged exactly (alpha = 1, p = 0), so the result is bit-identical to the plain loop.
+        f16x8 kA[4], vA[4], kB[4], vB[4];
+        load_blk(wave, kA, vA);
+        for (int cb = wave; cb < nblk; cb += 8) {           // nblk >= 4: every wave owns at least one block
+            load_blk(cb + 4, kB, vB);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_blk(cb, kA, vA);
+            load_blk(cb + 8, kA, vA);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_blk(cb + 4, kB, vB);
+        }
+    } else {
+#pragma unroll 2
+        for (int cb = wave; cb < nblk; cb += 4) {
+            f16x8 kf[4], vf[4];
+            load_blk(cb, kf, vf);
+            compute_blk(cb, kf, vf);
         }
     }
 
@@ -669,13 +694,15 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     if (a.qs.slabs && !dec) return -5;         // only the decode kernel finishes q from slabs
     if (dec) {
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
-        const bool nt = (swx_flags() & SWX_FLAG_NT_XKV) != 0, qsl = a.qs.slabs != nullptr;
+        const int fl = swx_flags();
+        const bool nt = (fl & SWX_FLAG_NT_XKV) != 0, qsl = a.qs.slabs != nullptr, pipe = (fl & SWX_FLAG_XATTN_PIPE) != 0;
         if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias)) return -5;
         dim3 gd(a.H, a.B);
-        if (nt && qsl) hipLaunchKernelGGL((attn_decode_cross_f16<true, true>), gd, dim3(256), 0, s, a);
-        else if (nt) hipLaunchKernelGGL((attn_decode_cross_f16<true, false>), gd, dim3(256), 0, s, a);
-        else if (qsl) hipLaunchKernelGGL((attn_decode_cross_f16<false, true>), gd, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((attn_decode_cross_f16<false, false>), gd, dim3(256), 0, s, a);
+#define SWX_XA(NT_, QS_, PP_) hipLaunchKernelGGL((attn_decode_cross_f16<NT_, QS_, PP_>), gd, dim3(256), 0, s, a)
+        if (nt) { if (qsl) SWX_XA(true, true, false); else SWX_XA(true, false, false); }        // nt: measured slower, kept for A/B
+        else if (pipe) { if (qsl) SWX_XA(false, true, true); else SWX_XA(false, false, true); }
+        else { if (qsl) SWX_XA(false, true, false); else SWX_XA(false, false, false); }
+#undef SWX_XA
     } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);

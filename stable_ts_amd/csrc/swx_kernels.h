@@ -31,6 +31,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_SC1_SLABS 4        // decode-step GEMM: write-through (agent-scope) stores for the split-K partial slabs
 #define SWX_FLAG_NT_XKV 8           // decode cross-attention: non-temporal loads for K / V^T
 #define SWX_FLAG_FUSE_ATTN_Q 16     // self-/cross-attention read q (k, v) straight from the split-K slabs (no finish launch)
+#define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
 int swx_flags();
 
 // split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:

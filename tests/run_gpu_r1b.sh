@@ -3,6 +3,5 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( timeout 240 python -m pytest tests/test_gpu_model.py tests/test_gpu_kernels.py -m gpu -q -n 4 --timeout=200 -k "switches or fast_step or gemm or attention or attn" 2>&1 | tail -12 ) > gpurun_out/switch_tests.log
-( timeout 150 python tests/tune_flags.py --flags 0,2,4,8,16,30 2>&1 | grep -v "^\[" | tail -12 ) > gpurun_out/tune_flags.log
-( SWX_PG_BLOCKS=160 timeout 100 python tests/tune_flags.py --flags 0,30 2>&1 | tail -3 ) > gpurun_out/tune_flags_160.log
-tail -12 gpurun_out/switch_tests.log; cat gpurun_out/tune_flags.log gpurun_out/tune_flags_160.log
+( timeout 150 python tests/tune_flags.py --flags 0,20,32,52,0,52 2>&1 | grep -v "^\[" | tail -12 ) > gpurun_out/tune_flags.log
+tail -12 gpurun_out/switch_tests.log; cat gpurun_out/tune_flags.log
