@@ -22,13 +22,6 @@
 
 namespace {
 
-// 16-byte global load; NT = streamed once (cross-attention K / V^T: 4.9 GB per decode step, never re-used in cache)
-template <bool NT>
-__device__ __forceinline__ f16x8 ldg8(const f16 *p)
-{
-    if constexpr (NT) return __builtin_nontemporal_load((const f16x8 *)p);
-    else return *(const f16x8 *)p;
-}
 
 constexpr int DH = 64;
 
@@ -165,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
 //   S^T[16 keys][16 q] = K-frag . Q^T        (K rows gathered so that a lane ends up holding 8 CONSECUTIVE keys)
 //   O^T[64 d][16 q]   += V^T-frag . P^T      (V^T rows are key-contiguous: 16-byte loads again)
 // 4 waves split the keys (32-key blocks, round-robin) with a private online softmax each and merge through LDS once.
-template <bool NT, bool QSLAB, bool PIPE>
+template <bool QSLAB, bool PIPE>
 __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 {
     __shared__ float sm_m[4][16], sm_l[4][16];
@@ -223,11 +216,11 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         for (int t = 0; t < 2; ++t) {
             const int key = k0 + krow + 4 * t;
             const f16 *kr = Kp + (size_t)(key < a.nk ? key : a.nk - 1) * a.ldkv + g * 8;   // rows past nk are masked to -inf below
-            kf[2 * t] = ldg8<NT>(kr);
-            kf[2 * t + 1] = ldg8<NT>(kr + 32);
+            kf[2 * t] = *(const f16x8 *)(kr);
+            kf[2 * t + 1] = *(const f16x8 *)(kr + 32);
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vf[t] = ldg8<NT>(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);
+        for (int t = 0; t < 4; ++t) vf[t] = *(const f16x8 *)(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);
     };
     auto compute_blk = [&](int cb, const f16x8 (&kf)[4], const f16x8 (&vf)[4]) {
         const int k0 = cb << 5;
@@ -694,14 +687,12 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     if (a.qs.slabs && !dec) return -5;         // only the decode kernel finishes q from slabs
     if (dec) {
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
-        const int fl = swx_flags();
-        const bool nt = (fl & SWX_FLAG_NT_XKV) != 0, qsl = a.qs.slabs != nullptr, pipe = (fl & SWX_FLAG_XATTN_PIPE) != 0;
+        const bool qsl = a.qs.slabs != nullptr, pipe = (swx_flags() & SWX_FLAG_XATTN_PIPE) != 0;
         if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias)) return -5;
         dim3 gd(a.H, a.B);
-#define SWX_XA(NT_, QS_, PP_) hipLaunchKernelGGL((attn_decode_cross_f16<NT_, QS_, PP_>), gd, dim3(256), 0, s, a)
-        if (nt) { if (qsl) SWX_XA(true, true, false); else SWX_XA(true, false, false); }        // nt: measured slower, kept for A/B
-        else if (pipe) { if (qsl) SWX_XA(false, true, true); else SWX_XA(false, false, true); }
-        else { if (qsl) SWX_XA(false, true, false); else SWX_XA(false, false, false); }
+#define SWX_XA(QS_, PP_) hipLaunchKernelGGL((attn_decode_cross_f16<QS_, PP_>), gd, dim3(256), 0, s, a)
+        if (pipe) { if (qsl) SWX_XA(true, true); else SWX_XA(false, true); }
+        else { if (qsl) SWX_XA(true, false); else SWX_XA(false, false); }
 #undef SWX_XA
     } else if (flash) {
         if (dtype != SWX_F16) return -5;

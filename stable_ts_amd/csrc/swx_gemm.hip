@@ -350,16 +350,9 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
     const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
     const f16x8 zero8 = (f16x8)(f16)0;
 
-    // the weights are read exactly once per decode step (1.6 GB per step >> MALL): optionally streamed non-temporally
     f16x8 wf[2 * MAXIT];
-    if (flags & SWX_FLAG_NT_WEIGHTS) {
 #pragma unroll
-        for (int ks = 0; ks < 2 * MAXIT; ++ks)
-            wf[ks] = (nok && ks < 2 * nit) ? __builtin_nontemporal_load((const f16x8 *)(wp + ks * 32)) : zero8;
-    } else {
-#pragma unroll
-        for (int ks = 0; ks < 2 * MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
-    }
+    for (int ks = 0; ks < 2 * MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
 
     f32x4 acc[MT];
 #pragma unroll

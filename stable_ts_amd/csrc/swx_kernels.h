@@ -25,13 +25,16 @@ struct GemmArgs {
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 
-// ---- run-time experiment switches (swx_debug_flags(); initial value from the environment variable SWX_FLAGS)
+// ---- run-time switches of the decode step (swx_debug_flags(); initial value: SWX_DEFAULT_FLAGS, or the environment
+//      variable SWX_FLAGS).  Every switch is arithmetic-neutral: results are bit-identical with it on or off (tested).
+//      Measured on MI355X, large-v3, 20 windows x beam 5 (profiles/README.md): 4 -> -2.8 %, 16 -> -4.0 %, 4|16 -> -7.3 %
+//      of the pass time; 32 -> +0.7 % (kept as an opt-in); non-temporal weight / cross-KV loads were +1.2 % / +4.7 %
+//      slower and were removed again.
 #define SWX_FLAG_NO_FAST_STEP 1     // decode steps go through the generic per-op path (A/B reference for the fused step)
-#define SWX_FLAG_NT_WEIGHTS 2       // decode-step GEMM: non-temporal loads for the streamed weights (each read once per step)
 #define SWX_FLAG_SC1_SLABS 4        // decode-step GEMM: write-through (agent-scope) stores for the split-K partial slabs
-#define SWX_FLAG_NT_XKV 8           // decode cross-attention: non-temporal loads for K / V^T
 #define SWX_FLAG_FUSE_ATTN_Q 16     // self-/cross-attention read q (k, v) straight from the split-K slabs (no finish launch)
 #define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
+#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_ATTN_Q)
 int swx_flags();
 
 // split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:

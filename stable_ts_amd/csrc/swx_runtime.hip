@@ -245,8 +245,7 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 // ---------------------------------------------------------------------------------------------- profiler
 struct ProfRec { int cls; double work; hipEvent_t a, b; };
 bool g_prof_enabled = false;
-// experiment switches (SWX_FLAG_* in swx_kernels.h); the environment variable SWX_FLAGS overrides the built-in default
-#define SWX_DEFAULT_FLAGS 0
+// decode-step switches (SWX_FLAG_* in swx_kernels.h); the environment variable SWX_FLAGS overrides the built-in default
 int g_debug_flags = [] { const char *e = getenv("SWX_FLAGS"); return e ? atoi(e) : SWX_DEFAULT_FLAGS; }();
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_pool;
