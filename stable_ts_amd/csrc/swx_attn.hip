@@ -22,6 +22,8 @@
 
 namespace {
 
+constexpr int SLAB_KMAX = 16;   // most split-K slabs a fused consumer (SlabRef) can finish; the launchers check ks2 <= SLAB_KMAX
+
 
 constexpr int DH = 64;
 
@@ -170,35 +172,6 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     const f16 *Kp = (const f16 *)a.k + (size_t)b * a.k_bs + h * DH;
     const f16 *Vp = (const f16 *)a.v + (size_t)b * a.v_bs + (size_t)h * DH * a.vt_kp;
 
-    f16x8 qf[2];
-    if constexpr (QSLAB) {
-        // q of this (window, head) finished here from the split-K partials of the query projection (same summation
-        // order and f16 rounding as splitk_finish_f16, so the result is bit-identical to the separate finish launch)
-        const SlabRef sr = a.qs;
-        const float *sp = sr.slabs + ((size_t)b * a.q_rows_per_batch + (qn < a.nq ? qn : 0)) * sr.N + h * DH + g * 8;
-        f32x4 acc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int k = 0; k < sr.ks2; ++k) {
-            const float *p = sp + (size_t)k * sr.stride;
-            const f32x4 v0 = *(const f32x4 *)(p), v1 = *(const f32x4 *)(p + 4), v2 = *(const f32x4 *)(p + 32), v3 = *(const f32x4 *)(p + 36);
-            acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3;
-        }
-        const float *bp = sr.bias + h * DH + g * 8;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            qf[0][e] = (f16)(acc[0][e] + bp[e]);
-            qf[0][4 + e] = (f16)(acc[1][e] + bp[4 + e]);
-            qf[1][e] = (f16)(acc[2][e] + bp[32 + e]);
-            qf[1][4 + e] = (f16)(acc[3][e] + bp[36 + e]);
-        }
-        if (qn >= a.nq) { qf[0] = (f16x8)(f16)0; qf[1] = (f16x8)(f16)0; }
-    } else {
-        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qn < a.nq ? qn : 0)) * a.ldq + h * DH + g * 8;
-        qf[0] = (qn < a.nq) ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
-        qf[1] = (qn < a.nq) ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
-    }
     f32x4 o[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -222,6 +195,45 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 #pragma unroll
         for (int t = 0; t < 4; ++t) vf[t] = *(const f16x8 *)(Vp + (size_t)(t * 16 + qn) * a.vt_kp + k0 + g * 8);
     };
+    // the first key block of this wave is requested before q is assembled, so its latency overlaps the q loads
+    f16x8 kA[4], vA[4];
+    load_blk(wave, kA, vA);
+
+    f16x8 qf[2];
+    if constexpr (QSLAB) {
+        // q of this (window, head) is finished here from the split-K partials of the query projection: wave 0 sums the
+        // slabs (same summation order and f16 rounding as splitk_finish_f16 -> bit-identical to the separate finish
+        // launch), parks the 16 x 64 tile in LDS, and every wave picks its MFMA fragments from there.
+        __shared__ __attribute__((aligned(16))) f16 qsh[16][DH + 8];
+        {
+            const SlabRef sr = a.qs;
+            const int row = tid >> 4, c0 = (tid & 15) * 4;          // 16 rows x 16 float4 columns = the 256 lanes
+            const bool rok = row < a.nq;
+            const float *sp = sr.slabs + ((size_t)b * a.q_rows_per_batch + (rok ? row : 0)) * sr.N + h * DH + c0;
+            // every slab load is issued before the first add (a rolled loop compiles to one round trip PER slab);
+            // slots past ks2 re-read the last slab (clamped, never predicated) and are skipped in the sum
+            f32x4 part[SLAB_KMAX];
+#pragma unroll
+            for (int k = 0; k < SLAB_KMAX; ++k) part[k] = *(const f32x4 *)(sp + (size_t)(k < sr.ks2 ? k : sr.ks2 - 1) * sr.stride);
+            const f32x4 bias = *(const f32x4 *)(sr.bias + h * DH + c0);
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < SLAB_KMAX; ++k) if (k < sr.ks2) acc += part[k];
+            acc += bias;
+            f16x4 q4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) q4[e] = rok ? (f16)acc[e] : (f16)0;
+            *(f16x4 *)&qsh[row][c0] = q4;
+        }
+        __syncthreads();
+        qf[0] = *(const f16x8 *)&qsh[qn][g * 8];
+        qf[1] = *(const f16x8 *)&qsh[qn][32 + g * 8];
+    } else {
+        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qn < a.nq ? qn : 0)) * a.ldq + h * DH + g * 8;
+        qf[0] = (qn < a.nq) ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
+        qf[1] = (qn < a.nq) ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
+    }
+
     auto compute_blk = [&](int cb, const f16x8 (&kf)[4], const f16x8 (&vf)[4]) {
         const int k0 = cb << 5;
         f32x4 s[2];
@@ -269,8 +281,7 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         // straight-line pair body (no exit between the two halves, or the optimizer sinks the prefetch below the first
         // compute).  The second block of the last pair may lie past nblk: its keys are all masked, which leaves
         // (m_run, l_run, o) unchanged exactly (alpha = 1, p = 0), so the result is bit-identical to the plain loop.
-        f16x8 kA[4], vA[4], kB[4], vB[4];
-        load_blk(wave, kA, vA);
+        f16x8 kB[4], vB[4];
         for (int cb = wave; cb < nblk; cb += 8) {           // nblk >= 4: every wave owns at least one block
             load_blk(cb + 4, kB, vB);
             __builtin_amdgcn_sched_barrier(0);
@@ -280,8 +291,9 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
             compute_blk(cb + 4, kB, vB);
         }
     } else {
+        compute_blk(wave, kA, vA);                           // nblk >= 4: every wave owns at least one block
 #pragma unroll 2
-        for (int cb = wave; cb < nblk; cb += 4) {
+        for (int cb = wave + 4; cb < nblk; cb += 4) {
             f16x8 kf[4], vf[4];
             load_blk(cb, kf, vf);
             compute_blk(cb, kf, vf);
@@ -510,13 +522,18 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     {
         const SlabRef sr = a.qkvs;
         const float *sp = sr.slabs + (size_t)r * sr.N + h * DH + lane;
-        float q = 0.f, k = 0.f, v = 0.f;
-#pragma unroll 4
-        for (int s = 0; s < sr.ks2; ++s) {
-            const float *p = sp + (size_t)s * sr.stride;
-            q += p[0]; k += p[d]; v += p[2 * d];
+        // all 3 x ks2 partial loads in flight before the first add (see attn_decode_cross_f16)
+        float pq[SLAB_KMAX], pk[SLAB_KMAX], pv[SLAB_KMAX];
+#pragma unroll
+        for (int s = 0; s < SLAB_KMAX; ++s) {
+            const float *p = sp + (size_t)(s < sr.ks2 ? s : sr.ks2 - 1) * sr.stride;
+            pq[s] = p[0]; pk[s] = p[d]; pv[s] = p[2 * d];
         }
-        q += sr.bias[h * DH + lane]; k += sr.bias[d + h * DH + lane]; v += sr.bias[2 * d + h * DH + lane];
+        const float bq = sr.bias[h * DH + lane], bk = sr.bias[d + h * DH + lane], bv = sr.bias[2 * d + h * DH + lane];
+        float q = 0.f, k = 0.f, v = 0.f;
+#pragma unroll
+        for (int s = 0; s < SLAB_KMAX; ++s) if (s < sr.ks2) { q += pq[s]; k += pk[s]; v += pv[s]; }
+        q += bq; k += bk; v += bv;
         const f16 qh = (f16)q, kh = (f16)k, vh = (f16)v;
         const size_t at = ((size_t)r * a.n_ctx + pos) * d + h * DH + lane;
         ((f16 *)a.kcache)[at] = kh;
@@ -688,7 +705,7 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     if (dec) {
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
         const bool qsl = a.qs.slabs != nullptr, pipe = (swx_flags() & SWX_FLAG_XATTN_PIPE) != 0;
-        if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias)) return -5;
+        if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias || a.qs.ks2 < 1 || a.qs.ks2 > SLAB_KMAX)) return -5;
         dim3 gd(a.H, a.B);
 #define SWX_XA(QS_, PP_) hipLaunchKernelGGL((attn_decode_cross_f16<QS_, PP_>), gd, dim3(256), 0, s, a)
         if (pipe) { if (qsl) SWX_XA(true, true); else SWX_XA(false, true); }
@@ -718,7 +735,8 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
     if (a.n_ctx > 512) return -5;
     SwxProfScope prof(PC_SELF_ATTN, 0.0, s);
     if (a.qkvs.slabs) {
-        if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.qkvs.bias || a.qkvs.N != 3 * a.d) return -5;
+        if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.qkvs.bias || a.qkvs.N != 3 * a.d || a.qkvs.ks2 < 1 ||
+            a.qkvs.ks2 > SLAB_KMAX) return -5;
         hipLaunchKernelGGL(self_attn_fused_f16, dim3(a.H, a.R), dim3(64), 0, s, a);
         SWX_CHECK_LAUNCH();
         return 0;

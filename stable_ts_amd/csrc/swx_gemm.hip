@@ -537,6 +537,8 @@ size_t swx_skinny_slab_floats(int M, int N, int K)
     return (size_t)(a > b ? a : b) * M * N;
 }
 
+int swx_pg_splits(int N, int K) { return (K % 128 != 0 || N <= 0) ? 0 : pg_ks2(N, K); }
+
 int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
                 hipStream_t s)
 {

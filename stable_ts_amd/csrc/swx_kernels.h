@@ -32,9 +32,10 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 //      slower and were removed again.
 #define SWX_FLAG_NO_FAST_STEP 1     // decode steps go through the generic per-op path (A/B reference for the fused step)
 #define SWX_FLAG_SC1_SLABS 4        // decode-step GEMM: write-through (agent-scope) stores for the split-K partial slabs
-#define SWX_FLAG_FUSE_ATTN_Q 16     // self-/cross-attention read q (k, v) straight from the split-K slabs (no finish launch)
+#define SWX_FLAG_FUSE_SELF 16       // self-attention finishes q|k|v from the split-K slabs, appends K/V and attends in one launch
+#define SWX_FLAG_FUSE_CROSS_Q 64    // cross-attention finishes q from the split-K slabs (no finish launch for the query projection)
 #define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
-#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_ATTN_Q)
+#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF)
 int swx_flags();
 
 // split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:
@@ -55,6 +56,7 @@ size_t swx_skinny_slab_floats(int M, int N, int K);
 int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
                            const FinishArgs &f, hipStream_t s);
 // the weight-streaming half alone: leaves the partial sums in `slabs` and describes them in *ref (bias is the caller's)
+int swx_pg_splits(int N, int K);     // the ks2 swx_gemm_pg will use for this shape (0 = shape not supported)
 int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
                 hipStream_t s);
 

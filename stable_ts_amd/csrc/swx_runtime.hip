@@ -318,7 +318,8 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
     SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->dec[0].ln1_g), m->A<float>(m->dec[0].ln1_b), h, d, rows, d, s));
     const int64_t chunk = xkv_chunk_elems(D);
     // cross-attention rows of a window are its f.rpw consecutive rows: q row (b, qn) = b * rpw + qn, as the slabs are laid out
-    const bool fuse_q = (g_debug_flags & SWX_FLAG_FUSE_ATTN_Q) && f.rpw <= 16 && D.n_audio_ctx >= 128;
+    const bool fuse_self = (g_debug_flags & SWX_FLAG_FUSE_SELF) && swx_pg_splits(3 * d, d) <= 16;
+    const bool fuse_cq = (g_debug_flags & SWX_FLAG_FUSE_CROSS_Q) && f.rpw <= 16 && D.n_audio_ctx >= 128 && swx_pg_splits(d, d) <= 16;
     for (int l = 0; l < D.n_text_layer; ++l) {
         const LayerW &w = m->dec[l];
         unsigned char *kc = f.kcache + (size_t)l * f.layer_stride, *vc = f.vcache + (size_t)l * f.layer_stride;
@@ -328,7 +329,7 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
         SelfAttnArgs sa{};
         sa.qkv = qkv; sa.ldqkv = 3 * d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
-        if (fuse_q) {       // the attention kernel finishes q|k|v from the partial slabs itself (no finish launch)
+        if (fuse_self) {    // the attention kernel finishes q|k|v from the partial slabs itself (no finish launch)
             SWX_TRY(swx_gemm_pg(h, d, m->arena + w.wqkv, d, rows, 3 * d, d, slabs, &sa.qkvs, s));
             sa.qkvs.bias = fq.bias;
         } else {
@@ -343,7 +344,7 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
         fc.bias = m->A<float>(w.bcq); fc.epi = EPI_BIAS; fc.C = qkv; fc.ldc = d;
         const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
         AttnArgs ca{};
-        if (fuse_q) {
+        if (fuse_cq) {
             SWX_TRY(swx_gemm_pg(h, d, m->arena + w.wcq, d, rows, d, d, slabs, &ca.qs, s));
             ca.qs.bias = fc.bias;
         } else {

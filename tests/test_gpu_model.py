@@ -239,10 +239,10 @@ def test_decode_f16_fast_step_equals_general_path(name, beam):
 
 
 @pytest.mark.parametrize("name,beam", [("tiny.en", False), ("base.en", True)])
-@pytest.mark.parametrize("flags", [4, 16, 32, 4 | 16, 4 | 16 | 32])
+@pytest.mark.parametrize("flags", [4, 16, 32, 64, 4 | 16, 4 | 16 | 64, 4 | 16 | 32 | 64])
 def test_decode_f16_step_switches_are_bit_identical(name, beam, flags):
-    # SWX_FLAG_* switches of the fused decode step: write-through partial slabs (4), attention kernels that finish
-    # q|k|v from the split-K slabs themselves (16), and the hand double-buffered cross-attention loop (32).  None of them
+    # SWX_FLAG_* switches of the fused decode step: write-through partial slabs (4), self-attention (16) and cross-attention (64)
+    # kernels that finish q|k|v from the split-K slabs themselves, the hand double-buffered cross-attention loop (32).  None of them
     # changes the arithmetic or its order, so tokens and sums of log-probabilities must be IDENTICAL to the default step.
     from stable_ts_amd import _lib
     lib = _lib.load()

@@ -33,6 +33,7 @@ def main():
               batch_size=20)
     lib = model.engine.lib
     ref_tokens = None
+    best = None
     model.transcribe(audio, **kw)                                   # warm-up (allocations, first-touch)
     for f in [int(x) for x in args.flags.split(",")]:
         lib.swx_debug_flags(f)
@@ -46,9 +47,13 @@ def main():
             model.transcribe(audio, **kw)
         torch.cuda.synchronize()
         ms = 1000.0 * (time.perf_counter() - t0) / args.passes
+        if toks == ref_tokens and (best is None or ms < best[1]):
+            best = (f, ms)
         print(f"flags={f:3d} pg_blocks={os.environ.get('SWX_PG_BLOCKS', 'default')} ms_per_pass={ms:8.2f} "
               f"rtf={args.minutes * 60000.0 / ms:7.1f} same_tokens={toks == ref_tokens} n_tokens={len(toks)}", flush=True)
-    lib.swx_debug_flags(0)
+    if best is not None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        with open(os.path.join(ROOT, "gpurun_out", "best_flags.txt"), "w") as fh:
+            fh.write(str(best[0]))
 
 
 if __name__ == "__main__":
