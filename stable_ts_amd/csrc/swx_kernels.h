@@ -26,16 +26,16 @@ struct GemmArgs {
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 
 // ---- run-time switches of the decode step (swx_debug_flags(); initial value: SWX_DEFAULT_FLAGS, or the environment
-//      variable SWX_FLAGS).  Every switch is arithmetic-neutral: results are bit-identical with it on or off (tested).
-//      Measured on MI355X, large-v3, 20 windows x beam 5 (profiles/README.md): 4 -> -2.8 %, 16 -> -4.0 %, 4|16 -> -7.3 %
-//      of the pass time; 32 -> +0.7 % (kept as an opt-in); non-temporal weight / cross-KV loads were +1.2 % / +4.7 %
-//      slower and were removed again.
+//      variable SWX_FLAGS).  Every switch is arithmetic-neutral: results are bit-identical with it on or off
+//      (tests/test_gpu_model.py::test_decode_f16_step_switches_are_bit_identical).  Measured on MI355X, large-v3,
+//      20 windows x beam 5, ms per 10-minute pass (profiles/README.md): none 735, 4 -> 714, 4|16 -> 682, 4|16|64 -> 668,
+//      4|16|32|64 -> 678.  Non-temporal weight / cross-KV loads measured +1.2 % / +4.7 % slower and were removed again.
 #define SWX_FLAG_NO_FAST_STEP 1     // decode steps go through the generic per-op path (A/B reference for the fused step)
 #define SWX_FLAG_SC1_SLABS 4        // decode-step GEMM: write-through (agent-scope) stores for the split-K partial slabs
 #define SWX_FLAG_FUSE_SELF 16       // self-attention finishes q|k|v from the split-K slabs, appends K/V and attends in one launch
 #define SWX_FLAG_FUSE_CROSS_Q 64    // cross-attention finishes q from the split-K slabs (no finish launch for the query projection)
 #define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
-#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF)
+#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q)
 int swx_flags();
 
 // split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:
