@@ -3,10 +3,10 @@
 Per window the device work is mel -> encoder -> one teacher-forced decoder pass with the alignment heads' qk captured
 -> softmax / z-norm / median / head-mean -> DTW; no autoregressive decoding.  The boundary the
 reference defines for this is ``compute_timestamps(audio_segment, word_tokens)`` (alignment.py:405-429, seam B2):
-`make_alignment_func` returns exactly that callable, and `align` drives it with a compact restatement of the
-window loop of non_whisper/alignment.py:252-394 (token batching by ``token_step``, seek = end of the last word whose
-timing is trusted).  The reference's re-alignment heuristics (`_fallback`, :937-1006) and non-speech skipping
-(:873-935) are "next" items.
+`make_alignment_func` returns exactly that callable, and `align` drives it with `stable_ts_amd.aligner.Aligner`, the
+restatement of the reference's window state machine (non_whisper/alignment.py:58-1033: token batching by
+``token_step``, gap padding, non-speech skipping, the re-alignment policy of ``_fallback``), which is tested against
+the reference's own class on CPU (tests/test_aligner_cpu.py).
 """
 from typing import List, Optional, Sequence, Union
 
@@ -19,9 +19,7 @@ from .timing import add_word_timestamps_batch
 from .tokenizer import get_tokenizer
 
 
-class WordToken:
-    def __init__(self, word: str, tokens: List[int], is_padding: bool = False):
-        self.word, self.tokens, self.is_padding = word, tokens, is_padding
+from .aligner import WordToken  # noqa: E402,F401  (re-exported: the seam-B2 callable takes these)
 
 
 def make_alignment_func(model, tokenizer):
@@ -54,12 +52,17 @@ def _words_from_text(text: str, tokenizer) -> List[WordToken]:
     return [WordToken(w, g) for w, g in zip(words, groups) if len(g)]
 
 
-def align(model, audio, text: Union[str, List[int], WhisperResult], language: str = None, *, token_step: int = 100,
-          tokenizer=None, batch_size: int = 1, regroup: Union[bool, str] = True,
-          **options) -> Optional[WhisperResult]:
-    """Forced alignment.  ``text`` may be a string, a token list, or a WhisperResult (its text is re-aligned).
-    Windows are consumed sequentially: each call aligns up to ``token_step`` tokens against the next <=30 s of audio and
-    the seek moves to the end of the last word that ended before the window's final second."""
+def align(model, audio, text: Union[str, List[int], WhisperResult], language: str = None, *, tokenizer=None,
+          ignore_compatibility: bool = False, remove_instant_words: bool = False, token_step: int = 100,
+          original_split: bool = False, word_dur_factor: Optional[float] = 2.0, max_word_dur: Optional[float] = 3.0,
+          nonspeech_skip: Optional[float] = 5.0, fast_mode: bool = False, failure_threshold: Optional[float] = None,
+          batch_size: int = 1, **options) -> Optional[WhisperResult]:
+    """Forced alignment of ``text`` (plain text, token ids, or a WhisperResult whose text is re-aligned) with ``audio``
+    (alignment.py:27-216).  The window state machine -- token batching, gap padding, non-speech skipping, the
+    re-alignment policy -- is :class:`stable_ts_amd.aligner.Aligner`, a restatement of the reference's ``Aligner`` that is
+    checked against it window for window on CPU; each window's timestamps come from the device through
+    ``make_alignment_func`` (seam B2).  Returns None when nothing could be aligned."""
+    from .aligner import Aligner
     from .transcribe import load_audio
     max_step = model.dims.n_text_ctx - 6                       # alignment.py:181-185
     if token_step < 1:
@@ -67,62 +70,19 @@ def align(model, audio, text: Union[str, List[int], WhisperResult], language: st
     elif token_step > max_step:
         raise ValueError(f"The max value for [token_step] is {max_step} but got {token_step}.")
     if tokenizer is None:
-        if language is None and model.is_multilingual and not isinstance(text, WhisperResult):
-            raise TypeError("expected argument for language")
-        if isinstance(text, WhisperResult) and language is None:
-            language = text.language
+        if not language and model.is_multilingual and (language := getattr(text, "language", None)) is None:
+            raise TypeError("expected argument for language")                                  # alignment.py:375-383
         tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language or "en",
                                   task="transcribe")
-    if isinstance(text, WhisperResult):
-        text = text.text
-    if isinstance(text, str):
-        queue = _words_from_text(text, tokenizer)
-    else:
-        words, groups = tokenizer.split_to_word_tokens(list(text))
-        queue = [WordToken(w, g) for w, g in zip(words, groups)]
-    audio = load_audio(audio)
-    total = int(audio.shape[-1])
-    func = make_alignment_func(model, tokenizer)
-    done: List[dict] = []
-    seek = 0
-    while queue and seek < total:
-        seg = audio[seek: seek + N_SAMPLES]
-        take, n_tok = [], 0
-        for w in queue:
-            if take and n_tok + len(w.tokens) > token_step:
-                break
-            take.append(w)
-            n_tok += len(w.tokens)
-        timed = func(seg, take)
-        seg_dur = seg.shape[-1] / SAMPLE_RATE
-        offset = seek / SAMPLE_RATE
-        last_window = seek + N_SAMPLES >= total
-        # trust words that end before the last second of the window (the tail is re-aligned with more context)
-        n_keep = len(timed)
-        if not last_window:
-            n_keep = 0
-            for wd in timed:
-                if wd["end"] <= seg_dur - 1.0:
-                    n_keep += 1
-                else:
-                    break
-            n_keep = max(n_keep, 1)
-        for wd in timed[:n_keep]:
-            done.append(dict(word=wd["word"], start=round(wd["start"] + offset, 3), end=round(wd["end"] + offset, 3),
-                             probability=wd["probability"], tokens=wd["tokens"]))
-        queue = queue[n_keep:]
-        new_seek = int(round(done[-1]["end"] * SAMPLE_RATE))
-        seek = new_seek if new_seek > seek else seek + int(seg.shape[-1])
-    if not done:
-        return None
-    for w in queue:                                           # unaligned tail: zero-length words at EOF (:349-362)
-        t = round(total / SAMPLE_RATE, 3)
-        done.append(dict(word=w.word, start=t, end=t, probability=0.0, tokens=w.tokens))
-    seg = dict(start=done[0]["start"], end=done[-1]["end"], text="".join(w["word"] for w in done), seek=0.0,
-               tokens=[t for w in done for t in w["tokens"]], words=done)
-    result = WhisperResult(dict(segments=[seg], language=getattr(tokenizer, "language", language)), check_sorted=False)
-    if regroup:                                               # non_whisper/alignment.py:388-389
-        result.regroup(regroup)
+    lang_code = getattr(tokenizer, "language_code", None) or getattr(tokenizer, "language", None)
+    aligner = Aligner(inference_func=make_alignment_func(model, tokenizer), decode=tokenizer.decode, encode=tokenizer.encode,
+                      split_words_by_space=lang_code not in {"zh", "ja", "th", "lo", "my"}, sample_rate=SAMPLE_RATE,
+                      max_segment_length=N_SAMPLES, remove_instant_words=remove_instant_words, token_step=token_step,
+                      original_split=original_split, word_dur_factor=word_dur_factor, max_word_dur=max_word_dur,
+                      nonspeech_skip=nonspeech_skip, fast_mode=fast_mode, failure_threshold=failure_threshold, **options)
+    result = aligner.align(load_audio(audio).detach().float().cpu(), text)
+    if result is not None:
+        result.language = lang_code or language or (None if model.is_multilingual else "en")    # alignment.py:388-393
     return result
 
 

@@ -111,6 +111,13 @@ class WordTiming:
     def unlock_both(self):
         self.left_locked = self.right_locked = False
 
+    def suppress_silence(self, silent_starts, silent_ends, min_word_dur: Optional[float] = None,
+                         nonspeech_error: float = 0.3, keep_end: Optional[bool] = True):
+        from .stabilization import snap_to_speech
+        snap_to_speech(self, silent_starts, silent_ends, 0.1 if min_word_dur is None else min_word_dur, nonspeech_error,
+                       keep_end)
+        return self
+
     def clamp_max(self, max_dur: float, clip_start: bool = False):
         """result.py:231-244: shorten an over-long word from one side."""
         if self.duration > max_dur:
@@ -272,6 +279,22 @@ class Segment:
         else:
             self.start = self.start * factor
             self.end = self.end * factor
+
+    def suppress_silence(self, silent_starts, silent_ends, min_word_dur: Optional[float] = None, word_level: bool = True,
+                         nonspeech_error: float = 0.3, use_word_position: bool = True):
+        """result.py:681-705: snap the words (or only the outer two) out of the non-speech sections; a word keeps its
+        END fixed unless it closes a clause (ends with closing punctuation) or the segment."""
+        from .stabilization import snap_to_speech
+        from .timing import APPEND_PUNCTUATIONS
+        mwd = 0.1 if min_word_dur is None else min_word_dur
+        if self.words:
+            sel = self.words if word_level or len(self.words) == 1 else [self.words[0], self.words[-1]]
+            for i, w in enumerate(sel, 1):
+                keep_end = (not (w.word[-1] in APPEND_PUNCTUATIONS or i == len(sel))) if use_word_position else None
+                snap_to_speech(w, silent_starts, silent_ends, mwd, nonspeech_error, keep_end)
+        else:
+            snap_to_speech(self, silent_starts, silent_ends, mwd, nonspeech_error, True)
+        return self
 
     def convert_to_segment_level(self):
         """result.py:918-925: freeze the word-derived fields and drop the words."""
@@ -462,6 +485,20 @@ class WhisperResult:
         d.pop("ori_dict", None)
         with open(path, "w", encoding="utf-8") as f:
             json.dump(d, f, allow_nan=True)
+
+    def suppress_silence(self, silent_starts, silent_ends, min_word_dur: Optional[float] = None, word_level: bool = True,
+                         nonspeech_error: float = 0.3, use_word_position: bool = True, verbose: bool = False):
+        """result.py:1137-1189: move timestamps lying in the given non-speech sections to the sections' boundaries."""
+        import numpy as np
+        s, e = np.asarray(silent_starts), np.asarray(silent_ends)
+        for seg in self.segments:
+            seg.suppress_silence(s, e, min_word_dur, word_level=word_level, nonspeech_error=nonspeech_error,
+                                 use_word_position=use_word_position)
+        return self
+
+    def set_current_as_orig(self, keep_orig: bool = False):
+        """result.py:3076-3080: the current state becomes what ``reset()`` returns to."""
+        self.ori_dict = self.to_dict(keep_orig=keep_orig)
 
     def reset(self):
         """result.py:3082-3092: back to the segments this result was created with."""

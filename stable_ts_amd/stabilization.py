@@ -83,20 +83,46 @@ def wav2mask(audio: torch.Tensor, q_levels: int = 20, k_size: int = 5) -> Option
 
 
 class NonSpeechPredictor:
-    """Non-VAD branch of stabilization/__init__.py::NonSpeechPredictor."""
+    """Non-VAD branches of stabilization/__init__.py::NonSpeechPredictor (:16-135, 241-286).
+
+    ``loudness=True``  -> ``predict_with_nonvad`` (the default ``suppress_silence=True`` path): quantised loudness mask.
+    ``loudness=False`` -> ``predict_with_samples`` (``suppress_silence=False``): no timings, the mask only looks at
+    exact-zero samples.  ``pad_mask`` pads the mask to the 1501 timestamp tokens of a window (transcribe's
+    ``mask_pad_func``); the aligner uses the mask unpadded."""
 
     def __init__(self, q_levels: int = 20, k_size: int = 5, min_word_dur: Optional[float] = 0.1,
-                 min_silence_dur: Optional[float] = None, get_mask: bool = False):
+                 min_silence_dur: Optional[float] = None, get_mask: bool = False, pad_mask: bool = True,
+                 loudness: bool = True):
         self.q_levels, self.k_size = q_levels, k_size
         self.min_silence_dur = min_silence_dur
         self.get_mask = get_mask
+        self.pad_mask = pad_mask
+        self.loudness = loudness
         mwd = 0.1 if min_word_dur is None else min_word_dur
         self.min_units_per_word = max(round(mwd * FRAMES_PER_SECOND), 1)
         self._starts: List[float] = []
         self._ends: List[float] = []
 
+    def _pad(self, mask: torch.Tensor) -> torch.Tensor:
+        if not self.pad_mask:
+            return mask
+        pad = torch.zeros(1501, dtype=torch.bool)
+        n = min(1501, mask.shape[-1])
+        pad[:n] = mask[:n]
+        return pad
+
     def predict(self, audio: torch.Tensor, offset: float = 0.0) -> dict:
         audio = audio.detach().float().cpu().contiguous()
+        if not self.loudness:
+            # :271-286 with get_mask: one flag per 20-ms unit, True where EVERY sample of the unit is non-zero
+            if not self.get_mask:
+                return dict(timings=None, mask=None, is_silent=False)
+            extra = audio.shape[-1] % N_SAMPLES_PER_TOKEN
+            if extra:
+                audio = F.pad(audio, (0, N_SAMPLES_PER_TOKEN - extra))
+            mask = torch.all(audio.reshape(-1, N_SAMPLES_PER_TOKEN) != 0, dim=-1)
+            silent = bool((mask.shape[-1] - int(mask.count_nonzero())) < self.min_units_per_word)
+            return dict(timings=None, mask=self._pad(mask), is_silent=silent)
         mask = wav2mask(audio, self.q_levels, self.k_size)
         timings = mask2timing(mask, time_offset=offset)
         if timings is not None:
@@ -104,10 +130,7 @@ class NonSpeechPredictor:
         is_silent = False
         if mask is not None:
             is_silent = bool((mask.shape[-1] - int(mask.count_nonzero())) < self.min_units_per_word)
-            pad = torch.zeros(1501, dtype=torch.bool)
-            n = min(1501, mask.shape[-1])
-            pad[:n] = mask[:n]
-            mask = pad
+            mask = self._pad(mask)
         if timings is not None and len(timings[0]):
             self._starts.extend(timings[0].tolist())
             self._ends.extend(timings[1].tolist())
@@ -116,10 +139,10 @@ class NonSpeechPredictor:
             timings = np.stack((timings[0][keep], timings[1][keep]), axis=0)
         return dict(timings=timings, mask=mask if self.get_mask else None, is_silent=is_silent)
 
-    def sections(self) -> List[dict]:
-        """finalize_timings (:120-135): merged, sorted non-speech sections."""
+    def timings(self) -> Optional[Tuple[List[float], List[float]]]:
+        """finalize_timings (:120-135): every section seen so far, sorted, overlaps merged; None when none was seen."""
         if not self._starts:
-            return []
+            return None
         s, e = np.sort(np.array(self._starts)), np.sort(np.array(self._ends))
         while len(s) > 1:
             ok = s[1:] >= e[:-1]
@@ -127,41 +150,63 @@ class NonSpeechPredictor:
                 break
             s = s[np.concatenate(([True], ok))]
             e = e[np.concatenate((ok, [True]))]
-        return [dict(start=float(a), end=float(b)) for a, b in zip(s, e)]
+        return s.tolist(), e.tolist()
+
+    def sections(self) -> List[dict]:
+        t = self.timings()
+        return [] if t is None else [dict(start=float(a), end=float(b)) for a, b in zip(*t)]
 
 
-def _snap(obj: dict, starts: np.ndarray, ends: np.ndarray, min_word_dur: float, nonspeech_error: float,
-          keep_end: Optional[bool]):
-    """stabilization/__init__.py:300-379 on a dict with 'start'/'end'."""
-    if len(starts) == 0 or (obj["end"] - obj["start"]) <= min_word_dur:
+class _DictSpan:
+    """start/end attribute view of a dict (the snapping code below is written against attributes)."""
+    __slots__ = ("d",)
+
+    def __init__(self, d: dict):
+        self.d = d
+
+    start = property(lambda self: self.d["start"], lambda self, v: self.d.__setitem__("start", v))
+    end = property(lambda self: self.d["end"], lambda self, v: self.d.__setitem__("end", v))
+
+
+def snap_to_speech(obj, starts: np.ndarray, ends: np.ndarray, min_word_dur: float, nonspeech_error: float,
+                   keep_end: Optional[bool]):
+    """stabilization/__init__.py:300-379 on any object with ``start`` / ``end`` attributes: a start lying in a
+    non-speech section moves to the section's end, an end lying in one moves to its start (never below
+    ``min_word_dur``); a single section strictly inside the span is cut off from the side it nearly touches."""
+    starts, ends = np.asarray(starts), np.asarray(ends)
+    if len(starts) == 0 or (obj.end - obj.start) <= min_word_dur:
         return
     if keep_end is None or keep_end:
-        hit = np.all((starts <= obj["start"], obj["start"] < ends, ends <= obj["end"]), axis=0).nonzero()[0]
+        hit = np.all((starts <= obj.start, obj.start < ends, ends <= obj.end), axis=0).nonzero()[0]
         if len(hit):
-            obj["start"] = min(float(ends[hit[0]]), round(obj["end"] - min_word_dur, 3))
-            if (obj["end"] - obj["start"]) <= min_word_dur:
+            obj.start = min(float(ends[hit[0]]), round(obj.end - min_word_dur, 3))
+            if (obj.end - obj.start) <= min_word_dur:
                 return
     if not keep_end:
-        hit = np.all((obj["start"] <= starts, starts < obj["end"], obj["end"] <= ends), axis=0).nonzero()[0]
+        hit = np.all((obj.start <= starts, starts < obj.end, obj.end <= ends), axis=0).nonzero()[0]
         if len(hit):
-            obj["end"] = max(float(starts[hit[0]]), round(obj["start"] + min_word_dur, 3))
-            if (obj["end"] - obj["start"]) <= min_word_dur:
+            obj.end = max(float(starts[hit[0]]), round(obj.start + min_word_dur, 3))
+            if (obj.end - obj.start) <= min_word_dur:
                 return
     if nonspeech_error:
-        inside = np.logical_and(obj["start"] <= starts, obj["end"] >= ends).nonzero()[0]
+        inside = np.logical_and(obj.start <= starts, obj.end >= ends).nonzero()[0]
         if len(inside) != 1:
             return
         s0, e0 = float(starts[inside[0]]), float(ends[inside[0]])
         dur = e0 - s0
-        err_start = (s0 - obj["start"]) / dur
-        err_end = (obj["end"] - e0) / dur
+        err_start = (s0 - obj.start) / dur
+        err_end = (obj.end - e0) / dur
         ke = keep_end if keep_end is not None else (err_start <= err_end)
         if not (err_start <= nonspeech_error or err_end <= nonspeech_error):
             return
         if ke:
-            obj["start"] = min(e0, round(obj["end"] - min_word_dur, 3))
+            obj.start = min(e0, round(obj.end - min_word_dur, 3))
         else:
-            obj["end"] = max(s0, round(obj["start"] + min_word_dur, 3))
+            obj.end = max(s0, round(obj.start + min_word_dur, 3))
+
+
+def _snap(obj: dict, starts, ends, min_word_dur, nonspeech_error, keep_end):
+    snap_to_speech(_DictSpan(obj), starts, ends, min_word_dur, nonspeech_error, keep_end)
 
 
 def suppress_segment_silence(seg: dict, starts, ends, min_word_dur: float = 0.1, word_level: bool = True,

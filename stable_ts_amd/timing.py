@@ -17,8 +17,9 @@ import numpy as np
 
 from .audio import N_SAMPLES_PER_TOKEN, TOKENS_PER_SECOND
 
-PREPEND_PUNCTUATIONS = "\"'“¿([{-"
-APPEND_PUNCTUATIONS = "\"'.。,，!！?？:：”)]}、"
+# stable-ts's defaults (stable_whisper/default.py:5-6): upstream whisper's sets plus the CJK corner brackets
+PREPEND_PUNCTUATIONS = "\"'“¿([{-「"
+APPEND_PUNCTUATIONS = "\"'.。,，!！?？:：”)]}、」"
 
 
 @dataclass

@@ -1,0 +1,113 @@
+"""The forced-alignment window state machine (stable_ts_amd/aligner.py) against the reference's ``Aligner``
+(stable_whisper/non_whisper/alignment.py), both driven by the SAME synthetic inference function.
+
+* golden: tests/golden/aligner_cases.json.gz = the reference's results on 40 seeded cases
+  (tests/golden/make_aligner_golden.py): every word, its start/end/probability/tokens, the segmentation, the detected
+  non-speech sections and the number of inference calls must be identical (host control flow on ms-rounded floats: exact).
+* live: where /root/reference is importable, more seeds are compared live, including the per-window inference inputs.
+"""
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import make_aligner_golden as mg  # noqa: E402
+
+from stable_ts_amd.aligner import Aligner, merge_punctuations, tokens_to_word_tokens, WordToken  # noqa: E402
+from stable_ts_amd.tokenizer import get_tokenizer  # noqa: E402
+
+
+def _tok():
+    return get_tokenizer(False, num_languages=99)
+
+
+def _norm(x):
+    return json.loads(json.dumps(x))
+
+
+def test_aligner_matches_reference_golden():
+    with gzip.open(os.path.join(HERE, "golden", "aligner_cases.json.gz"), "rb") as f:
+        cases = json.loads(f.read().decode("utf-8"))
+    assert len(cases) == 40
+    tok = _tok()
+    n_multi = 0
+    for seed, want in cases.items():
+        got, calls = mg.run(Aligner, int(seed), tok)
+        assert _norm(got) == want["out"], (seed, mg.synth_case(int(seed))[2])
+        assert len(calls) == want["n_calls"], seed
+        n_multi += len(calls) > 2
+    assert n_multi >= 20           # most cases need several windows / re-alignments
+
+
+def test_word_token_grouping():
+    tok = _tok()
+    ids = [20, 3, 25, 0, 30, 31, 16, 8, 40, 9, 1, 43]         # " aaau? aaaz.aabe aabf (" + " aabo),  aabr"
+    words = tokens_to_word_tokens(ids, tok.decode, True)
+    assert "".join(w.word for w in words) == tok.decode(ids)
+    assert [t for w in words for t in w.tokens] == ids
+    assert all(w.word.strip() not in ("?", ".", ",", "(") for w in words)   # single marks were merged into a neighbour
+    # a free-standing opening bracket joins the NEXT word, a closing mark the previous one; right to left, so "." first
+    # joins ")" and the pair ")." (no longer a single mark) stays a word of its own -- the reference's behaviour
+    ws = [WordToken(" a", [1]), WordToken(" (", [2]), WordToken(" b", [3]), WordToken(")", [4]), WordToken(".", [5])]
+    merge_punctuations(ws)
+    assert [w.word for w in ws] == [" a", " ( b", ")."] and [w.tokens for w in ws] == [[1], [2, 3], [4, 5]]
+
+
+def test_aligner_argument_errors():
+    tok = _tok()
+    with pytest.raises(ValueError):
+        Aligner(lambda a, w: [], tok.decode, tok.encode, failure_threshold=1.5)
+    with pytest.raises(TypeError):
+        Aligner(lambda a, w: [], tok.decode, tok.encode, not_an_option=1)
+    with pytest.raises(NotImplementedError):
+        Aligner(lambda a, w: [], tok.decode, tok.encode, vad=True)
+    import torch
+    al = Aligner(lambda a, w: [], tok.decode, tok.encode)       # fewer output words than requested: contract violation
+    with pytest.raises(RuntimeError):
+        al.align(0.1 * torch.randn(16000 * 3), " aaat aaau")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
+def test_aligner_matches_reference_live():
+    from make_golden import import_reference
+    import_reference()
+    from stable_whisper.non_whisper.alignment import Aligner as RefAligner
+    tok = _tok()
+    for seed in range(1000, 1030):
+        want, ref_calls = mg.run(RefAligner, seed, tok, extra=dict(verbose=None))
+        got, calls = mg.run(Aligner, seed, tok)
+        assert calls == ref_calls, (seed, mg.synth_case(seed)[2])         # same windows, same word batches
+        assert _norm(got) == _norm(want), (seed, mg.synth_case(seed)[2])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
+def test_aligner_reproduces_reference_align_with_whisper_inference():
+    """The committed golden `align_tiny_en` (tests/golden/reference_glue.json) is the reference's ``model.align`` on the
+    CPU oracle model.  Here the reference's own seam-B2 callable (get_whisper_alignment_func on that oracle model) is
+    plugged into stable_ts_amd's Aligner: words, times and probabilities must equal the golden exactly."""
+    from types import SimpleNamespace
+    import make_golden as G
+    sw = G.import_reference()
+    from oracle.whisper.model import build_model
+    from oracle.whisper.tokenizer import get_tokenizer as oracle_tokenizer
+    from stable_whisper.alignment import get_whisper_alignment_func
+    with open(os.path.join(HERE, "golden", "reference_glue.json")) as f:
+        g = json.load(f)["align_tiny_en"]
+    c = g["case"]
+    model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+    sw.modify_model(model)
+    tok = oracle_tokenizer(False, num_languages=model.num_languages)
+    opts = SimpleNamespace(align=SimpleNamespace(extra_models=None, dynamic_heads=None, aligner="legacy"))
+    func = get_whisper_alignment_func(model, tok, None, opts)
+    al = Aligner(func, tok.decode, tok.encode, regroup=False, suppress_silence=False)
+    res = al.align(G.synth_audio(c["seconds"], c["seed"]), g["text"])
+    got = [(w.word, w.start, w.end, list(w.tokens)) for w in res.all_words()]
+    want = [(w["word"], w["start"], w["end"], w["tokens"]) for w in g["words"]]
+    assert got == want
+    for a, b in zip(res.all_words(), g["words"]):
+        assert abs(a.probability - b["probability"]) < 1e-9

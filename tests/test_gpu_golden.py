@@ -69,11 +69,20 @@ def test_alignment_func_matches_reference_seam_b2():
         assert wa["word"] == wb["word"] and list(wa["tokens"]) == wb["tokens"]
         assert abs(wa["start"] - wb["start"]) <= 0.02 + 1e-9 and abs(wa["end"] - wb["end"]) <= 0.02 + 1e-9, (wa, wb)
         assert abs(wa["probability"] - wb["probability"]) <= 1e-3 * max(wb["probability"], 1e-3) + 1e-9
-    # model.align on the same single-window input reproduces the words in order
-    res = model.align(audio, g["text"], language="en")
+    # model.align = the Aligner state machine (CPU-tested against the reference's class) around that callable: same
+    # words in the same order as the reference's model.align on the oracle; the discrete re-alignment decisions hang on
+    # ms-level durations, so a few words may be re-timed differently when the device times differ by a frame
+    res = model.align(audio, g["text"], language="en", regroup=False, suppress_silence=False)
     words = res.all_words()
     assert [w.word for w in words] == [w["word"] for w in g["words"]]
+    assert [list(w.tokens) for w in words] == [w["tokens"] for w in g["words"]]
     assert all(w.start <= w.end for w in words)
+    close = sum(abs(w.start - r["start"]) <= 0.02 + 1e-9 and abs(w.end - r["end"]) <= 0.02 + 1e-9 for w, r in zip(words, g["words"]))
+    assert close >= 0.9 * len(words), (close, len(words))
+    # default call: silence suppression + default regrouping on top, all words kept
+    res2 = model.align(audio, g["text"], language="en")
+    assert "".join(w.word for w in res2.all_words()) == "".join(w["word"] for w in g["words"])
+    assert res2.regroup_history.startswith("isp=1_cm=") and res2.language == "en"
 
 
 def test_transcribe_window_parallel_equals_per_clip():
