@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence, Union
 import numpy as np
 import torch
 
-from .audio import N_SAMPLES, SAMPLE_RATE
+from .audio import HOP_LENGTH, N_SAMPLES, SAMPLE_RATE
 from .result import WhisperResult
 from .timing import add_word_timestamps_batch
 from .tokenizer import get_tokenizer
@@ -44,6 +44,32 @@ def make_alignment_func(model, tokenizer):
 
     compute_timestamps.batch = compute_timestamps_batch
     return compute_timestamps
+
+
+def make_refinement_func(model, tokenizer):
+    """alignment.py:636-672 (seam B3): ``inference_func(audio_segment f32[2, n], tokens) -> probabilities
+    [2, len(tokens), eot]`` over the text vocabulary, a device tensor.  Both audio copies go through mel -> encoder ->
+    cross-KV and ONE teacher-forced decoder pass of ``sot_sequence + [no_timestamps] + tokens + [eot]``.
+    Like the reference the log-mel is computed on the un-padded segment and the remaining frames are filled with 0.0
+    (``pad_or_trim`` of the mel, not of the audio).  Host-side bisection: stable_ts_amd/refiner.py (CPU-tested against
+    the reference's Refiner); this device callable is composed of GPU-tested entry points only (swx_log_mel, swx_encode,
+    swx_cross_kv, swx_forward_logits) but has no GPU parity test of its own yet."""
+    sot = list(tokenizer.sot_sequence)
+
+    def inference_func(audio_segment: torch.Tensor, tokens: List[int]) -> torch.Tensor:
+        n = int(audio_segment.shape[-1])
+        if n > N_SAMPLES:
+            audio_segment, n = audio_segment[..., :N_SAMPLES], N_SAMPLES
+        mel = model.log_mel_batch([audio_segment[0], audio_segment[1]], [N_SAMPLES - n] * 2)
+        n_frames = n // HOP_LENGTH
+        if n_frames < mel.shape[-1]:
+            mel[..., n_frames:] = 0.0
+        xkv = model.cross_kv(model.encoder(mel))
+        ids = [*sot, tokenizer.no_timestamps, *[int(t) for t in tokens], tokenizer.eot]
+        logits = model.engine.forward_logits(xkv, [ids, ids])
+        return logits[:, len(sot): len(sot) + len(tokens), : tokenizer.eot].softmax(dim=-1)
+
+    return inference_func
 
 
 def _words_from_text(text: str, tokenizer) -> List[WordToken]:
@@ -122,3 +148,29 @@ def align_words(model, audio, result: Union[WhisperResult, List[dict]], language
     if regroup:                                               # non_whisper/alignment.py:472
         out.regroup(regroup)
     return out
+
+
+def refine(model, audio, result: WhisperResult, *, steps: str = None, rel_prob_decrease: float = .03,
+           abs_prob_decrease: float = .05, rel_rel_prob_decrease: Optional[float] = None, prob_threshold: float = .5,
+           rel_dur_change: Optional[float] = .5, abs_dur_change: Optional[float] = None, word_level: bool = True,
+           precision: float = None, single_batch: bool = False, inplace: bool = True, **options) -> WhisperResult:
+    """alignment.py:512-635: move word starts later / ends earlier as far as the token probabilities allow.  The
+    bisection is :class:`stable_ts_amd.refiner.Refiner`; ``single_batch`` is accepted for signature compatibility (the
+    two audio copies always share one batched pass here)."""
+    from .refiner import Refiner
+    from .transcribe import load_audio
+    if result and (not result.has_words or any(w.probability is None for w in result.all_words())):
+        if not result.language:
+            raise RuntimeError("cannot align words with result missing language")
+        result = align_words(model, audio, result, regroup=False)
+    tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=result.language or "en",
+                              task="transcribe")
+    if result and not all(w.tokens for w in result.all_words()):
+        for w in result.all_words():
+            w.tokens = tokenizer.encode(w.word)
+    refiner = Refiner(make_refinement_func(model, tokenizer), sample_rate=SAMPLE_RATE, steps=steps,
+                      rel_prob_decrease=rel_prob_decrease, abs_prob_decrease=abs_prob_decrease,
+                      rel_rel_prob_decrease=rel_rel_prob_decrease, prob_threshold=prob_threshold,
+                      rel_dur_change=rel_dur_change, abs_dur_change=abs_dur_change, word_level=word_level,
+                      precision=precision, max_inference_tokens=model.dims.n_text_ctx - 6, **options)
+    return refiner.refine(load_audio(audio), result, inplace)

@@ -217,11 +217,12 @@ class Whisper:
 
     def _bind_api(self):
         from .transcribe import transcribe_stable
-        from .alignment import align, align_words
+        from .alignment import align, align_words, refine
         self.transcribe = types.MethodType(transcribe_stable, self)
         self.transcribe_stable = self.transcribe
         self.align = types.MethodType(align, self)
         self.align_words = types.MethodType(align_words, self)
+        self.refine = types.MethodType(refine, self)
 
 
 def _read_checkpoint(path: str):

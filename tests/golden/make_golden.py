@@ -105,8 +105,40 @@ def run():
                       tokens=[int(t) for t in w.tokens]) for w in res.all_words()]
         out[c["name"]] = dict(case=c, text=text, ids=ids, words=words, b2=b2)
         print(c["name"], len(words), "words", len(b2), "b2 words")
+    out["refine_tiny_en"] = run_refine_case(sw)
     with open(os.path.join(HERE, "reference_glue.json"), "w") as f:
         json.dump(out, f, indent=0)
+
+
+REFINE_CASE = dict(name="refine_tiny_en", model="tiny.en", gain=2.0, ts_gain=0.5, seconds=12.0, seed=6, n_tokens=24,
+                   mute=[[1.0, 2.0], [5.0, 6.5]])
+
+
+def refine_probe_audio(c):
+    """[2, n] copies of the case's audio with one stretch muted in each (what Refiner sends through seam B3)."""
+    audio = synth_audio(c["seconds"], c["seed"])
+    two = audio[None].repeat(2, 1)
+    for r, (a, b) in enumerate(c["mute"]):
+        two[r, int(a * 16000): int(b * 16000)] = 0.0
+    return two
+
+
+def run_refine_case(sw):
+    """seam B3 (alignment.py:636-672): the reference's get_whisper_refinement_func on the oracle model."""
+    from oracle.whisper.model import build_model
+    from oracle.whisper.tokenizer import get_tokenizer
+    from stable_whisper.alignment import get_whisper_refinement_func
+    c = REFINE_CASE
+    model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+    sw.modify_model(model)
+    tok = get_tokenizer(False, num_languages=model.num_languages)
+    g = torch.Generator().manual_seed(c["seed"])
+    ids = (torch.randint(6, 16000, (c["n_tokens"],), generator=g) * 3 + 19).tolist()
+    probs = get_whisper_refinement_func(model, tok, None, False)(refine_probe_audio(c), ids)      # [2, T, eot]
+    true_p = probs[:, torch.arange(len(ids)), ids]
+    print(c["name"], tuple(probs.shape), "true-token prob range", float(true_p.min()), float(true_p.max()))
+    return dict(case=c, ids=ids, true_prob=true_p.tolist(), top1=probs.argmax(-1).tolist(),
+                top1_prob=probs.max(-1).values.tolist())
 
 
 if __name__ == "__main__":
