@@ -11,9 +11,9 @@ where the next window starts (``_fallback`` :937-1006, ``_redo_words`` :825-871,
 (tests/test_aligner_cpu.py) plugs the SAME synthetic inference function into this class and into the reference's
 ``Aligner`` and requires identical results, window for window.
 
-Host-only control flow on a few hundred words; there is nothing here for the GPU.  Written as one state object
-(`_Run`) per ``align()`` call: ``queue`` = words still to align, ``pending`` = the last trusted word of the previous
-window that the next window is allowed to re-time, ``window`` = the words sent to the device for the current window.
+Host-only control flow on a few hundred words; there is nothing here for the GPU.  State of a run: ``queue`` = words
+still to align, ``pending`` = the last trusted word of the previous window that the next window is allowed to re-time,
+``window`` = the words sent to the device for the current window, ``curr`` = their timings.
 """
 import re
 import warnings
@@ -23,7 +23,7 @@ from typing import Callable, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
-from .result import WhisperResult
+from .result import WhisperResult, WordTiming
 from .stabilization import NonSpeechPredictor
 from .timing import APPEND_PUNCTUATIONS, PREPEND_PUNCTUATIONS
 
@@ -260,17 +260,19 @@ class Aligner:
 
     def _infer(self, audio_segment: torch.Tensor, words: List[WordToken], cuts: List[int], pad_first: bool,
                time_offset: Optional[float] = None) -> List[TimedWord]:
-        """Call the inference function and re-assemble its (possibly finer) output into the requested words
-        (:657-729); padding pseudo-words are dropped, times are clipped to the segment and shifted to absolute."""
+        """Call the inference function for one window (:657-729)."""
         asked = self._with_gap_padding(words, cuts, pad_first)
-        t_max = round(audio_segment.size(-1) / self.sample_rate, 4)
         got = self.inference_func(audio_segment, asked)
+        return self._assemble(asked, got, audio_segment.size(-1), self.time_offset if time_offset is None else time_offset)
+
+    def _assemble(self, asked: List[WordToken], got: List[dict], n_samples: int, time_offset: float) -> List[TimedWord]:
+        """Re-assemble the (possibly finer) output of the inference function into the requested words (:680-729);
+        padding pseudo-words are dropped, times are clipped to the segment and shifted to absolute."""
+        t_max = round(n_samples / self.sample_rate, 4)
         if len(got) < len(asked):
             raise RuntimeError(f"expected output word count to be at least {len(asked)} but got {len(got)}")
         if got[-1]["start"] > t_max:
             warnings.warn(f'word "{got[-1]}" start later than the max timestamp')
-        if time_offset is None:
-            time_offset = self.time_offset
         out: List[TimedWord] = []
         k, text, t0, probs = 0, "", -1, []
         for gi, g in enumerate(got):
@@ -534,4 +536,67 @@ class Aligner:
         n_bad = sum(1 for s in result.segments if s.end - s.start <= 0)
         if n_bad:
             warnings.warn(f"{n_bad}/{len(result.segments)} segments failed to align.", stacklevel=2)
+        return result
+
+    # ------------------------------------------------------------------------------------------- align_words
+    def align_words(self, audio: torch.Tensor, result, normalize_text: bool = True, inplace: bool = True,
+                    batch_inference: Optional[Callable] = None, batch_size: int = 1) -> WhisperResult:
+        """:396-474 -- every segment keeps its start/end and only its words are (re-)timed inside that span; no gap
+        padding, no fallback, segments are independent.  Because they are independent, ``batch_inference(list of
+        segments, list of word lists)`` may time ``batch_size`` of them per device pass; the results are the same."""
+        import copy
+        self._reset()
+        seg_tokens = None
+        if isinstance(result, WhisperResult):
+            if not inplace:
+                result = copy.deepcopy(result)
+        else:
+            if result and not result[0].get("text") and result[0].get("tokens"):
+                seg_tokens = [list(s["tokens"]) for s in result]
+                result = [dict(s, text=self.decode(s["tokens"])) for s in result]
+            result = WhisperResult(result)
+
+        def norm(text: str) -> str:
+            if not normalize_text:
+                return text
+            text = re.sub(r"\s", " ", text)
+            return text if text.startswith(" ") else " " + text
+
+        if seg_tokens is None:
+            seg_tokens = [self.encode(norm(s.text)) for s in result]
+        too_long = [i for i, t in enumerate(seg_tokens) if len(t) > self.token_step]
+        if too_long:
+            raise RuntimeError(f"found segments at following indices exceeding max length for model: {too_long}")
+        self.audio = _MemoryAudio(audio, self.sample_rate)
+        self.detector = NonSpeechPredictor(q_levels=self.q_levels, k_size=self.k_size, min_word_dur=self.min_word_dur,
+                                           min_silence_dur=self.min_silence_dur, get_mask=True, pad_mask=False,
+                                           loudness=self.suppress_silence)
+        jobs = []
+        for seg, toks in zip(result.segments, seg_tokens):
+            if seg.duration == 0:
+                continue
+            chunk = self.audio.next_chunk(round(seg.start * self.sample_rate), round(seg.duration * self.sample_rate))
+            if chunk is None:
+                break
+            self.detector.predict(chunk, offset=seg.start)
+            words = tokens_to_word_tokens(toks, self.decode, self.split_words_by_space)
+            jobs.append((seg, chunk, words))
+        step = max(int(batch_size), 1) if batch_inference is not None else 1
+        for k in range(0, len(jobs), step):
+            part = jobs[k:k + step]
+            if batch_inference is not None:
+                outs = batch_inference([c for _, c, _ in part], [w for _, _, w in part])
+            else:
+                outs = [self.inference_func(c, w) for _, c, w in part]
+            for (seg, chunk, words), got in zip(part, outs):
+                timed = self._assemble(words, got, chunk.size(-1), seg.start)
+                seg.words = [WordTiming(w.word, w.start, w.end, w.probability, w.tokens) for w in timed]
+        result.reassign_ids()
+        timings = self.detector.timings()
+        if self.suppress_silence and timings is not None:
+            result.suppress_silence(*timings, min_word_dur=self.min_word_dur, word_level=self.suppress_word_ts,
+                                    nonspeech_error=self.nonspeech_error, use_word_position=self.use_word_position)
+            result.update_nonspeech_sections(*timings)
+            result.set_current_as_orig()
+        result.regroup(self.regroup)
         return result

@@ -72,12 +72,6 @@ def make_refinement_func(model, tokenizer):
     return inference_func
 
 
-def _words_from_text(text: str, tokenizer) -> List[WordToken]:
-    tokens = tokenizer.encode(text if text.startswith(" ") else " " + text.strip())
-    words, groups = tokenizer.split_to_word_tokens(tokens)
-    return [WordToken(w, g) for w, g in zip(words, groups) if len(g)]
-
-
 def align(model, audio, text: Union[str, List[int], WhisperResult], language: str = None, *, tokenizer=None,
           ignore_compatibility: bool = False, remove_instant_words: bool = False, token_step: int = 100,
           original_split: bool = False, word_dur_factor: Optional[float] = 2.0, max_word_dur: Optional[float] = 3.0,
@@ -112,43 +106,34 @@ def align(model, audio, text: Union[str, List[int], WhisperResult], language: st
     return result
 
 
-def align_words(model, audio, result: Union[WhisperResult, List[dict]], language: str = None, *, tokenizer=None,
-                batch_size: int = 8, regroup: Union[bool, str] = True, **options) -> WhisperResult:
-    """alignment.py:219-368: re-align the words of each pre-timed segment independently (embarrassingly parallel:
-    segments are batched `batch_size` at a time through one encoder / scoring pass)."""
+def align_words(model, audio, result: Union[WhisperResult, List[dict]], language: str = None, *,
+                ignore_compatibility: bool = False, tokenizer=None, normalize_text: bool = True, inplace: bool = True,
+                batch_size: int = 8, **options) -> WhisperResult:
+    """alignment.py:219-368 / non_whisper/alignment.py:396-474: (re-)time the words of every segment inside the
+    segment's own start/end.  Segments are independent, so ``batch_size`` of them share one encoder / scoring pass on
+    the device (the reference runs them one by one); the host logic is ``Aligner.align_words``, compared with the
+    reference's on CPU, batched and unbatched."""
+    from .aligner import Aligner
     from .transcribe import load_audio
     if tokenizer is None:
-        lang = language or (result.language if isinstance(result, WhisperResult) else None) or "en"
-        tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=lang, task="transcribe")
-    segs = [s.to_dict() for s in result.segments] if isinstance(result, WhisperResult) else [dict(s) for s in result]
-    audio = load_audio(audio)
+        language = language or getattr(result, "language", None)
+        if not language and model.is_multilingual:
+            raise TypeError("expected argument for language")
+        tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language or "en",
+                                  task="transcribe")
+    lang_code = getattr(tokenizer, "language_code", None) or getattr(tokenizer, "language", None)
     func = make_alignment_func(model, tokenizer)
-    jobs = []
-    for s in segs:
-        a = int(round(s["start"] * SAMPLE_RATE))
-        b = min(int(round(s["end"] * SAMPLE_RATE)), a + N_SAMPLES, int(audio.shape[-1]))
-        if s.get("words"):
-            wts = [WordToken(w["word"], list(w["tokens"]) if w.get("tokens") else tokenizer.encode(w["word"])) for w in s["words"]]
-        else:
-            wts = _words_from_text(s["text"], tokenizer)
-        jobs.append((s, a, b, wts))
-    out_segments = []
-    for k in range(0, len(jobs), batch_size):
-        chunk = [j for j in jobs[k: k + batch_size] if j[2] > j[1] and j[3]]
-        if not chunk:
-            continue
-        timed = func.batch([audio[a:b] for _, a, b, _ in chunk], [w for *_, w in chunk])
-        for (s, a, b, _), words in zip(chunk, timed):
-            off = a / SAMPLE_RATE
-            ws = [dict(word=w["word"], start=round(w["start"] + off, 3), end=round(w["end"] + off, 3),
-                       probability=w["probability"], tokens=w["tokens"]) for w in words]
-            out_segments.append(dict(start=ws[0]["start"], end=ws[-1]["end"], text="".join(w["word"] for w in ws),
-                                     seek=round(off, 3), tokens=[t for w in ws for t in w["tokens"]], words=ws))
-    out = WhisperResult(dict(segments=out_segments, language=getattr(tokenizer, "language", language)), check_sorted=False)
-    if regroup:                                               # non_whisper/alignment.py:472
-        out.regroup(regroup)
-    return out
 
+    def clipped(fn):        # a segment longer than one window is aligned against its first 30 s (the reference trims the mel)
+        return lambda chunks, words: fn([c[..., :N_SAMPLES] for c in chunks], words)
+
+    aligner = Aligner(inference_func=lambda seg, words: clipped(func.batch)([seg], [words])[0], decode=tokenizer.decode,
+                      encode=tokenizer.encode, split_words_by_space=lang_code not in {"zh", "ja", "th", "lo", "my"},
+                      sample_rate=SAMPLE_RATE, max_segment_length=N_SAMPLES, token_step=model.dims.n_text_ctx, **options)
+    out = aligner.align_words(load_audio(audio).detach().float().cpu(), result, normalize_text, inplace,
+                              batch_inference=clipped(func.batch), batch_size=batch_size)
+    out.language = lang_code or language or (None if model.is_multilingual else "en")
+    return out
 
 def refine(model, audio, result: WhisperResult, *, steps: str = None, rel_prob_decrease: float = .03,
            abs_prob_decrease: float = .05, rel_rel_prob_decrease: Optional[float] = None, prob_threshold: float = .5,
@@ -162,7 +147,7 @@ def refine(model, audio, result: WhisperResult, *, steps: str = None, rel_prob_d
     if result and (not result.has_words or any(w.probability is None for w in result.all_words())):
         if not result.language:
             raise RuntimeError("cannot align words with result missing language")
-        result = align_words(model, audio, result, regroup=False)
+        result = align_words(model, audio, result)
     tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=result.language or "en",
                               task="transcribe")
     if result and not all(w.tokens for w in result.all_words()):

@@ -111,3 +111,56 @@ def test_aligner_reproduces_reference_align_with_whisper_inference():
     assert got == want
     for a, b in zip(res.all_words(), g["words"]):
         assert abs(a.probability - b["probability"]) < 1e-9
+
+
+def _align_words_case(seed: int, tok):
+    import random
+    rng = random.Random(seed)
+    audio, ids, opts = mg.synth_case(seed)
+    seconds = audio.shape[-1] / 16000
+    segs, t, k = [], rng.uniform(0.0, 2.0), 0
+    while t < seconds - 2 and k < len(ids):
+        n = rng.choice([1, 3, 6, 10])
+        piece = ids[k:k + n]
+        k += n
+        d = rng.choice([0.0, 0.6, 2.5, 6.0, 11.0])
+        a, b = round(t, 3), round(min(t + d, seconds), 3)
+        segs.append(dict(start=a, end=b, text=tok.decode(piece).strip() if rng.random() < 0.5 else tok.decode(piece)))
+        t = b + rng.choice([0.0, 0.3, 2.0])
+    keep = {k_: opts[k_] for k_ in ("suppress_silence", "regroup")}
+    return audio, segs, keep
+
+
+def _snap_segments(res):
+    return [[s.start, s.end, s.text, None if s.words is None else
+             [[w.word, w.start, w.end, round(float(w.probability), 12), list(w.tokens)] for w in s.words]]
+            for s in res.segments]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
+def test_align_words_matches_reference_live():
+    import contextlib
+    import copy
+    import io
+    import warnings
+    from make_golden import import_reference
+    import_reference()
+    from stable_whisper.non_whisper.alignment import Aligner as RefAligner
+    tok = _tok()
+    for seed in range(2000, 2015):
+        audio, segs, keep = _align_words_case(seed, tok)
+        outs = []
+        for cls, extra in ((RefAligner, dict(verbose=None)), (Aligner, {})):
+            al = cls(inference_func=mg.make_inference(seed), decode=tok.decode, encode=tok.encode, token_step=448, **keep, **extra)
+            with warnings.catch_warnings(), contextlib.redirect_stderr(io.StringIO()):
+                warnings.simplefilter("ignore")
+                outs.append(_norm(_snap_segments(al.align_words(audio, copy.deepcopy(segs)))))
+        assert outs[0] == outs[1], (seed, keep)
+        # batched inference (segments are independent) gives the same result as one call per segment
+        f = mg.make_inference(seed)
+        al = Aligner(inference_func=f, decode=tok.decode, encode=tok.encode, token_step=448, **keep)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            res = al.align_words(audio, copy.deepcopy(segs), batch_size=4,
+                                 batch_inference=lambda chunks, words: [f(c, w) for c, w in zip(chunks, words)])
+        assert _norm(_snap_segments(res)) == outs[0]
