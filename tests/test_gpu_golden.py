@@ -110,24 +110,10 @@ def test_transcribe_window_parallel_equals_per_clip():
 
 @pytest.mark.xfail(strict=False, reason="seam B3 callable written after the round's GPU minutes ran out: first hardware run decides")
 def test_refinement_func_matches_reference_seam_b3():
-    # the reference's get_whisper_refinement_func on the oracle model (golden) vs make_refinement_func on the device:
-    # probabilities of the true tokens for both muted audio copies, and the arg-max token of every position
-    import importlib.util
-    from stable_ts_amd.alignment import make_refinement_func
-    from stable_ts_amd.tokenizer import get_tokenizer
-    g = _golden()["refine_tiny_en"]
-    case = g["case"]
-    model = _model(case)
-    tok = get_tokenizer(False, num_languages=model.num_languages)
-    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    two = mod.refine_probe_audio(case)
-    probs = make_refinement_func(model, tok)(two, g["ids"])
-    assert tuple(probs.shape) == (2, len(g["ids"]), tok.eot)
-    pos = torch.arange(len(g["ids"]))
-    true_p = probs[:, pos, g["ids"]].float().cpu().numpy()
-    want = np.asarray(g["true_prob"])
-    assert np.allclose(true_p, want, rtol=2e-2, atol=1e-9), float(np.abs(true_p / want - 1).max())
-    top1 = probs.argmax(-1).cpu().numpy()
-    assert (top1 == np.asarray(g["top1"])).mean() >= 0.95
+    # the reference's get_whisper_refinement_func on the oracle model (golden) vs make_refinement_func on the device.
+    # Runs in its own process: a first-ever hardware run of new device code must not be able to disturb the GPU context
+    # of the tests that follow.
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(HERE, "golden", "b3_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
