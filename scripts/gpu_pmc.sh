@@ -1,4 +1,5 @@
 #!/bin/bash
+# usage: gpurun -- 'bash scripts/gpu_pmc.sh'
 # HBM traffic counters (separate passes, kernel-trace only) on a shortened decode (8 steps) of the bench workload
 mkdir -p gpurun_out
 export TMPDIR=/tmp

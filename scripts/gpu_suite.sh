@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-1 closing run: whole GPU suite, smoke, bench line, rocprofv3 kernel stats of the bench command
+# usage: gpurun -- 'bash scripts/gpu_suite.sh'
+# whole GPU suite, smoke, bench line, rocprofv3 kernel stats of the bench command
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( timeout 60 python __graft_entry__.py smoke 2>&1 | tail -3 ) > gpurun_out/smoke.log

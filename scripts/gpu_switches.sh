@@ -1,10 +1,11 @@
 #!/bin/bash
-# round-1 closing run (2): bit-identity tests of the decode-step switches, timing of the candidate defaults, then the
+# usage: gpurun -- 'bash scripts/gpu_switches.sh'
+# bit-identity tests of the decode-step switches, timing of the candidate defaults, then the
 # bench line and rocprofv3 kernel stats under the fastest bit-identical setting (SWX_FLAGS)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( timeout 120 python -m pytest tests/test_gpu_model.py tests/test_gpu_kernels.py -m gpu -q -n 4 --timeout=100 -k "switches or fast_step or attention or attn" 2>&1 | tail -6 ) > gpurun_out/switch_tests.log
-( timeout 100 python tests/tune_flags.py --flags 20,84,116,20,84 2>&1 | grep "^flags" ) > gpurun_out/tune_flags.log
+( timeout 100 python scripts/tune_flags.py --flags 20,84,116,20,84 2>&1 | grep "^flags" ) > gpurun_out/tune_flags.log
 export SWX_FLAGS=$(cat gpurun_out/best_flags.txt 2>/dev/null || echo 20)
 echo "SWX_FLAGS=$SWX_FLAGS" >> gpurun_out/tune_flags.log
 ( timeout 120 python bench.py 2> gpurun_out/bench.err | tail -2 ) > gpurun_out/bench.log

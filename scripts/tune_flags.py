@@ -1,6 +1,6 @@
 """A/B timing of the decode-step experiment switches (SWX_FLAG_* in csrc/swx_kernels.h) on the bench workload.
 
-    python tests/tune_flags.py [--flags 0,2,4,8,16,30] [--passes 2]     (one GPU; prints one line per flag value)
+    python scripts/tune_flags.py [--flags 0,2,4,8,16,30] [--passes 2]     (one GPU; prints one line per flag value)
 
 SWX_PG_BLOCKS (split-K workgroup target of the decode GEMM) is read once per process: set it in the environment.
 """
