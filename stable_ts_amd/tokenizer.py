@@ -15,11 +15,15 @@ Synthetic text vocabulary (ids < eot):
                 leading space (start a new word), the others continue the previous word.
 Every token string is unique and `decode` is plain concatenation, so
 ``encode(decode(ids)) == ids`` for any id list without specials.
+
+With a real vocabulary at hand (upstream's ``gpt2.tiktoken`` / ``multilingual.tiktoken`` in a directory named by
+``SWX_TIKTOKEN_DIR`` or ``get_tokenizer(..., vocab_dir=...)``) `TiktokenEncoding` takes the synthetic vocabulary's
+place: same interface, tiktoken's byte-pair algorithm, upstream's special-token layout (tests/test_tokenizer_cpu.py).
 """
 import string
 from dataclasses import dataclass, field
 from functools import cached_property, lru_cache
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple, Union
 
 LANGUAGES = {
     "en": "english", "zh": "chinese", "de": "german", "es": "spanish", "ru": "russian", "ko": "korean",
@@ -147,9 +151,73 @@ class SyntheticEncoding:
         return out
 
 
+class TiktokenEncoding:
+    """Real vocabulary: upstream's ``<name>.tiktoken`` rank file (one ``base64(token bytes) rank`` pair per line, e.g.
+    whisper/assets/gpt2.tiktoken / multilingual.tiktoken) with a byte-pair encoder that follows tiktoken's algorithm:
+    the text is cut by upstream's GPT-2 pattern, each piece is split into bytes and the adjacent pair with the lowest
+    merge rank is merged until none is left.  Special tokens are appended after the text vocabulary in upstream's
+    order (whisper/tokenizer.py::get_encoding), so every id convention of the hot path (eot, sot, timestamps) holds.
+    No vocabulary file ships with this repository (none is available offline): point ``SWX_TIKTOKEN_DIR`` or
+    ``get_tokenizer(..., vocab_dir=...)`` at a directory that holds the two files."""
+
+    PATTERN = r"""'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"""
+
+    def __init__(self, path: str, name: str, num_languages: int):
+        import base64
+        import regex
+        self.name = name
+        self.ranks: Dict[bytes, int] = {}
+        with open(path, "rb") as f:
+            for line in f:
+                if line.strip():
+                    tok, rank = line.split()
+                    self.ranks[base64.b64decode(tok)] = int(rank)
+        self.n_text = len(self.ranks)
+        self._bytes_by_id = {v: k for k, v in self.ranks.items()}
+        specials = [
+            "<|endoftext|>", "<|startoftranscript|>",
+            *[f"<|{lang}|>" for lang in list(LANGUAGES.keys())[:num_languages]],
+            "<|translate|>", "<|transcribe|>", "<|startoflm|>", "<|startofprev|>",
+            "<|nospeech|>", "<|notimestamps|>",
+            *[f"<|{i * 0.02:.2f}|>" for i in range(1501)],
+        ]
+        self.special_tokens: Dict[str, int] = {t: self.n_text + i for i, t in enumerate(specials)}
+        self.n_vocab = self.n_text + len(specials)
+        self.eot_token = self.special_tokens["<|endoftext|>"]
+        self._special_by_id = {v: k for k, v in self.special_tokens.items()}
+        self._pat = regex.compile(self.PATTERN)
+
+    def _bpe(self, piece: bytes) -> List[int]:
+        parts = [piece[i:i + 1] for i in range(len(piece))]
+        while len(parts) > 1:
+            best, best_rank = -1, None
+            for i in range(len(parts) - 1):
+                r = self.ranks.get(parts[i] + parts[i + 1])
+                if r is not None and (best_rank is None or r < best_rank):
+                    best, best_rank = i, r
+            if best < 0:
+                break
+            parts[best:best + 2] = [parts[best] + parts[best + 1]]
+        return [self.ranks[p] for p in parts]
+
+    def encode(self, text: str) -> List[int]:
+        out: List[int] = []
+        for piece in self._pat.findall(text):
+            b = piece.encode("utf-8")
+            r = self.ranks.get(b)
+            out.extend([r] if r is not None else self._bpe(b))
+        return out
+
+    def decode_bytes(self, tokens: List[int]) -> bytes:
+        return b"".join(self._bytes_by_id[t] if t < self.n_text else self._special_by_id[t].encode() for t in tokens)
+
+    def decode(self, tokens: List[int]) -> str:
+        return self.decode_bytes(tokens).decode("utf-8", errors="replace")
+
+
 @dataclass
 class Tokenizer:
-    encoding: SyntheticEncoding
+    encoding: Union[SyntheticEncoding, "TiktokenEncoding"]
     num_languages: int
     language: Optional[str] = None
     task: Optional[str] = None
@@ -248,7 +316,17 @@ class Tokenizer:
         """Upstream: symbols / brackets / music notes that are suppressed unless they are spoken.
         Synthetic vocabulary: the bracket and quote punctuation ids (a fixed subset, so that the
         SuppressTokens path is exercised with a non-trivial list)."""
-        return tuple(sorted(_PUNCT.index(c) for c in ['"', "(", ")", "[", "]", "{", "}", "%"]))
+        if isinstance(self.encoding, SyntheticEncoding):
+            return tuple(sorted(_PUNCT.index(c) for c in ['"', "(", ")", "[", "]", "{", "}", "%"]))
+        symbols = list("\"#()*+/:;<=>@[\\]^_`{|}~「」『』")
+        symbols += "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♪♪♪".split()
+        misc = set("♩♪♫♬♭♮♯")
+        result = {self.encoding.encode(" -")[0], self.encoding.encode(" '")[0]}
+        for symbol in symbols + list(misc):
+            for toks in (self.encoding.encode(symbol), self.encoding.encode(" " + symbol)):
+                if len(toks) == 1 or symbol in misc:
+                    result.add(toks[0])
+        return tuple(sorted(result))
 
     def split_to_word_tokens(self, tokens: List[int]):
         if self.language in {"zh", "ja", "th", "lo", "my", "yue"}:
@@ -256,11 +334,19 @@ class Tokenizer:
         return self.split_tokens_on_spaces(tokens)
 
     def split_tokens_on_unicode(self, tokens: List[int]):
-        words = []
-        word_tokens = []
+        """Upstream whisper/tokenizer.py::split_tokens_on_unicode: a unit ends where the running decoding holds no
+        U+FFFD (a token boundary inside a multi-byte character) -- unless the text itself contains one there."""
+        full = self.decode_with_timestamps(tokens)
+        bad = "\ufffd"
+        words, word_tokens, run, offset = [], [], [], 0
         for token in tokens:
-            words.append(self.decode_with_timestamps([token]))
-            word_tokens.append([token])
+            run.append(token)
+            piece = self.decode_with_timestamps(run)
+            if bad not in piece or full[offset + piece.index(bad)] == bad:
+                words.append(piece)
+                word_tokens.append(run)
+                run = []
+                offset += len(piece)
         return words, word_tokens
 
     def split_tokens_on_spaces(self, tokens: List[int]):
@@ -280,14 +366,29 @@ class Tokenizer:
         return words, word_tokens
 
 
+def _vocab_file(name: str, vocab_dir: Optional[str]) -> Optional[str]:
+    import os
+    for d in (vocab_dir, os.environ.get("SWX_TIKTOKEN_DIR")):
+        if d:
+            p = os.path.join(d, f"{name}.tiktoken")
+            if os.path.isfile(p):
+                return p
+            if d is vocab_dir:
+                raise FileNotFoundError(p)
+    return None
+
+
 @lru_cache(maxsize=None)
-def get_encoding(name: str = "gpt2", num_languages: int = 99) -> SyntheticEncoding:
+def get_encoding(name: str = "gpt2", num_languages: int = 99, vocab_dir: Optional[str] = None):
+    path = _vocab_file(name, vocab_dir)
+    if path is not None:
+        return TiktokenEncoding(path, name, num_languages)
     return SyntheticEncoding(name, num_languages)
 
 
 @lru_cache(maxsize=None)
 def get_tokenizer(multilingual: bool, *, num_languages: int = 99, language: Optional[str] = None,
-                  task: Optional[str] = None) -> Tokenizer:
+                  task: Optional[str] = None, vocab_dir: Optional[str] = None) -> Tokenizer:
     if language is not None:
         language = language.lower()
         if language not in LANGUAGES:
@@ -303,5 +404,5 @@ def get_tokenizer(multilingual: bool, *, num_languages: int = 99, language: Opti
         encoding_name = "gpt2"
         language = None
         task = None
-    encoding = get_encoding(name=encoding_name, num_languages=num_languages)
+    encoding = get_encoding(name=encoding_name, num_languages=num_languages, vocab_dir=vocab_dir)
     return Tokenizer(encoding=encoding, num_languages=num_languages, language=language, task=task)
