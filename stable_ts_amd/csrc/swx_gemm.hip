@@ -12,6 +12,9 @@
 // Epilogue (f32): +bias, GELU(erf), +f32 residual indexed by row % res_mod (positional embedding), +T residual,
 // store as T or f32.
 #include <cstdlib>
+#include <array>
+#include <vector>
+#include <cstdio>
 #include "swx_common.h"
 #include "swx_kernels.h"
 
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
 // shared by the four waves (4x fewer, 2x wider L2 requests), while every wave streams its own weight fragments of the
 // whole slice from HBM up front.  Partial sums go to f32 slabs (deterministic split-K), finished by splitk_finish_f16.
 constexpr int PG_LD = 72;        // halfs per LDS row
-constexpr int PG_MAXIT = 10;     // 64-wide K chunks per workgroup slice, upper bound (launcher picks the <= 5 or <= 10 build)
+constexpr int PG_MAXIT = 20;     // 64-wide K chunks per workgroup slice, upper bound (launcher picks the <= 5, <= 10 or <= 20 build)
 template <int MT, int MAXIT>
 __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int64_t slab_stride, int ks2, int flags)
 {
@@ -393,9 +396,27 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
             __syncthreads();
         }
     }
+    const int col = blockIdx.x * 64 + wave * 16 + (lane & 15), row_l = (lane >> 4) * 4;
+    if (!(g.epi & EPI_OUT_F32)) {
+        // un-split K (ks2 == 1): the workgroup owns the finished sums, so bias / GELU are applied here and the compute
+        // dtype is stored directly -- no slab, no finish launch.  Same arithmetic as splitk_finish_f16 on one slab.
+        if (col < g.N) {
+            const float bias = (g.epi & EPI_BIAS) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = t * 16 + row_l + r;
+                    float a = 0.f + acc[t][r];
+                    if (g.epi & EPI_BIAS) a += bias;
+                    if (g.epi & EPI_GELU) a = gelu_erf(a);
+                    if (row < g.M) ((f16 *)g.C)[(size_t)row * g.ldc + col] = (f16)a;
+                }
+        }
+        return;
+    }
     // each wave owns its 16 columns for this K slice: plain f32 partials, no cross-wave reduction
     float *out = slabs + (size_t)blockIdx.y * slab_stride;
-    const int col = blockIdx.x * 64 + wave * 16 + (lane & 15), row_l = (lane >> 4) * 4;
     if (col < g.N) {
         if (flags & SWX_FLAG_SC1_SLABS) {
             // write-through: the partials reach memory while the kernel runs instead of as one dirty-L2 write-back at
@@ -504,15 +525,36 @@ __global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict
     }
 }
 
+// Experiment hook: SWX_PG_POLICY="NxK=ks2,NxK=ks2,..." pins the K split of given GEMM shapes (e.g. "5120x1280=1" runs the
+// first MLP projection un-split on 80 fat workgroups, which lets the kernel finish bias + GELU itself).
+int pg_policy(int N, int K)
+{
+    static const std::vector<std::array<int, 3>> table = [] {
+        std::vector<std::array<int, 3>> t;
+        const char *e = getenv("SWX_PG_POLICY");
+        while (e && *e) {
+            int n = 0, k = 0, c = 0, used = 0;
+            if (sscanf(e, "%dx%d=%d%n", &n, &k, &c, &used) == 3 && used > 0) { t.push_back({n, k, c}); e += used; }
+            else break;
+            if (*e == ',') ++e;
+        }
+        return t;
+    }();
+    for (auto &r : table) if (r[0] == N && r[1] == K) return r[2];
+    return 0;
+}
+
 int pg_ks2(int N, int K)
 {
     const int units = K / 64;
     const int panels = (N + 63) / 64;
+    const int pinned = pg_policy(N, K);
+    if (pinned > 0 && units % pinned == 0 && units / pinned <= PG_MAXIT) return pinned;
     static const int target = [] { const char *e = getenv("SWX_PG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 320; }();
     int want = (target + panels - 1) / panels;     // workgroups wanted per launch (tunable for experiments)
     int ks2 = 0;
     for (int c = 1; c <= units; ++c)
-        if (units % c == 0 && units / c <= PG_MAXIT && (ks2 == 0 || c <= want)) ks2 = c;
+        if (units % c == 0 && units / c <= 10 && (ks2 == 0 || c <= want)) ks2 = c;
     return ks2;
 }
 
@@ -539,8 +581,21 @@ size_t swx_skinny_slab_floats(int M, int N, int K)
 
 int swx_pg_splits(int N, int K) { return (K % 128 != 0 || N <= 0) ? 0 : pg_ks2(N, K); }
 
+namespace {
+int pg_launch(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
+              const FinishArgs *direct, hipStream_t s);
+}
+
 int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
                 hipStream_t s)
+{
+    return pg_launch(A, lda, W, ldw, M, N, K, slabs, ref, nullptr, s);
+}
+
+namespace {
+// direct != null (only legal when the shape runs un-split): bias / GELU in the kernel's own epilogue, compute dtype out
+int pg_launch(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
+              const FinishArgs *direct, hipStream_t s)
 {
     if (M <= 0 || N <= 0) return -4;
     if (M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC || lda % 8 != 0 || ldw % 8 != 0) return -4;
@@ -548,12 +603,17 @@ int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, i
     if (ks2 <= 0) return -4;
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = EPI_OUT_F32; g.res_mod = 1;
+    if (direct) {
+        if (ks2 != 1) return -4;
+        g.epi = direct->epi & (EPI_BIAS | EPI_GELU); g.bias = direct->bias; g.C = direct->C; g.ldc = direct->ldc;
+    }
     const int64_t stride = (int64_t)M * N;
     const int flags = swx_flags();
     dim3 grid(cdiv(N, 64), ks2);
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)N * K + (double)M * K) + (double)M * N * 2, s);
-    const bool deep = K / (64 * ks2) > 5;     // K slice per workgroup in 64-wide chunks: <= 5 (default tuning) or <= 10
-#define SWX_PG(MT) do { if (deep) hipLaunchKernelGGL((gemm_f16_pg<MT, 10>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
+    const int nit = K / (64 * ks2);           // K slice per workgroup in 64-wide chunks: <= 5 (default tuning), <= 10 or <= 20
+#define SWX_PG(MT) do { if (nit > 10) hipLaunchKernelGGL((gemm_f16_pg<MT, 20>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
+                        else if (nit > 5) hipLaunchKernelGGL((gemm_f16_pg<MT, 10>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
                         else hipLaunchKernelGGL((gemm_f16_pg<MT, 5>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); } while (0)
     switch (cdiv(M, 16)) {
         case 1: SWX_PG(1); break;
@@ -569,12 +629,16 @@ int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, i
     if (ref) { ref->slabs = slabs; ref->ks2 = ks2; ref->stride = stride; ref->N = N; ref->bias = nullptr; }
     return 0;
 }
+}  // namespace
 
 int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
                            const FinishArgs &f, hipStream_t s)
 {
     if (M <= 0 || N <= 0) return 0;
     SlabRef ref{};
+    // an un-split shape (SWX_PG_POLICY) whose finish is only bias / GELU needs no finish launch at all
+    if (pg_ks2(N, K) == 1 && K % 128 == 0 && !f.ln_out && !f.kcache && !(f.epi & EPI_RES) && f.C)
+        return pg_launch(A, lda, W, ldw, M, N, K, slabs, &ref, &f, s);
     const int rc = swx_gemm_pg(A, lda, W, ldw, M, N, K, slabs, &ref, s);
     if (rc < 0) return rc;
     const int ks2 = ref.ks2;

@@ -4,6 +4,8 @@ alignment matrix + DTW) against the CPU oracle with the SAME seeded random weigh
 Strict mode (dtype f32) is held to the north-star bar: identical token ids, bit-exact DTW paths, logprobs within 1e-3.
 The fp16 mode (what the reference itself runs on a GPU) is held to fp16 tolerances and reported as agreement.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -302,3 +304,17 @@ def test_score_alignment_dtw_strict(name, heads):
         ri, rj = cache["dtw_path"]
         ti, tj = paths[w]
         assert ti.tolist() == ri.tolist() and tj.tolist() == rj.tolist()
+
+
+@pytest.mark.xfail(strict=False, reason="un-split decode GEMM variants (SWX_PG_POLICY) written after the round's GPU minutes ran out")
+@pytest.mark.parametrize("name,policy", [("tiny.en", "1536x384=1,1152x384=1,384x384=1,384x1536=2"),
+                                         ("base.en", "2048x512=1,1536x512=1,512x512=2,512x2048=4")])
+def test_decode_f16_unsplit_gemm_policy(name, policy):
+    # SWX_PG_POLICY is read once per process -> own process (also keeps a first-ever hardware run of the deeper
+    # kernel build and its in-kernel bias/GELU epilogue away from this process's GPU context)
+    import subprocess
+    import sys
+    env = dict(os.environ, SWX_PG_POLICY=policy)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pg_policy_check.py"), name],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
