@@ -164,3 +164,52 @@ def test_align_words_matches_reference_live():
             res = al.align_words(audio, copy.deepcopy(segs), batch_size=4,
                                  batch_inference=lambda chunks, words: [f(c, w) for c, w in zip(chunks, words)])
         assert _norm(_snap_segments(res)) == outs[0]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
+def test_align_wrapper_end_to_end_on_cpu(monkeypatch):
+    """stable_ts_amd.alignment.align / align_words / refine wrappers (argument handling, tokenizer and language
+    plumbing, option pass-through) with the device callables replaced by the reference's own seam callables on the CPU
+    oracle model: align() must reproduce the committed golden of the reference's model.align exactly."""
+    from types import SimpleNamespace
+    import make_golden as G
+    import stable_ts_amd.alignment as A
+    sw = G.import_reference()
+    from oracle.whisper.model import build_model
+    from stable_whisper.alignment import get_whisper_alignment_func, get_whisper_refinement_func
+    with open(os.path.join(HERE, "golden", "reference_glue.json")) as f:
+        g = json.load(f)["align_tiny_en"]
+    c = g["case"]
+    model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+    sw.modify_model(model)
+    opts = SimpleNamespace(align=SimpleNamespace(extra_models=None, dynamic_heads=None, aligner="legacy"))
+
+    def fake_alignment_func(m, tokenizer):
+        f = get_whisper_alignment_func(m, tokenizer, None, opts)
+        f.batch = lambda chunks, words: [f(ch, w) for ch, w in zip(chunks, words)]
+        return f
+
+    monkeypatch.setattr(A, "make_alignment_func", fake_alignment_func)
+    monkeypatch.setattr(A, "make_refinement_func", lambda m, tokenizer: get_whisper_refinement_func(m, tokenizer, None, False))
+    audio = G.synth_audio(c["seconds"], c["seed"])
+    res = A.align(model, audio, g["text"], language="en", regroup=False, suppress_silence=False)
+    assert [(w.word, w.start, w.end, list(w.tokens)) for w in res.all_words()] == \
+        [(w["word"], w["start"], w["end"], w["tokens"]) for w in g["words"]]
+    assert res.language == "en"
+    res2 = A.align(model, audio, g["text"], language="en")                       # defaults: silence suppression + regroup
+    assert "".join(w.word for w in res2.all_words()) == "".join(w["word"] for w in g["words"])
+    assert res2.regroup_history.startswith("isp=1_cm=")
+    with pytest.raises(ValueError):
+        A.align(model, audio, g["text"], language="en", token_step=10 ** 6)
+    with pytest.raises(TypeError):
+        A.align(model, audio, g["text"], language="en", no_such_option=1)
+    # align_words keeps the segmentation it is given and re-times the words inside each segment
+    segs = [dict(start=s.start, end=s.end, text=s.text) for s in res2.segments]
+    res3 = A.align_words(model, audio, segs, language="en", regroup=False)
+    assert [s.text for s in res3.segments] == [s["text"] for s in segs] and res3.has_words
+    assert all(s0["start"] <= w.start <= w.end <= s0["end"] + 1e-9 for s, s0 in zip(res3.segments, segs) for w in s.words)
+    # refine runs on the result and only moves starts later / ends earlier within the allowed range
+    before = [(w.start, w.end) for w in res.all_words()]
+    out = A.refine(model, audio, res, precision=0.5)
+    assert out is res and len(out.all_words()) == len(before)
+    assert all(w.start <= w.end for w in out.all_words())
