@@ -995,6 +995,25 @@ int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, cons
     return swx_gemm(dtype, g, force_kernel, S(stream));
 }
 
+int swx_test_gemm_splitk(const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
+                         void *d_c, int64_t ldc, const float *d_ln_g, const float *d_ln_b, void *d_ln_out,
+                         int M, int N, int K, int epilogue, void *stream)
+{
+    static float *slabs = nullptr;            // grown on demand, kept for the life of the process (test hook)
+    static size_t slab_floats = 0;
+    const size_t need = swx_skinny_slab_floats(M, N, K);
+    if (need == 0) return -4;
+    if (need > slab_floats) {
+        if (slabs) (void)hipFree(slabs);
+        if (hipMalloc((void **)&slabs, need * sizeof(float) + 256) != hipSuccess) { slabs = nullptr; slab_floats = 0; return -2; }
+        slab_floats = need;
+    }
+    FinishArgs f{};
+    f.bias = d_bias; f.epi = epilogue & (EPI_BIAS | EPI_GELU | EPI_RES); f.R = d_res; f.ldr = ldc; f.C = d_c; f.ldc = ldc;
+    f.ln_g = d_ln_g; f.ln_b = d_ln_b; f.ln_out = d_ln_out; f.ld_ln = N;
+    return swx_gemm_skinny_splitk(d_a, lda, d_w, K, M, N, K, slabs, f, S(stream));
+}
+
 int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float *d_b, void *d_y, int rows, int d, void *stream)
 {
     return swx_layernorm(dtype, d_x, d, d_g, d_b, d_y, d, rows, d, S(stream));

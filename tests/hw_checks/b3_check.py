@@ -1,7 +1,7 @@
 """Seam B3 on hardware: stable_ts_amd.alignment.make_refinement_func vs the golden produced by the reference's
 get_whisper_refinement_func on the CPU oracle (tests/golden/make_golden.py::run_refine_case).  Exit code 0 = parity.
 
-    python tests/golden/b3_check.py            (needs a GPU; run by tests/test_gpu_golden.py in a subprocess)
+    python tests/hw_checks/b3_check.py            (needs a GPU; run by tests/test_gpu_golden.py in a subprocess)
 """
 import json
 import os
@@ -11,8 +11,9 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(os.path.dirname(HERE), "golden")
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-sys.path.insert(0, HERE)
+sys.path.insert(0, GOLDEN)
 
 
 def main() -> int:
@@ -20,7 +21,7 @@ def main() -> int:
     from make_golden import refine_probe_audio
     from stable_ts_amd.alignment import make_refinement_func
     from stable_ts_amd.tokenizer import get_tokenizer
-    with open(os.path.join(HERE, "reference_glue.json")) as f:
+    with open(os.path.join(GOLDEN, "reference_glue.json")) as f:
         g = json.load(f)["refine_tiny_en"]
     case = g["case"]
     dims = sw.dims_for(case["model"])

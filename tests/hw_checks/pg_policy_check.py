@@ -2,7 +2,7 @@
 fused step under the policy vs the generic per-op path in the same process (same criterion as
 tests/test_gpu_model.py::test_decode_f16_fast_step_equals_general_path).  Exit code 0 = agreement.
 
-    SWX_PG_POLICY="1536x384=1,1152x384=1,384x384=1,384x1536=2" python tests/golden/pg_policy_check.py tiny.en
+    SWX_PG_POLICY="1536x384=1,1152x384=1,384x384=1,384x1536=2" python tests/hw_checks/pg_policy_check.py tiny.en
 """
 import os
 import sys

@@ -315,6 +315,6 @@ def test_decode_f16_unsplit_gemm_policy(name, policy):
     import subprocess
     import sys
     env = dict(os.environ, SWX_PG_POLICY=policy)
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pg_policy_check.py"), name],
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hw_checks", "pg_policy_check.py"), name],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
