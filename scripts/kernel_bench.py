@@ -35,6 +35,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--only", default="")
+    ap.add_argument("--gemm-kernel", type=int, default=1, help="force_kernel of the tiled GEMM: 1 register-staged, 4 direct-to-LDS")
     args = ap.parse_args()
     from stable_ts_amd import _lib
     lib = _lib.load()
@@ -46,12 +47,12 @@ def main():
     print(f"SWX_FLAGS={lib.swx_debug_flags(-1)} SWX_PG_POLICY={os.environ.get('SWX_PG_POLICY')} SWX_PG_BLOCKS={os.environ.get('SWX_PG_BLOCKS')}")
 
     if args.only in ("", "gemm"):
-        print("-- tiled MFMA GEMM (encoder / cross-KV / scoring shapes), f16, bias epilogue")
+        print(f"-- tiled MFMA GEMM (encoder / cross-KV / scoring shapes), f16, bias epilogue, force_kernel={args.gemm_kernel}")
         for M, N, K in [(30000, 1280, 1280), (30000, 3840, 1280), (30000, 5120, 1280), (30000, 1280, 5120), (30000, 2560, 1280),
                         (2240, 1280, 1280), (2240, 5120, 1280), (100, 51866, 1280)]:
             a, w, c = rnd(M, K), rnd(N, K), torch.empty(M, N, dtype=torch.half, device=dev)
             bias = torch.zeros(N, device=dev)
-            us = timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, 1, st), max(args.iters // 10, 5))
+            us = timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, args.gemm_kernel, st), max(args.iters // 10, 5))
             print(f"  M={M:6d} N={N:6d} K={K:5d}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s")
 
     if args.only in ("", "flash"):

@@ -43,6 +43,71 @@ constexpr int BM = 128, BN = 128;
 constexpr int BK16 = 64, LD16 = BK16 + 8;   // halfs; 144-byte rows keep every fragment read 16-byte aligned
 constexpr int CLD = BN + 4;                 // f32 staging row of the epilogue
 
+// Epilogue shared by the tiled f16 kernels: special layouts element-wise, otherwise accumulators -> f32 tile in LDS ->
+// 16-byte row-contiguous stores (bias / GELU / residual applied in f32).  `smem` must hold 128 x CLD floats.
+__device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][4], int m0, int n0,
+                                                  int tid, int lane, int wm, int wn)
+{
+    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const bool plain = !(g.epi & (EPI_STORE_VT | EPI_CBATCH | EPI_OUT_F32 | EPI_RESF32MOD)) && (g.ldc % 8 == 0) &&
+                       (!(g.epi & EPI_RES) || g.ldr % 8 == 0);
+    if (!plain) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
+        return;
+    }
+    // coalesced epilogue: accumulators -> f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32)
+    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 128 x 132 x 4 B = 67.6 KB <= 73.7 KB
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[wm * 64 + i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = tid + 256 * it, row = c >> 4, c8 = (c & 15) * 8;
+        const int gm = m0 + row, gn = n0 + c8;
+        if (gm >= g.M || gn >= g.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Cs[row][c8 + e];
+        const bool full = gn + 8 <= g.N;
+        if (g.epi & EPI_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || gn + e < g.N) v[e] += g.bias[gn + e];
+        }
+        if (g.epi & EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
+        if (full) {
+            if (g.epi & EPI_RES) {
+                const f16x8 rv = *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+            *(f16x8 *)cp = o;
+        } else {
+            for (int e = 0; e < 8 && gn + e < g.N; ++e) {
+                float t = v[e];
+                if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
+                cp[e] = (f16)t;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 {
     // one allocation: [A tiles | B tiles] during the K loop, reused as the f32 C tile of the coalesced epilogue
@@ -107,64 +172,96 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
         __syncthreads();
     }
 
-    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
-    const bool plain = !(g.epi & (EPI_STORE_VT | EPI_CBATCH | EPI_OUT_F32 | EPI_RESF32MOD)) && (g.ldc % 8 == 0) &&
-                       (!(g.epi & EPI_RES) || g.ldr % 8 == 0);
-    if (!plain) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
-        return;
+    tile_epilogue_f16(g, smem, acc, m0, n0, tid, lane, wm, wn);
+}
+
+// ------------------------------------------------------------------------------------- tiled f16, direct-to-LDS
+// Same 128 x 128 x 64 tile and 4 x 4 accumulator grid per wave as gemm_f16_tiled, but the operand tiles go
+// global -> LDS with `global_load_lds` (16 bytes per lane, 1 KiB per wave instruction): no staging VGPRs and no
+// ds_write pass, which is what bounds the register-staged kernel (8 ds_write_b128 per thread and K tile at ~79 B/clk/CU
+// are as many LDS cycles as the tile's MFMAs; cdna_hip_programming.md section 5, ladder step 2 -> 3).
+// LDS image: a wave instruction writes base + lane * 16, i.e. 8 consecutive 128-byte tile rows; rows are NOT padded.
+// Bank conflicts of the fragment reads (16 lanes = 16 tile rows at one 16-byte column slot) are removed by an XOR swizzle
+// of the slot with (row >> 1) & 7, applied on the SOURCE address of the load (the LDS destination is fixed by the
+// hardware) and on the read address.  Blocks are renumbered so that each XCD (private L2) works on neighbouring tiles.
+// Requires K % 64 == 0; rows past M / N are clamped to the last valid row (their results are never stored).
+constexpr int GL_TILE = 128 * 128;          // bytes of one operand tile: 128 rows x 64 halfs
+constexpr int GL_SMEM = 128 * CLD * 4 > 4 * GL_TILE ? 128 * CLD * 4 : 4 * GL_TILE;
+
+__global__ __launch_bounds__(256) void gemm_f16_glds(GemmArgs g)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[GL_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // XCD-aware, bijective renumbering of the workgroups (consecutive ids go to different XCDs in hardware)
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = wg % gx; by = wg / gx;
     }
-    // coalesced epilogue: accumulators -> f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32)
-    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 128 x 132 x 4 B = 67.6 KB <= 73.7 KB
+    const int m0 = by * BM, n0 = bx * BN;
+    const f16 *A = (const f16 *)g.A;
+    const f16 *W = (const f16 *)g.W;
+
+    f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane source rows of the four 8-row chunks this wave stages per operand (chunk = wave * 4 + c)
+    const f16 *srcA[4], *srcW[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[wm * 64 + i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int c = tid + 256 * it, row = c >> 4, c8 = (c & 15) * 8;
-        const int gm = m0 + row, gn = n0 + c8;
-        if (gm >= g.M || gn >= g.N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Cs[row][c8 + e];
-        const bool full = gn + 8 <= g.N;
-        if (g.epi & EPI_BIAS) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || gn + e < g.N) v[e] += g.bias[gn + e];
-        }
-        if (g.epi & EPI_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        }
-        f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
-        if (full) {
-            if (g.epi & EPI_RES) {
-                const f16x8 rv = *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-            }
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-            *(f16x8 *)cp = o;
-        } else {
-            for (int e = 0; e < 8 && gn + e < g.N; ++e) {
-                float t = v[e];
-                if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
-                cp[e] = (f16)t;
-            }
-        }
+    for (int c = 0; c < 4; ++c) {
+        const int r = (wave * 4 + c) * 8 + (lane >> 3);          // tile row of this lane's 16 bytes
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);             // logical 16-byte column slot it must fetch
+        const int gm = m0 + r < g.M ? m0 + r : g.M - 1, gn = n0 + r < g.N ? n0 + r : g.N - 1;
+        srcA[c] = A + (size_t)gm * g.lda + slot * 8;
+        srcW[c] = W + (size_t)gn * g.ldw + slot * 8;
     }
+    typedef __attribute__((address_space(3))) void lds_void;
+    auto stage = [&](int kt, int buf) {
+        unsigned char *ta = smem + buf * 2 * GL_TILE, *tb = ta + GL_TILE;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int off = (wave * 4 + c) * 1024;                // wave-uniform LDS base of the chunk
+            __builtin_amdgcn_global_load_lds(srcA[c] + kt * 64, (lds_void *)(ta + off), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(srcW[c] + kt * 64, (lds_void *)(tb + off), 16, 0, 0);
+        }
+    };
+
+    const int KT = g.K / 64;
+    const int fr = lane & 15, fs = lane >> 4;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+        const unsigned char *ta = smem + cur * 2 * GL_TILE, *tb = ta + GL_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                a[i] = *(const f16x8 *)(ta + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + fr;
+                b[j] = *(const f16x8 *)(tb + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();          // also drains this iteration's direct-to-LDS loads (vmcnt) before the next tile is read
+    }
+    tile_epilogue_f16(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------ tiled f32
@@ -676,7 +773,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
     if (dtype == SWX_F16) {
         if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;   // tiled: K % 32, skinny: K % 128
         const bool skinny_ok = g.M <= 128 && g.K % 128 == 0 && g.K / 128 <= 10 && g.N <= 16384;   // vocabulary-sized N: tiled
-        const bool use_skinny = force_kernel == 2 ? skinny_ok : (force_kernel == 1 ? false : skinny_ok);
+        const bool use_skinny = force_kernel == 2 ? skinny_ok : ((force_kernel == 1 || force_kernel == 4) ? false : skinny_ok);
         if (force_kernel == 2 && !skinny_ok) return -4;
         if (use_skinny) {
             SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * ((g.epi & EPI_OUT_F32) ? 4 : 2), s);
@@ -695,7 +792,12 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
         } else {
             SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
             dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
-            hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
+            const bool glds_ok = g.K % 64 == 0 && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0);
+            if (force_kernel == 4 && !glds_ok) return -4;
+            if (glds_ok && (force_kernel == 4 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
+                hipLaunchKernelGGL(gemm_f16_glds, grid, dim3(256), 0, s, g);
+            else
+                hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
         }
     } else {
         if (g.K % 16 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return -4;

@@ -35,6 +35,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_FUSE_SELF 16       // self-attention finishes q|k|v from the split-K slabs, appends K/V and attends in one launch
 #define SWX_FLAG_FUSE_CROSS_Q 64    // cross-attention finishes q from the split-K slabs (no finish launch for the query projection)
 #define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
+#define SWX_FLAG_GLDS_GEMM 256     // tiled f16 GEMM (encoder, cross-KV, scoring): direct-to-LDS operand staging (global_load_lds)
 #define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q)
 int swx_flags();
 

@@ -1,0 +1,57 @@
+"""Hardware check of the direct-to-LDS tiled GEMM (gemm_f16_glds, force_kernel = 4): it runs the same MFMA sequence per
+accumulator as gemm_f16_tiled (force_kernel = 1), so the two must agree BIT FOR BIT; both are also held to a torch fp32
+reference.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
+
+    python tests/hw_checks/gemm_glds_check.py
+"""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+EPI_BIAS, EPI_GELU, EPI_RES = 1, 2, 4
+
+
+def main() -> int:
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    _lib.require_gpu()
+    dev = "cuda:0"
+    g = torch.Generator(device="cpu").manual_seed(1)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    bad = 0
+    for (M, N, K, epi) in [(128, 128, 64, 0), (300, 384, 384, EPI_BIAS), (1500, 1280, 1280, EPI_BIAS | EPI_GELU),
+                           (1000, 1152, 3840, EPI_BIAS | EPI_RES), (3000, 1000, 1280, EPI_BIAS), (257, 5120, 5120, EPI_BIAS | EPI_RES),
+                           (4500, 3840, 1280, EPI_BIAS)]:
+        a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
+        w = (torch.randn(N, K, generator=g) * 0.03).half().to(dev)
+        bias = torch.randn(N, generator=g).float().to(dev)
+        res = torch.randn(M, N, generator=g).half().to(dev)
+        outs = []
+        for force in (1, 4):
+            c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
+            rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), p(res) if epi & EPI_RES else None, p(c), N, M, N, K, epi, force, st)
+            torch.cuda.synchronize()
+            outs.append((rc, c))
+        ref = a.float() @ w.float().t()
+        if epi & EPI_BIAS:
+            ref = ref + bias
+        if epi & EPI_GELU:
+            ref = torch.nn.functional.gelu(ref)
+        if epi & EPI_RES:
+            ref = ref + res.float()
+        (rc1, c1), (rc4, c4) = outs
+        same = rc1 == 0 and rc4 == 0 and torch.equal(c1, c4)
+        err = ((c4.float() - ref).abs() / (ref.abs() + 1.0)).max().item() if rc4 == 0 else float("inf")
+        ok = same and err < 4e-3
+        print(("ok   " if ok else "FAIL ") + f"M={M} N={N} K={K} epi={epi}: rc={rc1},{rc4} identical to tiled={same} max rel err vs fp32 {err:.2e}")
+        bad += not ok
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
