@@ -43,8 +43,9 @@ constexpr int BM = 128, BN = 128;
 constexpr int BK16 = 64, LD16 = BK16 + 8;   // halfs; 144-byte rows keep every fragment read 16-byte aligned
 constexpr int CLD = BN + 4;                 // f32 staging row of the epilogue
 
-// Epilogue shared by the tiled f16 kernels: special layouts element-wise, otherwise accumulators -> f32 tile in LDS ->
-// 16-byte row-contiguous stores (bias / GELU / residual applied in f32).  `smem` must hold 128 x CLD floats.
+// Epilogue of the direct-to-LDS kernel below (the same code as gemm_f16_tiled's inline epilogue, which stays textually
+// untouched until this variant has been validated on hardware): special layouts element-wise, otherwise accumulators ->
+// f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32).  `smem` must hold 128 x CLD floats.
 __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][4], int m0, int n0,
                                                   int tid, int lane, int wm, int wn)
 {
@@ -172,7 +173,64 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
         __syncthreads();
     }
 
-    tile_epilogue_f16(g, smem, acc, m0, n0, tid, lane, wm, wn);
+    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const bool plain = !(g.epi & (EPI_STORE_VT | EPI_CBATCH | EPI_OUT_F32 | EPI_RESF32MOD)) && (g.ldc % 8 == 0) &&
+                       (!(g.epi & EPI_RES) || g.ldr % 8 == 0);
+    if (!plain) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
+        return;
+    }
+    // coalesced epilogue: accumulators -> f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32)
+    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 128 x 132 x 4 B = 67.6 KB <= 73.7 KB
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[wm * 64 + i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = tid + 256 * it, row = c >> 4, c8 = (c & 15) * 8;
+        const int gm = m0 + row, gn = n0 + c8;
+        if (gm >= g.M || gn >= g.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Cs[row][c8 + e];
+        const bool full = gn + 8 <= g.N;
+        if (g.epi & EPI_BIAS) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (full || gn + e < g.N) v[e] += g.bias[gn + e];
+        }
+        if (g.epi & EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
+        if (full) {
+            if (g.epi & EPI_RES) {
+                const f16x8 rv = *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+            *(f16x8 *)cp = o;
+        } else {
+            for (int e = 0; e < 8 && gn + e < g.N; ++e) {
+                float t = v[e];
+                if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
+                cp[e] = (f16)t;
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------- tiled f16, direct-to-LDS
@@ -434,7 +492,7 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
 // whole slice from HBM up front.  Partial sums go to f32 slabs (deterministic split-K), finished by splitk_finish_f16.
 constexpr int PG_LD = 72;        // halfs per LDS row
 constexpr int PG_MAXIT = 20;     // 64-wide K chunks per workgroup slice, upper bound (launcher picks the <= 5, <= 10 or <= 20 build)
-template <int MT, int MAXIT>
+template <int MT, int MAXIT, bool DIRECT>
 __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int64_t slab_stride, int ks2, int flags)
 {
     __shared__ __attribute__((aligned(16))) f16 As[2][MT * 16][PG_LD];
@@ -494,7 +552,7 @@ __global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int
         }
     }
     const int col = blockIdx.x * 64 + wave * 16 + (lane & 15), row_l = (lane >> 4) * 4;
-    if (!(g.epi & EPI_OUT_F32)) {
+    if constexpr (DIRECT) {
         // un-split K (ks2 == 1): the workgroup owns the finished sums, so bias / GELU are applied here and the compute
         // dtype is stored directly -- no slab, no finish launch.  Same arithmetic as splitk_finish_f16 on one slab.
         if (col < g.N) {
@@ -709,9 +767,10 @@ int pg_launch(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int
     dim3 grid(cdiv(N, 64), ks2);
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)N * K + (double)M * K) + (double)M * N * 2, s);
     const int nit = K / (64 * ks2);           // K slice per workgroup in 64-wide chunks: <= 5 (default tuning), <= 10 or <= 20
-#define SWX_PG(MT) do { if (nit > 10) hipLaunchKernelGGL((gemm_f16_pg<MT, 20>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
-                        else if (nit > 5) hipLaunchKernelGGL((gemm_f16_pg<MT, 10>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
-                        else hipLaunchKernelGGL((gemm_f16_pg<MT, 5>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); } while (0)
+#define SWX_PG2(MT, DIR) do { if (nit > 10) hipLaunchKernelGGL((gemm_f16_pg<MT, 20, DIR>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
+                              else if (nit > 5) hipLaunchKernelGGL((gemm_f16_pg<MT, 10, DIR>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
+                              else hipLaunchKernelGGL((gemm_f16_pg<MT, 5, DIR>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); } while (0)
+#define SWX_PG(MT) do { if (direct) SWX_PG2(MT, true); else SWX_PG2(MT, false); } while (0)
     switch (cdiv(M, 16)) {
         case 1: SWX_PG(1); break;
         case 2: SWX_PG(2); break;
@@ -723,6 +782,7 @@ int pg_launch(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int
         default: SWX_PG(8); break;
     }
 #undef SWX_PG
+#undef SWX_PG2
     if (ref) { ref->slabs = slabs; ref->ks2 = ks2; ref->stride = stride; ref->N = N; ref->bias = nullptr; }
     return 0;
 }
