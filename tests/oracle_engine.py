@@ -1,0 +1,142 @@
+"""TEST INFRASTRUCTURE ONLY: a CPU stand-in for stable_ts_amd.engine.Engine / model.Whisper built on the oracle, so that
+the HOST side of transcribe() (window state machine, temperature ladder, prompt handling, segment slicing, word
+bookkeeping, silence suppression, regrouping) can be compared with the reference's own transcribe() on CPU -- the device
+arithmetic is the same oracle on both sides, so any difference is a host-logic difference.  Never imported by the product.
+"""
+import types
+from dataclasses import replace
+
+import numpy as np
+import torch
+
+from oracle import stable as ost
+from oracle.whisper.audio import N_FRAMES, N_SAMPLES, log_mel_spectrogram, pad_or_trim
+from oracle.whisper.decoding import DecodingOptions
+from oracle.whisper.timing import dtw as oracle_dtw
+from oracle.whisper.tokenizer import get_tokenizer
+
+
+class XKV:
+    """stands in for the device cross-KV buffer: keeps the encoder output of the batch"""
+
+    def __init__(self, xa: torch.Tensor):
+        self.xa = xa
+        self.n_windows = int(xa.shape[0])
+
+    def select(self, idx):
+        return XKV(self.xa[list(idx)])
+
+
+class OracleEngine:
+    tdtype = torch.float32
+    dtype_name = "f32"
+    device = torch.device("cpu")
+
+    def __init__(self, oracle_model):
+        self.m = oracle_model
+        self.dims = oracle_model.dims
+        self.tok = get_tokenizer(oracle_model.is_multilingual, num_languages=oracle_model.num_languages, language="en",
+                                 task="transcribe")
+        self.n_decode_calls = 0
+
+    def cross_kv(self, xa):
+        return XKV(xa)
+
+    @torch.no_grad()
+    def decode(self, xkv, init_tokens, *, n_group=1, beam=False, temperature=0.0, patience=None, sample_len=224,
+               sot_index=0, suppress_blank=True, apply_timestamp_rules=True, max_initial_timestamp_index=None, eot=0, sot=0,
+               no_timestamps=-1, timestamp_begin=0, no_speech=-1, blank_token=-1, suppress_tokens=(), ts_mask=None,
+               min_tokens=0, seed=0):
+        self.n_decode_calls += 1
+        W = xkv.n_windows
+        TS = self.dims.n_text_ctx + 1
+        toks = np.zeros((W, 1, TS), dtype=np.int32)
+        lens = np.zeros((W, 1), dtype=np.int32)
+        slp = np.zeros((W, 1), dtype=np.float32)
+        nsp = np.zeros(W, dtype=np.float32)
+        opts = DecodingOptions(
+            fp16=False, language="en", temperature=temperature, sample_len=sample_len,
+            beam_size=n_group if beam else None, best_of=(n_group if (not beam and n_group > 1) else None),
+            patience=patience, suppress_blank=suppress_blank, suppress_tokens=list(suppress_tokens),
+            without_timestamps=not apply_timestamp_rules,
+            max_initial_timestamp=(None if max_initial_timestamp_index is None else max_initial_timestamp_index * 0.02))
+        for w in range(W):
+            init = tuple(int(t) for t in init_tokens[w])
+
+            class _Task(ost.DecodingTaskStable):
+                def _get_initial_tokens(self_inner):
+                    return init
+
+            mask = None if ts_mask is None else ts_mask[w].bool()
+            task = _Task(self.m, opts, ts_token_mask=mask, audio_features=xkv.xa[w:w + 1])
+            assert task.sot_index == sot_index and task.sample_begin == len(init)
+            if min_tokens:
+                pos = len(task.logit_filters) - (0 if opts.without_timestamps else 1)
+                task.logit_filters.insert(pos, ost._MinTokens(task.tokenizer.eot, task.sample_begin, min_tokens))
+            r = task.run(torch.zeros(1, self.dims.n_mels, N_FRAMES))[0]
+            n = len(r.tokens)
+            toks[w, 0, len(init): len(init) + n] = r.tokens
+            lens[w, 0] = n
+            slp[w, 0] = r.avg_logprob * (n + 1)
+            nsp[w] = r.no_speech_prob
+        return dict(tokens=toks, lens=lens, sum_logprobs=slp, no_speech_prob=nsp, steps=sample_len, sample_begin=len(init_tokens[0]))
+
+    @torch.no_grad()
+    def score(self, xkv, tokens, n_frames, n_sot, eot, qk_scale=1.0, medfilt_width=7):
+        W = len(tokens)
+        max_n = max(len(t) for t in tokens)
+        neg = torch.zeros(W, max_n, self.dims.n_audio_ctx)
+        probs, T = [], []
+        for w, tk in enumerate(tokens):
+            text = list(tk[n_sot + 1:-1])
+            cache = dict(audio_features=xkv.xa[w:w + 1], qks=None, text_token_probs=None, jump_indices=None)
+            tt = torch.tensor(list(tk))
+            weights = ost.compute_atten_weights(self.m, self.tok, text, None, n_frames[w] * 320, tt, cache,
+                                                medfilt_width=medfilt_width, qk_scale=qk_scale)
+            mat = -weights.mean(dim=0)                               # [T + 1, n_frames]
+            neg[w, :mat.shape[0], :mat.shape[1]] = mat
+            probs.append([float(p) for p in cache["text_token_probs"]])
+            T.append(len(text))
+        return probs, neg, T
+
+    def dtw(self, neg, N, M):
+        out = []
+        for w in range(neg.shape[0]):
+            ti, tj = oracle_dtw(neg[w, :N[w], :M[w]])
+            out.append((np.asarray(ti), np.asarray(tj)))
+        return out
+
+
+class CpuWhisper:
+    """the attributes and methods of stable_ts_amd.model.Whisper that the host code reads"""
+
+    def __init__(self, oracle_model):
+        from stable_ts_amd.transcribe import transcribe_stable
+        self.om = oracle_model
+        self.dims = oracle_model.dims
+        self.is_multilingual = oracle_model.is_multilingual
+        self.num_languages = oracle_model.num_languages
+        self.device = torch.device("cpu")
+        self.engine = OracleEngine(oracle_model)
+        self.transcribe = types.MethodType(transcribe_stable, self)
+
+    def log_mel_batch(self, audios, paddings=None):
+        out = []
+        for b, a in enumerate(audios):
+            pad = 0 if paddings is None else paddings[b]
+            assert a.shape[-1] + pad == N_SAMPLES
+            out.append(pad_or_trim(log_mel_spectrogram(torch.as_tensor(a, dtype=torch.float32), self.dims.n_mels, padding=pad), N_FRAMES))
+        return torch.stack(out)
+
+    @torch.no_grad()
+    def encoder(self, mel):
+        return self.om.encoder(mel)
+
+    def cross_kv(self, xa):
+        return XKV(xa)
+
+
+def install(monkeypatch):
+    """route the product's device-buffer helper to the stand-in's"""
+    import stable_ts_amd.transcribe as T
+    monkeypatch.setattr(T, "_xkv_select", lambda model, xkv, idx: xkv.select(idx))

@@ -1,0 +1,83 @@
+"""The HOST side of transcribe() against the reference's own transcribe() on CPU.
+
+Both run on the same CPU oracle model (tests/oracle_engine.py stands in for the GPU engine; the reference's glue runs on
+oracle/whisper registered as `whisper`), so every difference would be a difference of the host logic: the window state
+machine, the temperature ladder and its thresholds, prompt / prefix handling, segment slicing by timestamp tokens, word
+bookkeeping, silence suppression and the default regrouping.  Needs /root/reference (this container only); the GPU
+golden tests cover the same path end to end on the device."""
+import os
+import sys
+import warnings
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
+
+BASE = dict(temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None, sample_len=36)
+CASES = {
+    "defaults_regroup": dict(),
+    "no_condition": dict(condition_on_previous_text=False),
+    "prompt": dict(initial_prompt=" aaat aaau aaax"),
+    "segment_level": dict(word_timestamps=False),
+    "no_silence": dict(suppress_silence=False, regroup=False),
+    "beam3": dict(beam_size=3),
+    "thresholds": dict(compression_ratio_threshold=2.4, logprob_threshold=-40.0, no_speech_threshold=0.6),
+    "ts_tokens": dict(suppress_ts_tokens=True, regroup=False),
+    "word_opts": dict(min_word_dur=0.2, gap_padding=None, regroup="sg=.3_mg=.2+3"),
+    "avg_prob": dict(avg_prob_threshold=0.00002, max_instant_words=0.2, regroup=False),
+    "nonspeech_skip": dict(nonspeech_skip=0.4, regroup=False),
+    "prefix_suppress": dict(prefix=" aaaw", suppress_tokens="1,2,19"),
+    "silence_opts": dict(use_word_position=False, suppress_word_ts=False, nonspeech_error=0.3, min_silence_dur=0.2, q_levels=10, k_size=3),
+    "ladder_not_taken": dict(temperature=(0.0, 0.4), compression_ratio_threshold=50.0, logprob_threshold=-60.0),
+    "punct_sets": dict(prepend_punctuations="(", append_punctuations=".,?", regroup="sp=./?"),
+}
+
+
+def _snap(res):
+    out = []
+    for s in res.segments:
+        ws = None if not s.has_words else [(w.word, w.start, w.end, round(float(w.probability), 9), list(w.tokens)) for w in s.words]
+        out.append((s.start, s.end, s.text, None if s.seek is None else round(float(s.seek), 3), ws))
+    return out
+
+
+@pytest.fixture(scope="module")
+def models():
+    import make_golden as G
+    sw = G.import_reference()
+    from oracle.whisper.model import build_model
+    m = build_model("tiny.en", seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5)
+    sw.modify_model(m)
+    from oracle_engine import CpuWhisper
+    return G, m, CpuWhisper(m)
+
+
+LONG = {"defaults_regroup": (97.0, 60), "no_condition": (83.0, 48), "thresholds": (75.0, 60), "prompt": (66.0, 48),
+        "nonspeech_skip": (91.0, 40), "avg_prob": (88.0, 40)}
+
+
+@pytest.mark.parametrize("name", list(CASES) + [k + "+long" for k in LONG])
+def test_transcribe_host_logic_matches_reference(models, monkeypatch, name):
+    G, ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    key = name.split("+")[0]
+    opts = dict(BASE, **CASES[key])
+    seconds = 41.0
+    if name.endswith("+long"):                  # more windows: seek / prompt carry-over paths get exercised repeatedly
+        seconds, opts["sample_len"] = LONG[key]
+    audio = G.synth_audio(seconds, seed=7 + len(name))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **opts)
+        got = mine.transcribe(audio, language="en", **opts)
+    assert _snap(got) == _snap(want)
+    assert len(want.segments) > 0 and len(_snap(want)) == len(want.segments)
+    assert got.regroup_history == want.regroup_history
+    assert [(round(d["start"], 3), round(d["end"], 3)) for d in got.nonspeech_sections] == \
+        [(round(d["start"], 3), round(d["end"], 3)) for d in want.nonspeech_sections]
