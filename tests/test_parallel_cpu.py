@@ -53,3 +53,51 @@ def test_shard_windows_partition():
             flat = [i for p in parts for i in p]
             assert flat == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _sharded_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    from stable_ts_amd import parallel as par
+    import stable_ts_amd.transcribe as T
+    from make_golden import synth_audio
+    from oracle.whisper.model import build_model
+    from oracle_engine import CpuWhisper
+    T._xkv_select = lambda model, xkv, idx: xkv.select(idx)          # oracle-backed stand-in for the GPU engine (tests only)
+    par.init_from_env(backend="gloo")
+    model = CpuWhisper(build_model("tiny.en", seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5))
+    audio = synth_audio(100.0, seed=3)                                # 4 windows: ranks take [0, 1] and [2, 3]
+    kw = dict(language="en", temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None,
+              no_speech_threshold=None, sample_len=24, regroup=False)
+    res = par.transcribe_sharded(model, audio, batch_size=2, **kw)
+    out = None
+    if res is not None:
+        out = [(s.start, s.end, s.text, [(w.word, w.start, w.end) for w in s.words]) for s in res.segments]
+    single = None
+    if rank == 0:                                                     # the same recording on one rank, same window-parallel mode
+        one = model.transcribe(audio, batch_size=2, **kw)
+        single = [(s.start, s.end, s.text, [(w.word, w.start, w.end) for w in s.words]) for s in one.segments]
+    par.barrier()
+    q.put((rank, out, single))
+    dist.destroy_process_group()
+
+
+def test_sharded_transcribe_equals_single_rank():
+    """parallel.transcribe_sharded over 2 gloo ranks == the window-parallel transcribe of the whole recording on one rank
+    (windows are independent in that mode); runs the real host pipeline on the oracle-backed CPU stand-in."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, out0, single0), (_, out1, _single1) = got
+    assert out1 is None and out0 is not None and len(out0) > 0
+    assert out0 == single0
