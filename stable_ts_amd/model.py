@@ -223,6 +223,8 @@ class Whisper:
         self.align = types.MethodType(align, self)
         self.align_words = types.MethodType(align_words, self)
         self.refine = types.MethodType(refine, self)
+        from .locate import locate
+        self.locate = types.MethodType(locate, self)
 
 
 def _read_checkpoint(path: str):

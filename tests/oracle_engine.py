@@ -87,17 +87,35 @@ class OracleEngine:
         max_n = max(len(t) for t in tokens)
         neg = torch.zeros(W, max_n, self.dims.n_audio_ctx)
         probs, T = [], []
+        from oracle.whisper.model import disable_sdpa
+        from oracle.whisper.timing import median_filter
         for w, tk in enumerate(tokens):
             text = list(tk[n_sot + 1:-1])
-            cache = dict(audio_features=xkv.xa[w:w + 1], qks=None, text_token_probs=None, jump_indices=None)
-            tt = torch.tensor(list(tk))
-            weights = ost.compute_atten_weights(self.m, self.tok, text, None, n_frames[w] * 320, tt, cache,
-                                                medfilt_width=medfilt_width, qk_scale=qk_scale)
-            mat = -weights.mean(dim=0)                               # [T + 1, n_frames]
+            qks = [None] * self.dims.n_text_layer
+            hooks = [blk.cross_attn.register_forward_hook(lambda _, i, o, k=k: qks.__setitem__(k, o[-1]))
+                     for k, blk in enumerate(self.m.decoder.blocks)]
+            with disable_sdpa():
+                logits = self.m.decoder(torch.tensor([list(tk)]), xkv.xa[w:w + 1])[0]
+            for h in hooks:
+                h.remove()
+            p = logits[n_sot:, :eot].softmax(dim=-1)                 # timing.py:62-64; targets >= eot score 0 like the kernel
+            probs.append([float(p[i, t]) if t < eot else 0.0 for i, t in enumerate(text)])
+            wts = torch.cat([qks[l][:, h] for l, h in self.m.alignment_heads.indices().T], dim=0)
+            wts = wts[:, n_sot:-1, :n_frames[w]]
+            wts = (wts * qk_scale).softmax(dim=-1)
+            std, mean = torch.std_mean(wts, dim=-2, keepdim=True, unbiased=False)
+            mat = -median_filter((wts - mean) / std, medfilt_width).mean(dim=0)     # [rows, n_frames]
             neg[w, :mat.shape[0], :mat.shape[1]] = mat
-            probs.append([float(p) for p in cache["text_token_probs"]])
             T.append(len(text))
         return probs, neg, T
+
+    @torch.no_grad()
+    def forward_logits(self, xkv, tokens, pad_token=0):
+        n = max(len(t) for t in tokens)
+        out = torch.zeros(len(tokens), n, self.dims.n_vocab)
+        for w, t in enumerate(tokens):
+            out[w, :len(t)] = self.m.decoder(torch.tensor([list(t)]), xkv.xa[w:w + 1])[0]
+        return out
 
     def dtw(self, neg, N, M):
         out = []
@@ -127,6 +145,9 @@ class CpuWhisper:
             assert a.shape[-1] + pad == N_SAMPLES
             out.append(pad_or_trim(log_mel_spectrogram(torch.as_tensor(a, dtype=torch.float32), self.dims.n_mels, padding=pad), N_FRAMES))
         return torch.stack(out)
+
+    def log_mel(self, audio, padding=0):
+        return self.log_mel_batch([audio], [padding])[0]
 
     @torch.no_grad()
     def encoder(self, mel):
