@@ -223,7 +223,7 @@ class Whisper:
         self.align = types.MethodType(align, self)
         self.align_words = types.MethodType(align_words, self)
         self.refine = types.MethodType(refine, self)
-        from .locate import locate
+        from .locator import locate
         self.locate = types.MethodType(locate, self)
 
 

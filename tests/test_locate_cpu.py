@@ -1,4 +1,4 @@
-"""``locate()`` (stable_ts_amd/locate.py) against the reference's ``locate`` (stable_whisper/alignment.py:756-1116) on
+"""``locate()`` (stable_ts_amd/locator.py) against the reference's ``locate`` (stable_whisper/alignment.py:756-1116) on
 the CPU oracle through the engine stand-in (tests/oracle_engine.py): end-time approximation from the alignment matrix,
 the greedy duration-window decode with the search text forced in (probability / arg-max / string match, EOT budget,
 token budget), word timestamps of the match, and the seek logic between chunks.  Needs /root/reference."""
@@ -56,7 +56,7 @@ CASES = [
 def test_locate_matches_reference(models, monkeypatch, case):
     G, sw, ref_model, mine = models
     from oracle.whisper.audio import N_FRAMES, log_mel_spectrogram, pad_or_trim
-    import stable_ts_amd.locate as L
+    import stable_ts_amd.locator as L
     from oracle_engine import install
     install(monkeypatch)
     # the stand-in computes the chunk mel exactly as the reference does (the device path's documented last-frame
