@@ -10,7 +10,6 @@ the reference's own class on CPU (tests/test_aligner_cpu.py).
 """
 from typing import List, Optional, Sequence, Union
 
-import numpy as np
 import torch
 
 from .audio import HOP_LENGTH, N_SAMPLES, SAMPLE_RATE

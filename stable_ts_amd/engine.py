@@ -5,7 +5,7 @@ path is a libswx call.  Nothing here falls back to torch ops or to the CPU.
 """
 import ctypes
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 import torch

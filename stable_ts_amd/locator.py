@@ -17,7 +17,7 @@ exactly, including what its KV cache holds after a partly matched text is rolled
 and decoding continues from the single next token) -- observable behaviour, so it is kept.  Checked against the
 reference's ``locate`` on the CPU oracle through the engine stand-in (tests/test_locate_cpu.py).
 """
-from typing import List, Optional, Sequence, Tuple, Union
+from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import torch

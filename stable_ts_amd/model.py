@@ -4,13 +4,12 @@ backed by an ``Engine`` (libswx.so) instead of torch modules.
 """
 import os
 import types
-import warnings
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
 
-from .audio import N_FRAMES, N_SAMPLES
+from .audio import N_SAMPLES
 from .engine import Engine, ModelDimensions
 
 # upstream architecture table (whisper/__init__.py::_MODELS dims; facts)

@@ -7,7 +7,7 @@ collective on the data path.  Two collectives exist in total:
   * end: the per-window result records (a few KB of segments/words per window) are gathered to rank 0.
 """
 import os
-from typing import Any, List, Optional, Sequence
+from typing import Any, List, Optional
 
 import torch
 import torch.distributed as dist

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .audio import FRAMES_PER_SECOND, N_SAMPLES_PER_TOKEN, SAMPLE_RATE, TOKENS_PER_SECOND
+from .audio import FRAMES_PER_SECOND, N_SAMPLES_PER_TOKEN, TOKENS_PER_SECOND
 from .timing import APPEND_PUNCTUATIONS
 
 

@@ -4,8 +4,6 @@ bookkeeping, silence suppression, regrouping) can be compared with the reference
 arithmetic is the same oracle on both sides, so any difference is a host-logic difference.  Never imported by the product.
 """
 import types
-from dataclasses import replace
-
 import numpy as np
 import torch
 
