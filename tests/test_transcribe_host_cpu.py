@@ -81,3 +81,42 @@ def test_transcribe_host_logic_matches_reference(models, monkeypatch, name):
     assert got.regroup_history == want.regroup_history
     assert [(round(d["start"], 3), round(d["end"], 3)) for d in got.nonspeech_sections] == \
         [(round(d["start"], 3), round(d["end"], 3)) for d in want.nonspeech_sections]
+
+
+RICH = {
+    "rich_default": dict(max_instant_words=1.0),
+    "rich_no_regroup_beam": dict(max_instant_words=1.0, regroup=False, beam_size=2),
+    "rich_filters": dict(max_instant_words=0.8, avg_prob_threshold=0.00001, condition_on_previous_text=False),
+    "rich_segment_level": dict(word_timestamps=False),
+}
+
+
+@pytest.fixture(scope="module")
+def rich_models():
+    """weights whose text logits beat the timestamp mass (embed gain 5, timestamp rows x 0.01): ~50 text tokens per
+    window instead of mostly timestamp pairs, so the word-level bookkeeping sees long segments"""
+    import make_golden as G
+    sw = G.import_reference()
+    from oracle.whisper.model import build_model
+    m = build_model("tiny.en", seed=4321, std=0.02, embed_gain=5.0, ts_gain=0.01)
+    sw.modify_model(m)
+    from oracle_engine import CpuWhisper
+    return G, m, CpuWhisper(m)
+
+
+@pytest.mark.parametrize("name", list(RICH))
+def test_transcribe_host_logic_on_long_segments(rich_models, monkeypatch, name):
+    G, ref_model, mine = rich_models
+    from oracle_engine import install
+    install(monkeypatch)
+    opts = dict(BASE, **RICH[name])
+    opts["sample_len"] = 64
+    audio = G.synth_audio(68.0, seed=23 + len(name))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **opts)
+        got = mine.transcribe(audio, language="en", **opts)
+    assert _snap(got) == _snap(want)
+    assert got.regroup_history == want.regroup_history
+    n_words = sum(len(s.words) for s in want.segments if s.has_words)
+    assert len(want.segments) > 0 and (n_words >= 60 or not opts.get("word_timestamps", True))
