@@ -378,6 +378,266 @@ def pad_parts(parts: list, start_pad: Optional[float], end_pad: Optional[float],
                 p.end = new_end
 
 
+# -------------------------------------------------------------------------------------------------- word edits
+def _norm_words(texts: List[str], strip: bool, ignore_punctuations: str, case_sensitive: bool) -> List[str]:
+    if strip:
+        texts = [w.strip() for w in texts]
+    if ignore_punctuations:
+        ptn = f"[{ignore_punctuations}]+$"
+        texts = [re.sub(ptn, "", w) for w in texts]
+    if not case_sensitive:
+        texts = [w.lower() for w in texts]
+    return texts
+
+
+def remove_repetition(result: WhisperResult, max_words: int, case_sensitive: bool, strip: bool, ignore_punctuations: str,
+                      extend_duration: bool):
+    """result.py:2238-2326 -- delete immediate repeats of runs of 1..max_words words (right to left), optionally
+    stretching the word before the repeat over it; of two copies the one with the longer text survives in place."""
+    for count in range(1, max_words + 1):
+        words = result.all_words()
+        if len(words) < 2:
+            return
+        texts = _norm_words([w.word for w in words], strip, ignore_punctuations, case_sensitive)
+        resume_at = None
+        for i in reversed(range(count * 2, len(texts) + 1)):
+            if resume_at is not None:
+                if resume_at != i:
+                    continue
+                resume_at = None
+            s0 = i - count
+            if texts[s0 - count:s0] != texts[s0:i]:
+                continue
+            resume_at = s0
+            if extend_duration:
+                words[s0 - 1].end = words[i - 1].end
+            for j in reversed(range(s0, i)):
+                result.remove_word(words[j], False, verbose=False, record=False)
+            for i0, i1 in zip(range(s0 - count, s0), range(s0, i)):
+                if len(words[i0].word) < len(words[i1].word):
+                    words[i1].start, words[i1].end = words[i0].start, words[i0].end
+                    result.segments[words[i0].segment_id].words[words[i0].id] = words[i1]
+        result.remove_no_word_segments(reassign_ids=False)
+    result.reassign_ids()
+
+
+def remove_words_by_str(result: WhisperResult, words, case_sensitive: bool, strip: bool, ignore_punctuations: str,
+                        min_prob: Optional[float], filters: Optional[Callable]):
+    """result.py:2328-2405."""
+    all_words = result.all_words()
+    texts = _norm_words([w.word for w in all_words], strip, ignore_punctuations, case_sensitive)
+    targets = None if words is None else _norm_words(list(words), strip, ignore_punctuations, case_sensitive)
+    for i, t in reversed(list(enumerate(texts))):
+        if not (targets is None or any(t == x for x in targets)):
+            continue
+        w = all_words[i]
+        if (min_prob is None or w.probability is None or min_prob > w.probability) and (filters is None or filters(w)):
+            result.remove_word(w, False, verbose=False, record=False)
+    result.remove_no_word_segments()
+
+
+def fill_in_gaps(result: WhisperResult, other: WhisperResult, min_gap: float, case_sensitive: bool, strip: bool,
+                 ignore_punctuations: str):
+    """result.py:2407-2513 -- words of `other` that fall into gaps (> min_gap) between this result's segments are
+    inserted as new segments; a gap word equal to the neighbouring word only extends that neighbour."""
+    def key(w: str) -> str:
+        return _norm_words([w], strip, ignore_punctuations, case_sensitive)[0]
+
+    segs = result.segments
+    pairs = [(-1, (None, segs[0]))] + list(enumerate(zip(segs[:-1], segs[1:])))
+    pairs.append((pairs[-1][0] + 1, (segs[-1], None)))
+    for i, (left, right) in reversed(pairs):
+        first = None if left is None else left.words[-1]
+        last = None if right is None else right.words[0]
+        start = other[0].start if first is None else first.end
+        end = other[-1].end if last is None else last.start
+        if end - start <= min_gap:
+            continue
+        gap = other.get_content_by_time((start, end))
+        if first is not None and gap and key(first.word) == key(gap[0].word):
+            first.end = gap[0].end
+            gap = gap[1:]
+        if last is not None and gap and key(last.word) == key(gap[-1].word):
+            last.start = gap[-1].start
+            gap = gap[:-1]
+        if not gap:
+            continue
+        if last is not None and last.start < gap[-1].end:
+            last.start = gap[-1].end
+        new_segs = [other[gap[0].segment_id].spawn([])]
+        for j, w in enumerate(gap):
+            c = w.copy(copy_tokens=True)
+            if j == 0 and first is not None and first.end > gap[0].start:
+                c.start = first.end
+            if new_segs[-1].id != w.segment_id:
+                new_segs.append(other[w.segment_id].spawn([]))
+            new_segs[-1].words.append(c)
+        result.segments = result.segments[:i + 1] + new_segs + result.segments[i + 1:]
+    result.reassign_ids()
+
+
+def adjust_gaps(result: WhisperResult, duration_threshold: float, one_section: bool):
+    """result.py:2515-2628 -- move the end of each segment / start of the next to the boundaries of the dominant
+    non-speech section(s) detected between them."""
+    if duration_threshold > 1:
+        raise ValueError(f"``duration_threshold`` must be at most 1.0 but got {duration_threshold}")
+    segs = result.segments
+    ns_idx = 0
+    for si in range(-1, len(segs)):
+        curr = None if si == -1 else segs[si]
+        nxt = None if curr is segs[-1] else segs[si + 1]
+        cs = ce = ns = ne = None
+        if result.has_words:
+            if curr is None:
+                d = np.median([w.duration for w in nxt.words]) * 2
+                cs = ce = max(nxt.start - d, 0)
+            if nxt is None:
+                d = np.median([w.duration for w in curr.words]) * 2
+                ns = ne = curr.end + d
+            if curr is not None:
+                curr = curr.words[-1]
+            if nxt is not None:
+                nxt = nxt.words[0]
+        else:
+            if curr is None:
+                cs = ce = max(nxt.start - nxt.duration, 0)
+            if nxt is None:
+                ns = ne = curr.end + curr.duration
+        cs = curr.start if cs is None else cs
+        ce = curr.end if ce is None else ce
+        ns = nxt.start if ns is None else ns
+        ne = nxt.end if ne is None else ne
+        sections: List[Tuple[float, float]] = []
+        for ns_idx in range(ns_idx, len(result.nonspeech_sections)):
+            sec = result.nonspeech_sections[ns_idx]
+            a, b = sec["start"], sec["end"]
+            if cs < (b if curr is None else a) and (a if nxt is None else b) < ne:
+                sections.append((a, b))
+            if ns < a:
+                break
+        if not sections:
+            continue
+        durs = np.array([b - a for a, b in sections])
+        order = np.argsort(durs)
+        durs = durs[order]
+        ok = durs / durs[-1] >= duration_threshold
+        if not np.any(ok):
+            continue
+        order = order[ok]
+        c_scores = np.array([abs(sections[k][0] - ce) for k in order])
+        n_scores = np.array([abs(sections[k][1] - ns) for k in order])
+        if one_section:
+            bc = bn = order[np.argmin(c_scores + n_scores)]
+        else:
+            bc, bn = order[np.argmin(c_scores)], order[np.argmin(n_scores)]
+            if bc > bn:
+                bc = bn = order[np.argmin(c_scores + n_scores)]
+        new_end = sections[bc][0]
+        if curr is not None and cs < new_end:
+            curr.end = new_end
+        new_start = sections[bn][1]
+        if nxt is not None and new_start < ne:
+            nxt.start = new_start
+
+
+_OPERATORS = {"==": lambda a, b: a == b, ">": lambda a, b: a > b, ">=": lambda a, b: a >= b, "<": lambda a, b: a < b,
+              "<=": lambda a, b: a <= b, "is": lambda a, b: a is b, "in": lambda a, b: a in b, "start": str.startswith,
+              "end": str.endswith}
+_ACTIONS = ("mergeleft", "mergeright", "merge", "lockright", "lockleft", "lock", "splitright", "splitleft", "split",
+            "remove")
+
+
+def custom_operation(result: WhisperResult, key: str, operator, value, method, word_level: Optional[bool]):
+    """result.py:2653-2891 -- apply merge / lock / split / remove (or a callable) to every word or segment whose
+    attribute `key` satisfies `operator(attribute, value)`, right to left.  Returns the strings for the history entry."""
+    if result.has_words:
+        if word_level is None:
+            word_level = True
+    elif word_level:
+        raise ValueError("result is missing word timestamps and not compatible with ``word_level=True``")
+    value = result._get_content(value, strict=False)
+    method = result._get_content(method)
+    builtin = isinstance(method, str)
+    if builtin:
+        if method not in _ACTIONS:
+            raise ValueError(f"invalid method: '{method}'. Valid methods: {method}")
+    elif not callable(method):
+        raise TypeError(f"'{type(method)}' object is not callable")
+    key = key.replace(" ", "_")
+    operator = result._get_content(operator)
+    if isinstance(operator, str):
+        if operator not in _OPERATORS:
+            raise ValueError(f"invalid operator: '{operator}'. Valid operators: {tuple(_OPERATORS)}")
+        operator_str, operator = operator, _OPERATORS[operator]
+    else:
+        operator_str = result._store_content(operator)
+    method_str = method if builtin else result._store_content(method)
+    if builtin and method.startswith("split"):
+        if word_level is None:
+            raise ValueError("Segment-level result is not compatible with split actions.")
+        if not word_level:
+            raise ValueError("``word_level=False`` is not compatible with split actions.")
+
+    def act(si: int, wi: Optional[int]):
+        if not builtin:
+            return method(result, si, wi)
+        seg = result.segments[si]
+        if method.startswith("merge"):
+            pairs = []
+            if method in ("mergeright", "merge") and not (si + 1 >= len(result.segments) or
+                                                          (wi is not None and wi != len(seg.words) - 1)):
+                pairs.append((si, si + 1))
+            if method in ("mergeleft", "merge") and not (si == 0 or (wi is not None and wi != 0)):
+                pairs.append((si - 1, si))
+            for a, b in pairs:
+                result.add_segments(a, b, inplace=True, reassign_ids=False)
+        elif method.startswith("lock"):
+            target = seg if wi is None else seg.words[wi]
+            if method in ("lockright", "lock"):
+                target.lock_right()
+            if method in ("lockleft", "lock"):
+                target.lock_left()
+        elif method == "splitright":
+            if wi != len(seg.words) + 1:
+                result.split_segment_by_index(seg, wi, reassign_ids=False)
+        elif method == "splitleft":
+            if wi != 0:
+                result.split_segment_by_index(seg, wi - 1, reassign_ids=False)
+        elif method == "split":
+            idx = ([wi - 1] if wi != 0 else []) + ([wi] if wi < len(seg.words) + 1 else [])
+            result.split_segment_by_index(seg, idx, reassign_ids=False)
+        elif wi is None:
+            result.remove_segment(seg, reassign_ids=False, record=False, verbose=False)
+        else:
+            result.remove_word(seg.words[wi], reassign_ids=False, record=False, verbose=False)
+
+    if key.startswith("len="):
+        get = lambda o: len(getattr(o, key[4:]))          # noqa: E731
+    elif key == "":
+        get = lambda o: o                                  # noqa: E731
+    else:
+        get = lambda o: getattr(o, key)                    # noqa: E731
+    if isinstance(value, str) and (value.startswith("all=") or value.startswith("any=")):
+        check = any if value.startswith("any=") else all
+        values = [v.replace("\\,", ",") for v in re.split(r"(?<!\\),", value[4:])]
+        ok = lambda o: check(operator(get(o), v) for v in values)      # noqa: E731
+    else:
+        ok = lambda o: operator(get(o), value)             # noqa: E731
+    for si in range(len(result.segments) - 1, -1, -1):
+        if word_level:
+            for wi in range(len(result.segments[si].words) - 1, -1, -1):
+                if ok(result.segments[si].words[wi]):
+                    act(si, wi)
+        elif ok(result.segments[si]):
+            act(si, None)
+    result.reassign_ids()
+    if isinstance(value, bool):
+        value = f"<{value}>"
+    elif not isinstance(value, (str, int, float)):
+        value = result._store_content(value)
+    return key.replace("_", " "), operator_str, value, method_str, int(word_level)
+
+
 # ------------------------------------------------------------------------------------------------------------ DSL
 def punctuation_str(punctuation: Punct) -> str:
     if isinstance(punctuation, str):
@@ -417,9 +677,14 @@ _OPS = dict(
     p=("pad", ("start_pad", "end_pad", "max_dur", "max_end", "word_level")),
     csl=("convert_to_segment_level", ()),
     isp=("ignore_special_periods", ("enable",)),
+    rp=("remove_repetition", ("max_words", "case_sensitive", "strip", "ignore_punctuations", "extend_duration", "verbose")),
+    rws=("remove_words_by_str", ("words", "case_sensitive", "strip", "ignore_punctuations", "min_prob", "filters",
+                                 "verbose")),
+    fg=("fill_in_gaps", ("other_result", "min_gap", "case_sensitive", "strip", "ignore_punctuations", "verbose")),
+    ag=("adjust_gaps", ("duration_threshold", "one_section")),
+    co=("custom_operation", ("key", "operator", "value", "method", "word_level")),
 )
-# editing operations of the reference DSL that are outside this package's scope (DESIGN.md "out of scope")
-_UNSUPPORTED = ("rp", "rws", "fg", "ag", "co")
+_UNSUPPORTED = ()
 
 
 def parse_regroup_algo(result: WhisperResult, regroup_algo: str, include_str: bool = True):

@@ -469,10 +469,139 @@ class WhisperResult:
         for s in self.segments:
             s.rescale_time(factor)
 
-    def add_segments(self, other: "WhisperResult"):
-        """Append another result's segments (chunked / sharded transcription)."""
-        self.segments.extend(other.segments)
-        self.reassign_ids()
+    def add_segments(self, index0: int, index1: int, inplace: bool = False, lock: bool = False, newline: bool = False,
+                     reassign_ids: bool = True) -> Segment:
+        """result.py:1074-1100: the two segments fused into one (words concatenated, statistics averaged)."""
+        from . import regroup as R
+        fused = R._fuse(self.segments[index0], self.segments[index1], newline)
+        if reassign_ids:
+            fused.reassign_ids()
+        if lock and self.segments[index0].has_words:
+            k = len(self.segments[index0].words)
+            fused.words[k - 1].lock_right()
+            if k < len(fused.words):
+                fused.words[k].lock_left()
+        if inplace:
+            i0, i1 = sorted([index0, index1])
+            self.segments[i0] = fused
+            del self.segments[i1]
+            if reassign_ids:
+                self.reassign_ids(True)
+        return fused
+
+    def split_segment_by_index(self, segment: Union[int, Segment], indices: Union[int, List[int]], reassign_ids: bool = True):
+        """result.py:1411-1432: cut one segment after the given word indices."""
+        from . import regroup as R
+        if not self.has_words:
+            return
+        if isinstance(indices, int):
+            indices = [indices]
+        elif not indices:
+            return
+        si = segment if isinstance(segment, int) else segment.id
+        seg = self.segments[si]
+        bad = [i for i in indices if i < 0 or i > len(seg.words)]
+        if bad:
+            raise IndexError(f"got out of split range indices: {bad}")
+        parts = R._pieces(seg, list(indices))
+        if reassign_ids:
+            for p in parts:
+                p.reassign_ids()
+        self.segments[si:si + 1] = parts
+        if reassign_ids:
+            self.reassign_ids(True)
+
+    def get_content_by_time(self, time, within: bool = False, segment_level: bool = False):
+        """result.py:1540-1583: words (or segments) overlapping / lying within a time or (start, end) range."""
+        if not segment_level and not self.has_words:
+            raise ValueError("Missing word timestamps in result. Use ``segment_level=True`` instead.")
+        parts = self.segments if segment_level else self.all_words()
+        if isinstance(time, (float, int)):
+            time = [time, time]
+        elif isinstance(time, dict):
+            time = [time["start"], time["end"]]
+        a, b = time
+        if within:
+            return [c for c in parts if a <= c.start and b >= c.end]
+        return [c for c in parts if a <= c.end and b >= c.start]
+
+    # -- objects referenced from the regroup history ("<key>" place-holders, result.py:44-71)
+    def _store_content(self, content) -> str:
+        if content is None:
+            return ""
+        if isinstance(content, str):
+            return content
+        key = repr(content).replace("_", "-")
+        if not key.startswith("<") and not key.endswith(">"):
+            key = f"<{key}>"
+        if not hasattr(self, "_content_cache"):
+            self._content_cache = {}
+        self._content_cache[key] = content
+        return key
+
+    def _get_content(self, content, strict: bool = True):
+        if isinstance(content, str) and content.startswith("<") and content.endswith(">"):
+            found = {"<True>": True, "<False>": False}.get(content)
+            if found is None and hasattr(self, "_content_cache"):
+                found = self._content_cache.get(content)
+            if found is None:
+                if strict:
+                    raise NameError(f'{content.replace("-", "_")} not found')
+                return content
+            return found
+        return content
+
+    def remove_repetition(self, max_words: int = 1, case_sensitive: bool = False, strip: bool = True,
+                          ignore_punctuations: str = "\"',.?!", extend_duration: bool = True, verbose: bool = True):
+        from . import regroup as R
+        if not self.has_words:
+            return self
+        R.remove_repetition(self, max_words, case_sensitive, strip, ignore_punctuations, extend_duration)
+        self._log(f"rp={max_words}+{int(case_sensitive)}+{int(strip)}+{ignore_punctuations}+{int(extend_duration)}+{int(verbose)}")
+        return self
+
+    def remove_words_by_str(self, words, case_sensitive: bool = False, strip: bool = True,
+                            ignore_punctuations: str = "\"',.?!", min_prob: float = None, filters=None,
+                            verbose: bool = True):
+        from . import regroup as R
+        if not self.has_words:
+            return self
+        if isinstance(words, str):
+            words = [words]
+        elif words == 0:
+            words = None
+        filters = self._get_content(filters)
+        R.remove_words_by_str(self, words, case_sensitive, strip, ignore_punctuations, min_prob, filters)
+        shown = 0 if words is None else "/".join(R._norm_words(list(words), strip, ignore_punctuations, case_sensitive))
+        self._log(f"rws={shown}+{int(case_sensitive)}+{int(strip)}+{ignore_punctuations}+{min_prob}"
+                  f"+{self._store_content(filters)}+{int(verbose)}")
+        return self
+
+    def fill_in_gaps(self, other_result, min_gap: float = 0.1, case_sensitive: bool = False, strip: bool = True,
+                     ignore_punctuations: str = "\"',.?!", verbose: bool = True):
+        from . import regroup as R
+        if len(self.segments) < 2:
+            return self
+        other_result = self._get_content(other_result)
+        if isinstance(other_result, str):
+            path, other_result = other_result, WhisperResult(other_result)
+        else:
+            path = self._store_content(other_result)
+        R.fill_in_gaps(self, other_result, min_gap, case_sensitive, strip, ignore_punctuations)
+        self._log(f"fg={path}+{min_gap}+{int(case_sensitive)}+{int(strip)}+{ignore_punctuations}+{int(verbose)}")
+        return self
+
+    def adjust_gaps(self, duration_threshold: float = 0.75, one_section: bool = False):
+        from . import regroup as R
+        R.adjust_gaps(self, duration_threshold, one_section)
+        self._log(f"ag={duration_threshold}+{int(one_section)}")
+        return self
+
+    def custom_operation(self, key: str, operator, value, method, word_level: Optional[bool] = None):
+        from . import regroup as R
+        parts = R.custom_operation(self, key, operator, value, method, word_level)
+        self._log("co=" + "+".join(str(x) for x in parts))
+        return self
 
     def to_dict(self, keep_orig: bool = True) -> dict:
         ori = self.ori_dict if keep_orig else {}
