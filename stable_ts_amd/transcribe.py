@@ -267,7 +267,8 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                       gap_padding: str = " ...", max_instant_words: float = 0.5, avg_prob_threshold: Optional[float] = None,
                       nonspeech_skip: Optional[float] = None, progress_callback: Callable = None,
                       ignore_compatibility: bool = True, split_callback: Callable = None,
-                      batch_size: Optional[int] = None, **decode_options) -> WhisperResult:
+                      batch_size: Optional[int] = None, clip_timestamps: Optional[Union[str, List[float]]] = None,
+                      **decode_options) -> WhisperResult:
     """Same keyword surface as the reference's ``model.transcribe`` for the options that reach the hot path
     (original_whisper.py:27-79); ``batch_size`` (window-parallel mode) is the only addition."""
     unknown = set(decode_options) - _DECODE_KEYS
@@ -319,17 +320,45 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
 
     all_segments: List[dict] = []
 
+    # clip_timestamps (original_whisper.py:280-287; audio/__init__.py:414-441): only the listed [start, end) sections are
+    # processed; a window never crosses a section end and the seek jumps to the next section's start
+    sections: List[Tuple[int, Optional[int]]] = []
+    if isinstance(clip_timestamps, str):
+        clip_timestamps = [float(ts) for ts in (clip_timestamps.split(",") if clip_timestamps else [])]
+    if clip_timestamps:
+        if batch_size:
+            raise NotImplementedError("clip_timestamps is defined on the sequential driver (window-parallel mode: slice the audio)")
+        pairs = [list(clip_timestamps[i:i + 2]) for i in range(0, len(clip_timestamps), 2)]
+        if len(pairs[-1]) == 1:
+            pairs[-1] = [pairs[-1][0], None]
+        sections = [(None if a is None else round(a * SAMPLE_RATE), None if b is None else round(b * SAMPLE_RATE)) for a, b in pairs]
+    section_state = dict(index=-1, span=(0, 0))
+
+    def next_valid_seek(seek: int) -> Tuple[Optional[int], Optional[int]]:
+        """-> (seek moved into the current / next section, or None when no section is left; exclusive end of that section)"""
+        if not sections:
+            return seek, None
+        while section_state["span"][1] is not None and seek + 1 >= section_state["span"][1]:
+            if section_state["index"] + 1 >= len(sections):
+                return None, None
+            section_state["index"] += 1
+            section_state["span"] = sections[section_state["index"]]
+            if seek < section_state["span"][0]:
+                seek = section_state["span"][0]
+        return seek, section_state["span"][1]
+
     # silence analysis is host-side vector code (CPU); keep one host copy of the recording for it
     audio_host = audio.detach().float().cpu() if nonspeech is not None else None
     pred_cache = {}
 
-    def window_input(seek: int, prompt: List[int]):
-        seg = audio[seek: seek + N_SAMPLES]
+    def window_input(seek: int, prompt: List[int], stop: Optional[int] = None):
+        n_max = N_SAMPLES if stop is None else min(N_SAMPLES, stop - seek)
+        seg = audio[seek: seek + n_max]
         item = dict(audio=seg, seek_sample=seek, prompt=prompt, ts_mask=None, silence=None, skip=False)
         if nonspeech is not None:
-            pred = pred_cache.pop(seek, None)
+            pred = pred_cache.pop(seek, None) if stop is None else None
             if pred is None:
-                pred = nonspeech.predict(audio_host[seek: seek + N_SAMPLES], offset=seek / SAMPLE_RATE)
+                pred = nonspeech.predict(audio_host[seek: seek + n_max], offset=seek / SAMPLE_RATE)
             item["silence"] = pred["timings"] if suppress_silence else None
             item["ts_mask"] = pred["mask"]
             item["skip"] = pred["is_silent"]
@@ -383,7 +412,10 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
         # ---- sequential driver (reference control flow)
         prompt_reset_since = 0
         while seek < total:
-            item = window_input(seek, all_tokens[prompt_reset_since:])
+            seek, stop = next_valid_seek(seek)
+            if seek is None:
+                break
+            item = window_input(seek, all_tokens[prompt_reset_since:], stop)
             n_seg = int(item["audio"].shape[-1])
             if n_seg == 0:
                 break

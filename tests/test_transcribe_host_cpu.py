@@ -35,6 +35,8 @@ CASES = {
     "silence_opts": dict(use_word_position=False, suppress_word_ts=False, nonspeech_error=0.3, min_silence_dur=0.2, q_levels=10, k_size=3),
     "ladder_not_taken": dict(temperature=(0.0, 0.4), compression_ratio_threshold=50.0, logprob_threshold=-60.0),
     "punct_sets": dict(prepend_punctuations="(", append_punctuations=".,?", regroup="sp=./?"),
+    "clip_str": dict(clip_timestamps="3,18,25.5,40", regroup=False),
+    "clip_open_end": dict(clip_timestamps=[10.0, 30.0, 35.0], suppress_silence=False),
 }
 
 
@@ -58,7 +60,7 @@ def models():
 
 
 LONG = {"defaults_regroup": (97.0, 60), "no_condition": (83.0, 48), "thresholds": (75.0, 60), "prompt": (66.0, 48),
-        "nonspeech_skip": (91.0, 40), "avg_prob": (88.0, 40)}
+        "nonspeech_skip": (91.0, 40), "avg_prob": (88.0, 40), "clip_open_end": (95.0, 40)}
 
 
 @pytest.mark.parametrize("name", list(CASES) + [k + "+long" for k in LONG])
