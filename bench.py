@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--embed-gain", type=float, default=2.0)
     ap.add_argument("--ts-gain", type=float, default=0.5)
     ap.add_argument("--max-instant-words", type=float, default=None)
+    ap.add_argument("--streams", type=int, default=1, help="experimental: host threads / HIP streams per batch (engine clones)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="hard cap (s) on the CPU-baseline leg")
@@ -125,6 +126,8 @@ def main():
               min_tokens=args.tokens, word_timestamps=True, regroup=False, batch_size=args.batch)
     if args.max_instant_words is not None:
         kw["max_instant_words"] = args.max_instant_words
+    if args.streams > 1:
+        kw["streams"] = args.streams
 
     def step():
         return model.transcribe(audio, **kw)

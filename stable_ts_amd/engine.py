@@ -56,12 +56,31 @@ class Engine:
         self.arena = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         check(self.lib.swx_bind_weights(self.h, _ptr(self.arena), nbytes), "swx_bind_weights")
         self._load_constants()
+        self._heads = None
         if alignment_heads is not None:
             self.set_alignment_heads(alignment_heads)
         self.max_windows = 0
         self.max_rows = 0
         self.ws = None
         self.reserve(max_windows, max_rows)
+
+    def clone_shared(self, max_windows: Optional[int] = None, max_rows: Optional[int] = None) -> "Engine":
+        """A second engine on the SAME weight arena (no copy) with its own workspace: lets another host thread drive
+        another HIP stream through the library concurrently (stable_ts_amd.transcribe, ``streams=``).  Experimental."""
+        e = object.__new__(Engine)
+        e.lib, e.dims, e.dtype_name, e.dtype, e.tdtype, e.device = self.lib, self.dims, self.dtype_name, self.dtype, self.tdtype, self.device
+        cd = swx_dims(**{f: getattr(self.dims, f) for f, _ in swx_dims._fields_})
+        h = ctypes.c_void_p()
+        check(self.lib.swx_model_create(ctypes.byref(cd), self.dtype, ctypes.byref(h)), "swx_model_create")
+        e.h = h
+        e.arena = self.arena
+        check(self.lib.swx_bind_weights(e.h, _ptr(e.arena), e.arena.numel()), "swx_bind_weights")
+        e._heads = None
+        if self._heads is not None:
+            e.set_alignment_heads(self._heads)
+        e.max_windows, e.max_rows, e.ws = 0, 0, None
+        e.reserve(self.max_windows if max_windows is None else max_windows, self.max_rows if max_rows is None else max_rows)
+        return e
 
     # ------------------------------------------------------------------ lifetime
     def __del__(self):
@@ -122,6 +141,7 @@ class Engine:
             raise _lib.SwxError(f"missing tensors in state dict: {missing} ...")
 
     def set_alignment_heads(self, pairs: Sequence[Tuple[int, int]]):
+        self._heads = [tuple(int(v) for v in p) for p in pairs]
         flat = [int(v) for p in pairs for v in p]
         check(self.lib.swx_set_alignment_heads(self.h, _i32arr(flat), len(pairs)), "swx_set_alignment_heads")
         self.alignment_heads = [tuple(p) for p in pairs]

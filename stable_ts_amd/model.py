@@ -214,6 +214,20 @@ class Whisper:
                for i in range(x.shape[0])]
         return (lang_tokens[0], out[0]) if single else (lang_tokens, out)
 
+    def clone_for_stream(self) -> "Whisper":
+        """A view of this model for another host thread / HIP stream: shares the weight arena, owns its workspace."""
+        import copy
+        other = copy.copy(self)
+        other.engine = self.engine.clone_shared()
+        other._bind_api()
+        return other
+
+    def stream_context(self):
+        """a fresh side stream that waits for the work already queued on the current stream"""
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(s), s
+
     def _bind_api(self):
         from .transcribe import transcribe_stable
         from .alignment import align, align_words, refine

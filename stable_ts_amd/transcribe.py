@@ -268,7 +268,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                       nonspeech_skip: Optional[float] = None, progress_callback: Callable = None,
                       ignore_compatibility: bool = True, split_callback: Callable = None,
                       batch_size: Optional[int] = None, clip_timestamps: Optional[Union[str, List[float]]] = None,
-                      **decode_options) -> WhisperResult:
+                      streams: int = 1, **decode_options) -> WhisperResult:
     """Same keyword surface as the reference's ``model.transcribe`` for the options that reach the hot path
     (original_whisper.py:27-79); ``batch_size`` (window-parallel mode) is the only addition."""
     unknown = set(decode_options) - _DECODE_KEYS
@@ -400,14 +400,40 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             with ThreadPoolExecutor(max_workers=8) as pool:
                 preds = list(pool.map(lambda sk: nonspeech.predict(audio_host[sk: sk + N_SAMPLES], offset=sk / SAMPLE_RATE), seeks))
             pred_cache.update(zip(seeks, preds))
+        lanes = None
+        if streams and streams > 1:
+            # experimental: each batch is split over `streams` host threads, each driving its own HIP stream through its
+            # own engine clone (shared weights).  The decode step is a chain of short latency-bound kernels; two
+            # independent chains can overlap on the device.  Results are identical (windows are independent in this mode).
+            from concurrent.futures import ThreadPoolExecutor
+            lanes = [model] + [model.clone_for_stream() for _ in range(streams - 1)]
+            lane_pool = ThreadPoolExecutor(max_workers=streams)
+
+        def run_lane(m, part):
+            if not part:
+                return []
+            ctx, side = m.stream_context()
+            with ctx:
+                outs_k = _process_batch(m, tokenizer, part, o)
+            if side is not None:
+                side.synchronize()
+            return outs_k
+
         for b0 in range(0, len(seeks), batch_size):
             items = [window_input(s, list(initial_prompt_tokens)) for s in seeks[b0: b0 + batch_size]]
             live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
-            outs = _process_batch(model, tokenizer, live, o) if live else []
+            if lanes and len(live) >= len(lanes):
+                per = (len(live) + len(lanes) - 1) // len(lanes)
+                parts = [live[k * per:(k + 1) * per] for k in range(len(lanes))]
+                outs = [x for r in lane_pool.map(run_lane, lanes, parts) for x in r]
+            else:
+                outs = _process_batch(model, tokenizer, live, o) if live else []
             for it, out in zip(live, outs):
                 commit(it, out)
             if progress_callback is not None:
                 progress_callback(min(total, (b0 + len(items)) * N_SAMPLES) / SAMPLE_RATE, total / SAMPLE_RATE)
+        if lanes:
+            lane_pool.shutdown()
     else:
         # ---- sequential driver (reference control flow)
         prompt_reset_since = 0

@@ -154,6 +154,14 @@ class CpuWhisper:
     def cross_kv(self, xa):
         return XKV(xa)
 
+    def clone_for_stream(self):
+        import copy
+        return CpuWhisper(copy.deepcopy(self.om))      # the oracle's hook-based KV cache is per module instance
+
+    def stream_context(self):
+        import contextlib
+        return contextlib.nullcontext(), None
+
 
 def install(monkeypatch):
     """route the product's device-buffer helper to the stand-in's"""

@@ -122,3 +122,23 @@ def test_transcribe_host_logic_on_long_segments(rich_models, monkeypatch, name):
     assert got.regroup_history == want.regroup_history
     n_words = sum(len(s.words) for s in want.segments if s.has_words)
     assert len(want.segments) > 0 and (n_words >= 60 or not opts.get("word_timestamps", True))
+
+
+def test_window_parallel_streams_equal_single_lane(models, monkeypatch):
+    """batch_size mode split over two host threads / engine clones (`streams=2`, experimental) returns exactly what one
+    lane returns: windows are independent in that mode."""
+    G, _ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    audio = G.synth_audio(130.0, seed=5)
+    kw = dict(BASE, language="en", batch_size=4, regroup=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = mine.transcribe(audio, **kw)
+        two = mine.transcribe(audio, streams=2, **kw)
+    a, b = _snap(one), _snap(two)
+    assert len(a) == len(b) > 0
+    for sa, sb in zip(a, b):                       # different batch shapes -> last-digit differences in the CPU matmuls
+        assert sa[:4] == sb[:4] and len(sa[4]) == len(sb[4])
+        for wa, wb in zip(sa[4], sb[4]):
+            assert wa[:3] == wb[:3] and wa[4] == wb[4] and abs(wa[3] - wb[3]) <= 1e-5 * max(wa[3], 1e-9) + 1e-9
