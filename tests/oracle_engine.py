@@ -14,6 +14,11 @@ from oracle.whisper.timing import dtw as oracle_dtw
 from oracle.whisper.tokenizer import get_tokenizer
 
 
+import threading
+
+_SDPA_LOCK = threading.Lock()      # the oracle's disable_sdpa() flips a class-level flag: serialise it across lanes (tests only)
+
+
 class XKV:
     """stands in for the device cross-KV buffer: keeps the encoder output of the batch"""
 
@@ -71,7 +76,8 @@ class OracleEngine:
             if min_tokens:
                 pos = len(task.logit_filters) - (0 if opts.without_timestamps else 1)
                 task.logit_filters.insert(pos, ost._MinTokens(task.tokenizer.eot, task.sample_begin, min_tokens))
-            r = task.run(torch.zeros(1, self.dims.n_mels, N_FRAMES))[0]
+            with _SDPA_LOCK:               # keep another lane's scoring pass from flipping the attention code path mid-decode
+                r = task.run(torch.zeros(1, self.dims.n_mels, N_FRAMES))[0]
             n = len(r.tokens)
             toks[w, 0, len(init): len(init) + n] = r.tokens
             lens[w, 0] = n
@@ -92,7 +98,7 @@ class OracleEngine:
             qks = [None] * self.dims.n_text_layer
             hooks = [blk.cross_attn.register_forward_hook(lambda _, i, o, k=k: qks.__setitem__(k, o[-1]))
                      for k, blk in enumerate(self.m.decoder.blocks)]
-            with disable_sdpa():
+            with _SDPA_LOCK, disable_sdpa():
                 logits = self.m.decoder(torch.tensor([list(tk)]), xkv.xa[w:w + 1])[0]
             for h in hooks:
                 h.remove()
@@ -149,7 +155,8 @@ class CpuWhisper:
 
     @torch.no_grad()
     def encoder(self, mel):
-        return self.om.encoder(mel)
+        with _SDPA_LOCK:
+            return self.om.encoder(mel)
 
     def cross_kv(self, xa):
         return XKV(xa)
