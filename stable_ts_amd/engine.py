@@ -141,8 +141,9 @@ class Engine:
             raise _lib.SwxError(f"missing tensors in state dict: {missing} ...")
 
     def set_alignment_heads(self, pairs: Sequence[Tuple[int, int]]):
-        self._heads = [tuple(int(v) for v in p) for p in pairs]
-        flat = [int(v) for p in pairs for v in p]
+        pairs = [tuple(int(v) for v in p) for p in pairs]
+        self._heads = pairs
+        flat = [v for p in pairs for v in p]
         check(self.lib.swx_set_alignment_heads(self.h, _i32arr(flat), len(pairs)), "swx_set_alignment_heads")
         self.alignment_heads = [tuple(p) for p in pairs]
         if getattr(self, "ws", None) is not None:
