@@ -102,8 +102,13 @@ def synth_case(seed: int):
                 remove_instant_words=rng.random() < 0.2,
                 original_split=rng.random() < 0.25,
                 suppress_silence=rng.random() < 0.8,
-                presplit=rng.choice([True, True, False]),
-                regroup=rng.choice([True, True, False]))
+                presplit=rng.choice([True, True, False, [".", "?"]]),
+                regroup=rng.choice([True, True, False]),
+                gap_padding=rng.choice([" ...", " ...", None]),
+                min_word_dur=rng.choice([None, None, 0.2]),
+                q_levels=rng.choice([20, 20, 10]), k_size=rng.choice([5, 5, 3]),
+                nonspeech_error=rng.choice([0.1, 0.1, 0.3]),
+                use_word_position=rng.random() < 0.8, suppress_word_ts=rng.random() < 0.8)
     return audio, ids, opts
 
 
