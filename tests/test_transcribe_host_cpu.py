@@ -142,3 +142,22 @@ def test_window_parallel_streams_equal_single_lane(models, monkeypatch):
         assert sa[:4] == sb[:4] and len(sa[4]) == len(sb[4])
         for wa, wb in zip(sa[4], sb[4]):
             assert wa[:3] == wb[:3] and wa[4] == wb[4] and abs(wa[3] - wb[3]) <= 1e-5 * max(wa[3], 1e-9) + 1e-9
+
+
+@pytest.mark.parametrize("kind", ["half_second", "silent", "one_window_exact", "tail_of_200_samples"])
+def test_transcribe_edge_inputs_match_reference(models, monkeypatch, kind):
+    """degenerate inputs: shorter than a frame budget, all-zero audio (every window skipped), exactly one window, and a
+    recording whose last window holds only 200 samples"""
+    G, ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    audio = {"half_second": G.synth_audio(30.0, seed=1)[:8000],
+             "silent": torch.zeros(16000 * 40),
+             "one_window_exact": G.synth_audio(30.0, seed=2),
+             "tail_of_200_samples": G.synth_audio(30.0 + 200 / 16000, seed=3)}[kind]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **BASE)
+        got = mine.transcribe(audio, language="en", **BASE)
+    assert _snap(got) == _snap(want)
+    assert got.text == want.text
