@@ -213,3 +213,28 @@ def test_align_wrapper_end_to_end_on_cpu(monkeypatch):
     out = A.refine(model, audio, res, precision=0.5)
     assert out is res and len(out.all_words()) == len(before)
     assert all(w.start <= w.end for w in out.all_words())
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
+@pytest.mark.parametrize("text,seconds", [("", 5.0), (" .", 5.0), (" aaat", 0.05), (" aaat aaau. aaax", 0.4),
+                                          (" aaat\n\n aaau", 12.0), ("aaat   aaau\taaax", 12.0)])
+def test_aligner_degenerate_inputs_match_reference(text, seconds):
+    import contextlib
+    import io
+    import warnings
+    import torch
+    from make_golden import import_reference
+    import_reference()
+    from stable_whisper.non_whisper.alignment import Aligner as RefAligner
+    tok = _tok()
+    audio = 0.1 * torch.randn(int(seconds * 16000), generator=torch.Generator().manual_seed(3))
+    outs = []
+    for cls, extra in ((RefAligner, dict(verbose=None)), (Aligner, {})):
+        al = cls(inference_func=mg.make_inference(7), decode=tok.decode, encode=tok.encode, original_split=True, **extra)
+        with warnings.catch_warnings(), contextlib.redirect_stderr(io.StringIO()):
+            warnings.simplefilter("ignore")
+            try:
+                outs.append(_norm(mg.snapshot(al.align(audio, text))))
+            except Exception as e:
+                outs.append(type(e).__name__)
+    assert outs[0] == outs[1], (text, seconds, outs)
