@@ -68,6 +68,16 @@ int swx_bind_workspace(swx_model *m, void *d_ws, size_t bytes, int max_windows, 
  *         (upstream quirk inherited by refine) and per window when per_item_max!=0 */
 int swx_log_mel(swx_model *m, const float *d_pcm, int B, float *d_mel, int per_item_max, void *stream);
 
+/* log-mel of segments that are NOT zero-padded to 30 s, followed by pad_or_trim(mel, 3000): refine's inference
+ * (alignment.py:660-661, padding 0) and locate (alignment.py:924-925, padding 201).
+ * d_pcm f32 [B][480000] (only the first n_valid[b] samples of a row are read); n_valid / n_total: HOST int32 [B],
+ * n_total = n_valid + the zero padding upstream appends (200 < n_total, n_total/160 <= 3008, n_valid <= 480000).
+ * Frames t < n_total/160 are upstream's (reflection about n_total, clamp floor from the per-item max over all
+ * n_total/160 frames, also those past 3000; over the whole batch when per_item_max==0, which is what upstream's
+ * batched call in refine does); frames >= n_total/160 are 0.0.  Returns -2 on a length out of range. */
+int swx_log_mel_ragged(swx_model *m, const float *d_pcm, const int32_t *n_valid, const int32_t *n_total, int B,
+                       float *d_mel, int per_item_max, void *stream);
+
 /* ---- a2: encoder (replaces model.encoder(mel), decode.py:27-30, timing.py:59-60)
  * d_mel f32 [B][n_mels][3000] -> d_xa [B][1500][d] in the compute dtype */
 int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream);

@@ -47,6 +47,7 @@ SYMBOLS = {
     "swx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "swx_bind_workspace": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int]),
     "swx_log_mel": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "swx_log_mel_ragged": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "swx_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "swx_cross_kv_bytes": (c_size_t, [c_void_p, c_int]),
     "swx_cross_kv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence, Union
 
 import torch
 
-from .audio import HOP_LENGTH, N_SAMPLES, SAMPLE_RATE
+from .audio import N_SAMPLES, SAMPLE_RATE
 from .result import WhisperResult
 from .timing import add_word_timestamps_batch
 from .tokenizer import get_tokenizer
@@ -51,18 +51,13 @@ def make_refinement_func(model, tokenizer):
     cross-KV and ONE teacher-forced decoder pass of ``sot_sequence + [no_timestamps] + tokens + [eot]``.
     Like the reference the log-mel is computed on the un-padded segment and the remaining frames are filled with 0.0
     (``pad_or_trim`` of the mel, not of the audio).  Host-side bisection: stable_ts_amd/refiner.py (CPU-tested against
-    the reference's Refiner); this device callable is composed of GPU-tested entry points only (swx_log_mel, swx_encode,
-    swx_cross_kv, swx_forward_logits) but has no GPU parity test of its own yet."""
+    the reference's Refiner); the callable is CPU-tested against the reference's on the engine stand-in
+    (tests/test_locate_cpu.py) and has a hardware check (tests/hw_checks/b3_check.py; status in DESIGN.md section 7)."""
     sot = list(tokenizer.sot_sequence)
 
     def inference_func(audio_segment: torch.Tensor, tokens: List[int]) -> torch.Tensor:
-        n = int(audio_segment.shape[-1])
-        if n > N_SAMPLES:
-            audio_segment, n = audio_segment[..., :N_SAMPLES], N_SAMPLES
-        mel = model.log_mel_batch([audio_segment[0], audio_segment[1]], [N_SAMPLES - n] * 2)
-        n_frames = n // HOP_LENGTH
-        if n_frames < mel.shape[-1]:
-            mel[..., n_frames:] = 0.0
+        audio_segment = audio_segment[..., :N_SAMPLES]      # the Refiner's probes are word-local, far below 30 s
+        mel = model.log_mel_segments([audio_segment[0], audio_segment[1]], batch_max=True)
         xkv = model.cross_kv(model.encoder(mel))
         ids = [*sot, tokenizer.no_timestamps, *[int(t) for t in tokens], tokenizer.eot]
         logits = model.engine.forward_logits(xkv, [ids, ids])

@@ -127,6 +127,9 @@ int swx_align_weights_launch(const float *d_qk, float *d_p, float *d_mean, float
                              float *d_neg_matrix, int out_ld_n, int out_ld_f, hipStream_t s);
 int swx_mel_launch(const float *d_pcm, int B, const float *d_hann, const double2 *d_twiddle, const float *d_filters,
                    int n_mels, float *d_mel, unsigned *d_gmax, int per_item_max, hipStream_t s);
+int swx_mel_ragged_launch(const float *d_pcm, const int *d_lens, int B, const float *d_hann, const double2 *d_twiddle,
+                          const float *d_filters, int n_mels, float *d_mel, unsigned *d_gmax, int per_item_max,
+                          hipStream_t s);
 
 // ---- swx_decode.hip
 struct DecodeState;   // device-resident bookkeeping, defined in swx_decode.hip

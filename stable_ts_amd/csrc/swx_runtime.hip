@@ -668,6 +668,32 @@ int swx_log_mel(swx_model *m, const float *d_pcm, int B, float *d_mel, int per_i
                           m->dims.n_mels, d_mel, m->Wp<unsigned>(m->L.gmax), per_item_max, S(stream));
 }
 
+int swx_log_mel_ragged(swx_model *m, const float *d_pcm, const int32_t *n_valid, const int32_t *n_total, int B,
+                       float *d_mel, int per_item_max, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (B <= 0) return 0;
+    if (B > m->max_windows) return -8;
+    if (!n_valid || !n_total) return -2;
+    std::vector<int32_t> lens((size_t)B * 2);
+    for (int b = 0; b < B; ++b) {
+        // torch.stft's reflect padding needs more than n_fft/2 samples; one extra block row of 8 frames is launched
+        if (n_total[b] <= 200 || n_total[b] / 160 > 3008 || n_valid[b] < 0 || n_valid[b] > n_total[b] ||
+            n_valid[b] > 480000)
+            return -2;
+        lens[2 * b] = n_valid[b];
+        lens[2 * b + 1] = n_total[b];
+    }
+    hipStream_t s = S(stream);
+    int32_t *d_lens = m->Wp<int32_t>(m->L.h1);          // encoder scratch, idle while the spectrogram is computed
+    hipError_t e = hipMemcpyAsync(d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);   // lens is a stack-lifetime staging buffer
+    if (e != hipSuccess) return -100 - (int)e;
+    return swx_mel_ragged_launch(d_pcm, d_lens, B, m->A<float>(m->o_hann), m->A<double2>(m->o_twiddle),
+                                 m->A<float>(m->o_filters), m->dims.n_mels, d_mel, m->Wp<unsigned>(m->L.gmax), per_item_max,
+                                 s);
+}
+
 // ----------------------------------------------------------------------------------------------------- encoder
 int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream)
 {

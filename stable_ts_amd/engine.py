@@ -165,6 +165,20 @@ class Engine:
         check(self.lib.swx_log_mel(self.h, _ptr(pcm), B, _ptr(mel), int(per_item_max), self.stream), "swx_log_mel")
         return mel
 
+    def log_mel_ragged(self, pcm: torch.Tensor, n_valid: Sequence[int], n_total: Sequence[int],
+                       per_item_max: bool = True) -> torch.Tensor:
+        """pcm f32 [B, 480000] (row b holds n_valid[b] samples) -> pad_or_trim(log_mel(segment, padding=n_total-n_valid),
+        3000): upstream's frames for a segment that is not padded to 30 s (refine / locate)."""
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.shape[-1] == N_SAMPLES and pcm.is_contiguous()
+        B = pcm.shape[0]
+        assert len(n_valid) == B and len(n_total) == B
+        self.reserve(max(B, self.max_windows), max(self.max_rows, 1))
+        mel = torch.empty(B, self.dims.n_mels, N_FRAMES, dtype=torch.float32, device=self.device)
+        check(self.lib.swx_log_mel_ragged(self.h, _ptr(pcm), _i32arr(n_valid), _i32arr(n_total), B, _ptr(mel),
+                                          int(per_item_max), self.stream),
+              "swx_log_mel_ragged")
+        return mel
+
     # ------------------------------------------------------------------ a2 encoder
     def encode(self, mel: torch.Tensor) -> torch.Tensor:
         assert mel.is_cuda and mel.dtype == torch.float32 and mel.is_contiguous()

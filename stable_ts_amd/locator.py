@@ -32,16 +32,8 @@ CHUNK_LENGTH = N_SAMPLES // SAMPLE_RATE
 
 def _chunk_mel(model, audio_segment: torch.Tensor) -> torch.Tensor:
     """log-mel [n_mels, 3000] of one chunk as the reference computes it for locate (:924-925): the segment plus
-    N_FFT // 2 + 1 zero samples, trimmed / zero-filled to 3000 frames.  On the device the segment is zero-padded to the
-    fixed 30-s input of swx_log_mel and the frames past the padded length are blanked; for a full chunk this differs from
-    the reference only in the very last frame (reflect padding there, zeros here)."""
-    n = int(audio_segment.shape[-1])
-    mel = model.log_mel(audio_segment, N_SAMPLES - n)
-    n_frames = (n + N_FFT // 2 + 1) // HOP_LENGTH
-    if n_frames < N_FRAMES:
-        mel = mel.clone()
-        mel[..., n_frames:] = 0.0
-    return mel
+    N_FFT // 2 + 1 zero samples, trimmed / zero-filled to 3000 frames (swx_log_mel_ragged)."""
+    return model.log_mel_segments([audio_segment], padding=N_FFT // 2 + 1)[0]
 
 
 def _pad_frames(mel: torch.Tensor) -> torch.Tensor:

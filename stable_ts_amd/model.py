@@ -176,6 +176,24 @@ class Whisper:
             buf[b, :n] = a.to(self.device)
         return self.engine.log_mel(buf, per_item_max=True)
 
+    def log_mel_segments(self, audios: Sequence[torch.Tensor], padding: int = 0, batch_max: bool = False) -> torch.Tensor:
+        """``pad_or_trim(log_mel_spectrogram(a, n_mels, padding=padding), N_FRAMES)`` for segments of at most 30 s that
+        are NOT padded to 30 s first -- refine's inference (alignment.py:660-661) and locate (alignment.py:924-925).
+        Returns f32 [B, n_mels, 3000] on the device; the frames past ``(len + padding) // 160`` are 0.0.
+        ``batch_max``: the clamp floor comes from the max over the whole batch, as upstream's batched call computes it."""
+        B = len(audios)
+        buf = torch.zeros(B, N_SAMPLES, dtype=torch.float32, device=self.device)
+        n_valid = []
+        for b, a in enumerate(audios):
+            a = torch.as_tensor(a, dtype=torch.float32)
+            n = int(a.shape[-1])
+            if n > N_SAMPLES:
+                raise ValueError(f"segment longer than {N_SAMPLES} samples: {n}")
+            buf[b, :n] = a.to(self.device)
+            n_valid.append(n)
+        return self.engine.log_mel_ragged(buf, n_valid, [n + int(padding) for n in n_valid],
+                                          per_item_max=not batch_max)
+
     def encoder(self, mel: torch.Tensor) -> torch.Tensor:
         mel = mel.to(device=self.device, dtype=torch.float32)
         if mel.ndim == 2:

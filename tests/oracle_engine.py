@@ -153,6 +153,12 @@ class CpuWhisper:
     def log_mel(self, audio, padding=0):
         return self.log_mel_batch([audio], [padding])[0]
 
+    def log_mel_segments(self, audios, padding=0, batch_max=False):
+        audios = [torch.as_tensor(a, dtype=torch.float32) for a in audios]
+        if batch_max:                                      # upstream's batched call: one clamp floor for the batch
+            return pad_or_trim(log_mel_spectrogram(torch.stack(audios), self.dims.n_mels, padding=padding), N_FRAMES)
+        return torch.stack([pad_or_trim(log_mel_spectrogram(a, self.dims.n_mels, padding=padding), N_FRAMES) for a in audios])
+
     @torch.no_grad()
     def encoder(self, mel):
         with _SDPA_LOCK:

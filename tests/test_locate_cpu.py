@@ -55,13 +55,9 @@ CASES = [
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_locate_matches_reference(models, monkeypatch, case):
     G, sw, ref_model, mine = models
-    from oracle.whisper.audio import N_FRAMES, log_mel_spectrogram, pad_or_trim
     import stable_ts_amd.locator as L
     from oracle_engine import install
     install(monkeypatch)
-    # the stand-in computes the chunk mel exactly as the reference does (the device path's documented last-frame
-    # deviation is a kernel matter, not host logic)
-    monkeypatch.setattr(L, "_chunk_mel", lambda model, seg: pad_or_trim(log_mel_spectrogram(seg, model.dims.n_mels, padding=201), N_FRAMES))
     kw = dict(CASES[case])
     text = kw.pop("text")
     audio = G.synth_audio(75.0, seed=11 + case)
@@ -74,3 +70,22 @@ def test_locate_matches_reference(models, monkeypatch, case):
             except Exception as e:
                 outs.append(("error", type(e).__name__))
     assert outs[0] == outs[1], (CASES[case], outs)
+
+
+@pytest.mark.parametrize("n", [9000, 52000, 480000])
+def test_refinement_callable_matches_reference_seam_b3(models, n):
+    """make_refinement_func (seam B3) on the CPU stand-in vs the reference's get_whisper_refinement_func on the same
+    oracle model: un-padded spectrogram with the floor from the batch max, pad_or_trim of the mel, one teacher-forced
+    pass, softmax over the text vocabulary."""
+    G, sw, ref_model, mine = models
+    from stable_whisper.alignment import get_whisper_refinement_func
+    from stable_ts_amd.alignment import make_refinement_func
+    from stable_ts_amd.tokenizer import get_tokenizer
+    tok = get_tokenizer(False, num_languages=ref_model.num_languages)
+    a = torch.as_tensor(G.synth_audio(31.0, seed=5))[:n]
+    seg = torch.stack([a, torch.cat([a[: n // 3], 0.01 * a[n // 3:]])])      # second copy mostly muted: floors differ per item
+    ids = tok.encode(" aaat aabc aaau")
+    want = get_whisper_refinement_func(ref_model, tok, None, False)(seg, ids)
+    got = make_refinement_func(mine, tok)(seg, ids)
+    assert tuple(got.shape) == tuple(want.shape) == (2, len(ids), tok.eot)
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-7), (got - want).abs().max()
