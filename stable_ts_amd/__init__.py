@@ -14,7 +14,8 @@ from .model import Whisper, available_models, dims_for, load_model, random_state
 from .engine import Engine, ModelDimensions  # noqa: F401
 from .result import Segment, WhisperResult, WordTiming  # noqa: F401
 from .decoding import DecodingOptions, DecodingResult  # noqa: F401
-from .transcribe import transcribe_stable, load_audio  # noqa: F401
+from .transcribe import transcribe_stable  # noqa: F401
+from .audio_io import AudioLoader, load_audio, prep_audio  # noqa: F401
 from .alignment import align, align_words, refine  # noqa: F401
 from .locator import locate  # noqa: F401
 from .audio import (  # noqa: F401

@@ -77,7 +77,8 @@ def align(model, audio, text: Union[str, List[int], WhisperResult], language: st
     checked against it window for window on CPU; each window's timestamps come from the device through
     ``make_alignment_func`` (seam B2).  Returns None when nothing could be aligned."""
     from .aligner import Aligner
-    from .transcribe import load_audio
+    from .transcribe import as_waveform, pop_audio_options
+    audio_options = pop_audio_options(options)
     max_step = model.dims.n_text_ctx - 6                       # alignment.py:181-185
     if token_step < 1:
         token_step = max_step
@@ -94,7 +95,7 @@ def align(model, audio, text: Union[str, List[int], WhisperResult], language: st
                       max_segment_length=N_SAMPLES, remove_instant_words=remove_instant_words, token_step=token_step,
                       original_split=original_split, word_dur_factor=word_dur_factor, max_word_dur=max_word_dur,
                       nonspeech_skip=nonspeech_skip, fast_mode=fast_mode, failure_threshold=failure_threshold, **options)
-    result = aligner.align(load_audio(audio).detach().float().cpu(), text)
+    result = aligner.align(as_waveform(audio, **audio_options).detach().float().cpu(), text)
     if result is not None:
         result.language = lang_code or language or (None if model.is_multilingual else "en")    # alignment.py:388-393
     return result
@@ -108,7 +109,8 @@ def align_words(model, audio, result: Union[WhisperResult, List[dict]], language
     the device (the reference runs them one by one); the host logic is ``Aligner.align_words``, compared with the
     reference's on CPU, batched and unbatched."""
     from .aligner import Aligner
-    from .transcribe import load_audio
+    from .transcribe import as_waveform, pop_audio_options
+    audio_options = pop_audio_options(options)
     if tokenizer is None:
         language = language or getattr(result, "language", None)
         if not language and model.is_multilingual:
@@ -124,7 +126,7 @@ def align_words(model, audio, result: Union[WhisperResult, List[dict]], language
     aligner = Aligner(inference_func=lambda seg, words: clipped(func.batch)([seg], [words])[0], decode=tokenizer.decode,
                       encode=tokenizer.encode, split_words_by_space=lang_code not in {"zh", "ja", "th", "lo", "my"},
                       sample_rate=SAMPLE_RATE, max_segment_length=N_SAMPLES, token_step=model.dims.n_text_ctx, **options)
-    out = aligner.align_words(load_audio(audio).detach().float().cpu(), result, normalize_text, inplace,
+    out = aligner.align_words(as_waveform(audio, **audio_options).detach().float().cpu(), result, normalize_text, inplace,
                               batch_inference=clipped(func.batch), batch_size=batch_size)
     out.language = lang_code or language or (None if model.is_multilingual else "en")
     return out
@@ -137,7 +139,8 @@ def refine(model, audio, result: WhisperResult, *, steps: str = None, rel_prob_d
     bisection is :class:`stable_ts_amd.refiner.Refiner`; ``single_batch`` is accepted for signature compatibility (the
     two audio copies always share one batched pass here)."""
     from .refiner import Refiner
-    from .transcribe import load_audio
+    from .transcribe import as_waveform, pop_audio_options
+    audio_options = pop_audio_options(options)
     if result and (not result.has_words or any(w.probability is None for w in result.all_words())):
         if not result.language:
             raise RuntimeError("cannot align words with result missing language")
@@ -152,4 +155,4 @@ def refine(model, audio, result: WhisperResult, *, steps: str = None, rel_prob_d
                       rel_rel_prob_decrease=rel_rel_prob_decrease, prob_threshold=prob_threshold,
                       rel_dur_change=rel_dur_change, abs_dur_change=abs_dur_change, word_level=word_level,
                       precision=precision, max_inference_tokens=model.dims.n_text_ctx - 6, **options)
-    return refiner.refine(load_audio(audio), result, inplace)
+    return refiner.refine(as_waveform(audio, **audio_options), result, inplace)

@@ -48,14 +48,10 @@ def locate(model, audio, text: Union[str, List[int]], language: str, count: int 
            end: float = None, probability_threshold: float = 0.5, eots: int = 1, max_token_per_seg: int = 20,
            exact_token: bool = False, case_sensitive: bool = False, verbose: Optional[bool] = False,
            initial_prompt: str = None, suppress_tokens: Union[str, List[int]] = "-1", **unsupported):
-    for k in ("denoiser", "demucs", "only_voice_freq"):
-        if unsupported.pop(k, None):
-            raise NotImplementedError(f"{k} is outside this package's scope (DESIGN.md section 7)")
-    for k in ("denoiser_options", "demucs_options"):
-        unsupported.pop(k, None)
+    from .transcribe import as_waveform, pop_audio_options
+    audio_options = pop_audio_options(unsupported)
     if unsupported:
         raise TypeError(f"locate() got unexpected keyword argument(s): {sorted(unsupported)}")
-    from .transcribe import load_audio
     sec_per_emb = model.dims.n_audio_ctx / CHUNK_LENGTH
     if isinstance(duration_window, (float, int)):
         duration_window = [duration_window] * 2
@@ -73,7 +69,7 @@ def locate(model, audio, text: Union[str, List[int]], language: str, count: int 
     suppressed = [t for t in plan.suppress if t < tok.eot]
     eng = model.engine
 
-    audio = load_audio(audio).detach().float().cpu()
+    audio = as_waveform(audio, **audio_options).detach().float().cpu()
     if end:
         audio = audio[:round(end * SAMPLE_RATE)]
     seek_sample = round(start * SAMPLE_RATE) if start else 0

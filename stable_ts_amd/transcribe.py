@@ -1,6 +1,8 @@
 """model.transcribe(): the 30-s window loop around the GPU hot path.
 
-Mirrors ``transcribe_stable`` (whisper_word_level/original_whisper.py:27-781) for in-memory 16 kHz audio:
+Mirrors ``transcribe_stable`` (whisper_word_level/original_whisper.py:27-781); the recording is pulled window by
+window from an ``AudioLoader`` (audio_io.py: waveforms, WAVE paths / bytes, streamed or whole) as the reference does
+(:289-311, :494):
 per window  log-mel -> encoder -> decode_with_fallback (:349-393) -> segment slicing at consecutive timestamp tokens
 (:550-602) -> segment filters (:604-627) -> word timestamps (:635-652) -> instant-word / probability filters (:654-674)
 -> seek advance (:629-633, :703-704), with the prompt carried over between windows (:533, :680-682, :706-708).
@@ -9,10 +11,9 @@ Two drivers share one per-batch routine:
   * sequential (default): identical control flow to the reference, one window per iteration;
   * ``batch_size=N`` (window-parallel): fixed 30-s stride, no prompt carry-over, N windows per GPU batch -- the mode
     SURVEY.md 8e describes for throughput / sharding; its oracle is "the reference run on each 30-s clip separately".
-Out of scope here: ffmpeg/yt-dlp audio I/O, denoisers, VAD models, resume.
+Out of scope here: yt-dlp URLs, denoisers, VAD models, resume (non-WAVE containers need ffmpeg on PATH).
 """
 import warnings
-import wave
 from dataclasses import replace
 from typing import Callable, List, Optional, Sequence, Tuple, Union
 
@@ -20,6 +21,7 @@ import numpy as np
 import torch
 
 from .audio import HOP_LENGTH, N_FRAMES, N_SAMPLES, N_SAMPLES_PER_TOKEN, SAMPLE_RATE
+from .audio_io import AudioLoader, audioloader_not_supported, prep_audio
 from .decoding import DecodingOptions, DecodingPlan, DecodingResult
 from .result import WhisperResult
 from .timing import APPEND_PUNCTUATIONS, PREPEND_PUNCTUATIONS, add_word_timestamps_batch
@@ -28,34 +30,28 @@ from .tokenizer import get_tokenizer
 _DECODE_KEYS = set(DecodingOptions.__dataclass_fields__)
 
 
-def load_audio(audio) -> torch.Tensor:
-    """torch.Tensor / np.ndarray (already 16 kHz mono, as the reference requires for arrays) or a PCM .wav path
-    (stdlib reader + polyphase resample; no ffmpeg offline).  Returns a 1-D f32 tensor (device preserved)."""
-    if isinstance(audio, torch.Tensor):
-        a = audio
-        if a.ndim == 2:
-            a = a.mean(0)
-        return a.to(torch.float32)
+def as_waveform(audio, only_voice_freq: bool = False) -> torch.Tensor:
+    """Whole recording as a 1-D f32 tensor (device preserved for tensors): arrays / tensors are taken as 16 kHz already
+    (2-D = channels first, down-mixed), paths and file bytes are decoded by ``audio_io.prep_audio``
+    (alignment.py:167-176 and the other whole-file callers of the reference's ``prep_audio``)."""
+    audioloader_not_supported(audio)
     if isinstance(audio, np.ndarray):
-        a = torch.from_numpy(np.ascontiguousarray(audio))
-        if a.ndim == 2:
-            a = a.float().mean(0)
-        return a.to(torch.float32)
-    if isinstance(audio, (str, bytes)) and str(audio).lower().endswith(".wav"):
-        with wave.open(audio, "rb") as wf:
-            sr, ch, sw, n = wf.getframerate(), wf.getnchannels(), wf.getsampwidth(), wf.getnframes()
-            raw = wf.readframes(n)
-        if sw != 2:
-            raise RuntimeError("only 16-bit PCM wav files are supported without ffmpeg")
-        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-        x = x.reshape(-1, ch).mean(1)
-        if sr != SAMPLE_RATE:
-            from math import gcd
-            from scipy.signal import resample_poly
-            g = gcd(sr, SAMPLE_RATE)
-            x = resample_poly(x, SAMPLE_RATE // g, sr // g).astype(np.float32)
-        return torch.from_numpy(x)
-    raise RuntimeError(f"Failed to load audio: {type(audio)} (ffmpeg / URL inputs are out of scope offline)")
+        audio = torch.from_numpy(np.ascontiguousarray(audio))
+    if torch.is_tensor(audio):
+        audio = audio.float().mean(0) if audio.ndim == 2 else audio.to(torch.float32)
+    return prep_audio(audio, only_voice_freq=only_voice_freq).to(torch.float32)
+
+
+def pop_audio_options(options: dict) -> dict:
+    """Takes the audio pre-processing options of the reference's whole-file entry points (align / align_words / refine
+    / locate) out of ``options`` and returns the keyword arguments for :func:`as_waveform`.  Denoisers are out of scope
+    (DESIGN.md section 7); ``stream`` has no effect on a recording that is held whole."""
+    for k in ("denoiser", "demucs"):
+        if options.pop(k, None):
+            raise NotImplementedError(f"{k} is outside this package's scope (DESIGN.md section 7)")
+    for k in ("denoiser_options", "demucs_options", "stream", "only_ffmpeg"):
+        options.pop(k, None)
+    return dict(only_voice_freq=bool(options.pop("only_voice_freq", False)))
 
 
 def _xkv_select(model, xkv, idx: Sequence[int]):
@@ -268,9 +264,13 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                       nonspeech_skip: Optional[float] = None, progress_callback: Callable = None,
                       ignore_compatibility: bool = True, split_callback: Callable = None,
                       batch_size: Optional[int] = None, clip_timestamps: Optional[Union[str, List[float]]] = None,
-                      streams: int = 1, **decode_options) -> WhisperResult:
+                      streams: int = 1, stream: Optional[bool] = None, only_voice_freq: bool = False,
+                      only_ffmpeg: bool = False, denoiser: Optional[str] = None, denoiser_options: Optional[dict] = None,
+                      **decode_options) -> WhisperResult:
     """Same keyword surface as the reference's ``model.transcribe`` for the options that reach the hot path
-    (original_whisper.py:27-79); ``batch_size`` (window-parallel mode) is the only addition."""
+    (original_whisper.py:27-79); ``batch_size`` (window-parallel mode) and ``streams`` are the only additions.
+    ``audio``: waveform (tensor / array, 16 kHz), file path or file bytes, or an ``AudioLoader``; ``stream`` loads files
+    in chunks as the seek advances (default for paths, as in the reference)."""
     unknown = set(decode_options) - _DECODE_KEYS
     if unknown:
         raise TypeError(f"transcribe() got unexpected keyword argument(s): {sorted(unknown)}")
@@ -281,15 +281,35 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     if "max_initial_timestamp" not in decode_options:
         decode_options["max_initial_timestamp"] = None                                         # :262-263
     task = decode_options.get("task", "transcribe")
-    audio = load_audio(audio)
-    total = int(audio.shape[-1])
+
+    # clip_timestamps (original_whisper.py:280-287): pairs of seconds; only those sections are loaded and processed
+    if isinstance(clip_timestamps, str):
+        clip_timestamps = [float(ts) for ts in (clip_timestamps.split(",") if clip_timestamps else [])]
+    sections = None
+    if clip_timestamps:
+        if batch_size:
+            raise NotImplementedError("clip_timestamps is defined on the sequential driver (window-parallel mode: slice the audio)")
+        sections = [list(clip_timestamps[i:i + 2]) for i in range(0, len(clip_timestamps), 2)]
+        if len(sections[-1]) == 1:
+            sections[-1] = [sections[-1][0], None]
+    if isinstance(audio, AudioLoader):                                                          # :289-298
+        audio.validate_external_args(sr=SAMPLE_RATE, vad=vad, stream=stream, denoiser=denoiser,
+                                     denoiser_options=denoiser_options, only_voice_freq=only_voice_freq)
+        audio.load_sections = sections
+        loader = audio
+    else:                                                                                       # :299-311
+        if torch.is_tensor(audio) or isinstance(audio, np.ndarray):
+            audio = as_waveform(audio)
+        loader = AudioLoader(audio, stream=stream, denoiser=denoiser, denoiser_options=denoiser_options,
+                             only_voice_freq=only_voice_freq, only_ffmpeg=only_ffmpeg, verbose=verbose,
+                             new_chunk_divisor=None, load_sections=sections)
 
     language = decode_options.get("language")
     if not language:
         if not model.is_multilingual:
             language = "en"
         else:                                                                                   # :319-336
-            first = audio[:N_SAMPLES]
+            first = loader.next_chunk(0, N_SAMPLES)
             mel0 = model.log_mel(first, N_SAMPLES - first.shape[-1])
             _, probs = model.detect_language(mel0)
             language = max(probs, key=probs.get)
@@ -320,45 +340,14 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
 
     all_segments: List[dict] = []
 
-    # clip_timestamps (original_whisper.py:280-287; audio/__init__.py:414-441): only the listed [start, end) sections are
-    # processed; a window never crosses a section end and the seek jumps to the next section's start
-    sections: List[Tuple[int, Optional[int]]] = []
-    if isinstance(clip_timestamps, str):
-        clip_timestamps = [float(ts) for ts in (clip_timestamps.split(",") if clip_timestamps else [])]
-    if clip_timestamps:
-        if batch_size:
-            raise NotImplementedError("clip_timestamps is defined on the sequential driver (window-parallel mode: slice the audio)")
-        pairs = [list(clip_timestamps[i:i + 2]) for i in range(0, len(clip_timestamps), 2)]
-        if len(pairs[-1]) == 1:
-            pairs[-1] = [pairs[-1][0], None]
-        sections = [(None if a is None else round(a * SAMPLE_RATE), None if b is None else round(b * SAMPLE_RATE)) for a, b in pairs]
-    section_state = dict(index=-1, span=(0, 0))
+    def host_copy(seg: torch.Tensor) -> torch.Tensor:
+        return seg.detach().float().cpu()                       # silence analysis is host-side vector code (CPU)
 
-    def next_valid_seek(seek: int) -> Tuple[Optional[int], Optional[int]]:
-        """-> (seek moved into the current / next section, or None when no section is left; exclusive end of that section)"""
-        if not sections:
-            return seek, None
-        while section_state["span"][1] is not None and seek + 1 >= section_state["span"][1]:
-            if section_state["index"] + 1 >= len(sections):
-                return None, None
-            section_state["index"] += 1
-            section_state["span"] = sections[section_state["index"]]
-            if seek < section_state["span"][0]:
-                seek = section_state["span"][0]
-        return seek, section_state["span"][1]
-
-    # silence analysis is host-side vector code (CPU); keep one host copy of the recording for it
-    audio_host = audio.detach().float().cpu() if nonspeech is not None else None
-    pred_cache = {}
-
-    def window_input(seek: int, prompt: List[int], stop: Optional[int] = None):
-        n_max = N_SAMPLES if stop is None else min(N_SAMPLES, stop - seek)
-        seg = audio[seek: seek + n_max]
+    def window_input(seek: int, seg: torch.Tensor, prompt: List[int], pred: Optional[dict] = None):
         item = dict(audio=seg, seek_sample=seek, prompt=prompt, ts_mask=None, silence=None, skip=False)
         if nonspeech is not None:
-            pred = pred_cache.pop(seek, None) if stop is None else None
             if pred is None:
-                pred = nonspeech.predict(audio_host[seek: seek + n_max], offset=seek / SAMPLE_RATE)
+                pred = nonspeech.predict(host_copy(seg), offset=seek / SAMPLE_RATE)
             item["silence"] = pred["timings"] if suppress_silence else None
             item["ts_mask"] = pred["mask"]
             item["skip"] = pred["is_silent"]
@@ -393,13 +382,23 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     seek = 0
     if batch_size:
         # ---- window-parallel driver: fixed stride, no prompt carry-over
-        seeks = list(range(0, total, N_SAMPLES))
-        if nonspeech is not None and len(seeks) > 1:
-            # the windows are known up front in this mode: analyse them concurrently (torch/numpy release the GIL)
+        # the loader hands out the windows in order (a streamed source only moves forward); chunks are short-lived
+        def batches():
+            pos, group = 0, []
+            while (chunk := loader.next_chunk(pos, N_SAMPLES)) is not None:
+                group.append((pos, chunk))
+                pos += N_SAMPLES
+                if len(group) == batch_size:
+                    yield group
+                    group = []
+            if group:
+                yield group
+
+        pool = None
+        if nonspeech is not None:
+            # the windows of a batch are known up front in this mode: analyse them concurrently (torch/numpy release the GIL)
             from concurrent.futures import ThreadPoolExecutor
-            with ThreadPoolExecutor(max_workers=8) as pool:
-                preds = list(pool.map(lambda sk: nonspeech.predict(audio_host[sk: sk + N_SAMPLES], offset=sk / SAMPLE_RATE), seeks))
-            pred_cache.update(zip(seeks, preds))
+            pool = ThreadPoolExecutor(max_workers=8)
         lanes = None
         if streams and streams > 1:
             # experimental: each batch is split over `streams` host threads, each driving its own HIP stream through its
@@ -419,8 +418,12 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                 side.synchronize()
             return outs_k
 
-        for b0 in range(0, len(seeks), batch_size):
-            items = [window_input(s, list(initial_prompt_tokens)) for s in seeks[b0: b0 + batch_size]]
+        done = 0
+        for group in batches():
+            preds = [None] * len(group)
+            if pool is not None and len(group) > 1:
+                preds = list(pool.map(lambda g: nonspeech.predict(host_copy(g[1]), offset=g[0] / SAMPLE_RATE), group))
+            items = [window_input(sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
             live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
             if lanes and len(live) >= len(lanes):
                 per = (len(live) + len(lanes) - 1) // len(lanes)
@@ -430,18 +433,22 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                 outs = _process_batch(model, tokenizer, live, o) if live else []
             for it, out in zip(live, outs):
                 commit(it, out)
+            done += len(items)
             if progress_callback is not None:
-                progress_callback(min(total, (b0 + len(items)) * N_SAMPLES) / SAMPLE_RATE, total / SAMPLE_RATE)
+                total = loader.get_total_samples()
+                progress_callback(min(total, done * N_SAMPLES) / SAMPLE_RATE, total / SAMPLE_RATE)
         if lanes:
             lane_pool.shutdown()
+        if pool is not None:
+            pool.shutdown()
     else:
         # ---- sequential driver (reference control flow)
         prompt_reset_since = 0
-        while seek < total:
-            seek, stop = next_valid_seek(seek)
-            if seek is None:
+        while True:
+            seg, seek = loader.next_valid_chunk(seek, N_SAMPLES)                                # :494-500
+            if seg is None:
                 break
-            item = window_input(seek, all_tokens[prompt_reset_since:], stop)
+            item = window_input(seek, seg, all_tokens[prompt_reset_since:])
             n_seg = int(item["audio"].shape[-1])
             if n_seg == 0:
                 break
@@ -455,7 +462,9 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                     prompt_reset_since = len(all_tokens)
             seek += max(int(adv), 1) if adv is not None else n_seg
             if progress_callback is not None:
+                total = loader.get_total_samples()
                 progress_callback(min(seek, total) / SAMPLE_RATE, total / SAMPLE_RATE)
+    loader.terminate()                                                                          # :731
 
     text = tokenizer.decode(all_tokens[len(initial_prompt_tokens):])
     result = WhisperResult(dict(text=text, segments=all_segments, language=language), force_order=not word_timestamps)

@@ -161,3 +161,43 @@ def test_transcribe_edge_inputs_match_reference(models, monkeypatch, kind):
         got = mine.transcribe(audio, language="en", **BASE)
     assert _snap(got) == _snap(want)
     assert got.text == want.text
+
+
+def test_transcribe_audio_sources_agree(models, monkeypatch, tmp_path):
+    """the same recording as tensor, 16 kHz WAVE path (streamed in chunks by default, or loaded whole), file bytes and
+    AudioLoader instance -- sequential and window-parallel drivers -- and the reference's transcribe on the tensor"""
+    import wave
+    import numpy as np
+    from stable_ts_amd.audio_io import AudioLoader
+    G, ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    pcm = (np.asarray(G.synth_audio(47.0, seed=21)) * 32768).round().clip(-32768, 32767).astype("<i2")
+    audio = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
+    path = str(tmp_path / "rec.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1), w.setsampwidth(2), w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **BASE)
+        base = _snap(mine.transcribe(audio, language="en", **BASE))
+        assert base == _snap(want) and len(base) > 0
+        assert _snap(mine.transcribe(path, language="en", progress_callback=lambda a, b: seen.append((a, b)), **BASE)) == base
+        assert _snap(mine.transcribe(path, language="en", stream=False, **BASE)) == base
+        assert _snap(mine.transcribe(open(path, "rb").read(), language="en", **BASE)) == base
+        assert _snap(mine.transcribe(AudioLoader(path, buffer_size="7s"), language="en", **BASE)) == base
+        assert _snap(mine.transcribe(AudioLoader(audio), language="en", **BASE)) == base
+        # sections through a caller-made loader: transcribe overrides its sections with clip_timestamps like the reference
+        clip = dict(clip_timestamps=[5.0, 22.0, 30.0], regroup=False)
+        want_clip = _snap(ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **BASE, **clip))
+        assert _snap(mine.transcribe(AudioLoader(path, load_sections=[(0.0, 1.0)]), language="en", **BASE, **clip)) == want_clip
+        # window-parallel driver: the streamed file hands out the same windows as the tensor
+        par = _snap(mine.transcribe(audio, language="en", batch_size=2, **BASE))
+        assert _snap(mine.transcribe(path, language="en", batch_size=2, **BASE)) == par
+    assert seen and seen[-1][1] == pytest.approx(len(pcm) / 16000) and all(a <= b for a, b in seen)
+    with pytest.raises(NotImplementedError):
+        mine.transcribe(audio, language="en", denoiser="demucs", **BASE)
+    with pytest.raises(RuntimeError):
+        mine.transcribe(str(tmp_path / "missing.wav"), language="en", **BASE)
