@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--ts-gain", type=float, default=0.5)
     ap.add_argument("--max-instant-words", type=float, default=None)
     ap.add_argument("--streams", type=int, default=1, help="experimental: host threads / HIP streams per batch (engine clones)")
+    ap.add_argument("--spans", type=int, default=0, help="experimental: span-parallel mode (the reference's sequential "
+                    "algorithm on this many spans in lockstep, spans.py) instead of the fixed-stride window batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="hard cap (s) on the CPU-baseline leg")
@@ -129,7 +131,13 @@ def main():
     if args.streams > 1:
         kw["streams"] = args.streams
 
+    if args.spans > 0:
+        kw.pop("batch_size")
+        kw.pop("streams", None)
+
     def step():
+        if args.spans > 0:
+            return model.transcribe_spans(audio, min(args.spans, args.batch), **kw)
         return model.transcribe(audio, **kw)
 
     res = None
@@ -162,7 +170,8 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} (random-init), {args.minutes:g} min synthetic 16 kHz audio per GPU, "
                                    f"word_timestamps=True, beam_size={args.beam}, {args.tokens} decode steps/window, "
-                                   f"window-parallel batch {args.batch}",
+                                   + (f"span-parallel, {min(args.spans, args.batch)} spans in lockstep" if args.spans > 0
+                                      else f"window-parallel batch {args.batch}"),
                        "windows_per_gpu": int(np.ceil(seconds / 30.0)), "segments": n_segs, "words": n_words,
                        "parallelism": f"dp{world} (windows sharded, no data-path collective)"},
         }

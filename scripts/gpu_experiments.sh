@@ -29,3 +29,6 @@ SWX_PG_POLICY="5120x1280=1,3840x1280=1" T=200 run pass_fat python scripts/tune_f
 SWX_PG_POLICY="5120x1280=1,3840x1280=1,1280x1280=5,1280x5120=8" T=200 run pass_fat_all python scripts/tune_flags.py --flags 84,340
 L=3 T=200 run bench_streams2 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --streams 2
 L=3 T=200 run bench_rich python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --embed-gain 3 --ts-gain 0.01 --max-instant-words 1
+# span-parallel mode (exact per-span sequential semantics, spans.py): first device run + its rate next to the window batches
+L=3 T=240 run bench_spans20 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --spans 20
+L=3 T=240 run bench_spans8 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --spans 8

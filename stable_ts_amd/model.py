@@ -256,6 +256,8 @@ class Whisper:
         self.refine = types.MethodType(refine, self)
         from .locator import locate
         self.locate = types.MethodType(locate, self)
+        from .spans import transcribe_spans
+        self.transcribe_spans = types.MethodType(transcribe_spans, self)
 
 
 def _read_checkpoint(path: str):

@@ -70,14 +70,35 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
-def transcribe_sharded(model, audio: torch.Tensor, *, batch_size: int = 8, **kw):
-    """Window-parallel transcription of ONE long recording over all ranks: rank r takes the contiguous span of 30-s
-    windows `shard_windows(...)`, runs `model.transcribe(span, batch_size=...)`, shifts its timestamps by the span offset
-    and the segments are gathered on rank 0 (returns a WhisperResult there, None elsewhere)."""
+def transcribe_sharded(model, audio: torch.Tensor, *, batch_size: int = 8, mode: str = "windows", spans_per_rank: int = 4,
+                       **kw):
+    """Transcription of ONE long recording over all ranks; the segments are gathered on rank 0 (returns a WhisperResult
+    there, None elsewhere).
+
+    ``mode="windows"``: rank r takes the contiguous block of 30-s windows `shard_windows(...)` and runs
+    `model.transcribe(block, batch_size=...)` (fixed stride, no prompt carry-over).
+    ``mode="spans"``: the recording is cut at quiet places into ``world * spans_per_rank`` spans (every rank computes the
+    same plan from the same audio), rank r takes a contiguous run of them and advances them in lockstep with the
+    reference's sequential algorithm per span (spans.py) -- equal to the reference run once per span."""
     from .audio import N_SAMPLES, SAMPLE_RATE
     from .result import WhisperResult
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
+    if mode == "spans":
+        from .spans import merge_span_results, plan_spans, transcribe_spans
+        plan = plan_spans(audio.detach().float().cpu(), world * spans_per_rank, q_levels=kw.get("q_levels", 20),
+                          k_size=kw.get("k_size", 5))
+        mine = [plan[i] for i in shard_windows(len(plan), rank, world)]
+        parts = []
+        if mine:
+            res = transcribe_spans(model, audio, spans=mine, **kw)
+            parts = [(0, res.to_dict())]
+        gathered = gather_results(parts)
+        if gathered is None:
+            return None
+        return merge_span_results([(o, WhisperResult(d, check_sorted=False)) for o, d in gathered], kw.get("language"))
+    if mode != "windows":
+        raise ValueError(f"unknown mode {mode!r}")
     n_win = (int(audio.shape[-1]) + N_SAMPLES - 1) // N_SAMPLES
     mine = shard_windows(n_win, rank, world)
     segs = []

@@ -266,7 +266,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                       batch_size: Optional[int] = None, clip_timestamps: Optional[Union[str, List[float]]] = None,
                       streams: int = 1, stream: Optional[bool] = None, only_voice_freq: bool = False,
                       only_ffmpeg: bool = False, denoiser: Optional[str] = None, denoiser_options: Optional[dict] = None,
-                      **decode_options) -> WhisperResult:
+                      _span_bounds: Optional[List[Tuple[int, int]]] = None, **decode_options) -> WhisperResult:
     """Same keyword surface as the reference's ``model.transcribe`` for the options that reach the hot path
     (original_whisper.py:27-79); ``batch_size`` (window-parallel mode) and ``streams`` are the only additions.
     ``audio``: waveform (tensor / array, 16 kHz), file path or file bytes, or an ``AudioLoader``; ``stream`` loads files
@@ -316,17 +316,26 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     decode_options["language"] = language
     tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language, task=task)
 
-    all_tokens: List[int] = []
     initial_prompt_tokens: List[int] = []
     if initial_prompt is not None:                                                              # :342-345
         initial_prompt_tokens = tokenizer.encode(" " + initial_prompt.strip())
-        all_tokens.extend(initial_prompt_tokens)
 
-    nonspeech = None
-    if suppress_silence or suppress_ts_tokens or nonspeech_skip:
-        from .stabilization import NonSpeechPredictor
-        nonspeech = NonSpeechPredictor(q_levels=q_levels, k_size=k_size, min_word_dur=min_word_dur,
-                                       min_silence_dur=min_silence_dur, get_mask=suppress_ts_tokens)
+    def new_track(source: AudioLoader, offset: int = 0) -> _Track:
+        predictor = None
+        if suppress_silence or suppress_ts_tokens or nonspeech_skip:
+            from .stabilization import NonSpeechPredictor
+            predictor = NonSpeechPredictor(q_levels=q_levels, k_size=k_size, min_word_dur=min_word_dur,
+                                           min_silence_dur=min_silence_dur, get_mask=suppress_ts_tokens)
+        return _Track(source, predictor, list(initial_prompt_tokens), offset)
+
+    # one track = one run of the reference's sequential algorithm; ``_span_bounds`` (transcribe_spans) makes several
+    if _span_bounds:
+        whole = loader.next_chunk(0, loader.get_total_samples())
+        tracks = [new_track(AudioLoader(whole[a0:b0], new_chunk_divisor=None), a0) for a0, b0 in _span_bounds]
+    else:
+        tracks = [new_track(loader)]
+    tr0 = tracks[0]
+    nonspeech = tr0.nonspeech
 
     o = dict(decode_options=decode_options,
              temperatures=[temperature] if isinstance(temperature, (int, float)) else list(temperature),
@@ -338,16 +347,14 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
              gap_padding=gap_padding, max_instant_words=max_instant_words, avg_prob_threshold=avg_prob_threshold,
              suppress_ts_tokens=suppress_ts_tokens)
 
-    all_segments: List[dict] = []
-
     def host_copy(seg: torch.Tensor) -> torch.Tensor:
         return seg.detach().float().cpu()                       # silence analysis is host-side vector code (CPU)
 
-    def window_input(seek: int, seg: torch.Tensor, prompt: List[int], pred: Optional[dict] = None):
+    def window_input(tr: _Track, seek: int, seg: torch.Tensor, prompt: List[int], pred: Optional[dict] = None):
         item = dict(audio=seg, seek_sample=seek, prompt=prompt, ts_mask=None, silence=None, skip=False)
-        if nonspeech is not None:
+        if tr.nonspeech is not None:
             if pred is None:
-                pred = nonspeech.predict(host_copy(seg), offset=seek / SAMPLE_RATE)
+                pred = tr.nonspeech.predict(host_copy(seg), offset=seek / SAMPLE_RATE)
             item["silence"] = pred["timings"] if suppress_silence else None
             item["ts_mask"] = pred["mask"]
             item["skip"] = pred["is_silent"]
@@ -364,22 +371,43 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                         item["audio"] = seg[: int(starts[k] * SAMPLE_RATE)]
         return item
 
-    def commit(item: dict, out: dict):
+    def commit(tr: _Track, item: dict, out: dict):
         """original_whisper.py:676-708 for one finished window; returns the samples to advance by."""
         segs = out["segments"]
         if not segs:
             return out["segment_samples"]
-        all_tokens.extend(t for s in segs for t in s["tokens"])
+        tr.all_tokens.extend(t for s in segs for t in s["tokens"])
         if item["silence"] is not None:
             from .stabilization import suppress_segment_silence
             for s in segs:
                 suppress_segment_silence(s, *item["silence"], min_word_dur=o["min_word_dur"], word_level=suppress_word_ts,
                                          nonspeech_error=nonspeech_error, use_word_position=use_word_position)
         for s in segs:
-            all_segments.append({"id": len(all_segments), **s})
+            tr.all_segments.append({"id": len(tr.all_segments), **s})
         return out["segment_samples"]
 
-    seek = 0
+    def next_live_item(tr: _Track) -> Optional[dict]:
+        """the head of one iteration of the reference's loop (:494-526): fetch the window at the track's seek, fast-forward
+        over windows the silence analysis skips; None when the track has no audio left"""
+        while True:
+            seg, tr.seek = tr.loader.next_valid_chunk(tr.seek, N_SAMPLES)                        # :494-500
+            if seg is None:
+                return None
+            item = window_input(tr, tr.seek, seg, tr.all_tokens[tr.prompt_reset_since:])
+            n_seg = int(item["audio"].shape[-1])
+            if n_seg == 0:
+                return None
+            if not item["skip"]:
+                return item
+            tr.seek += item.get("skip_samples", n_seg)
+
+    def advance(tr: _Track, item: dict, out: dict):
+        adv = commit(tr, item, out)
+        if out["segments"]:
+            if not condition_on_previous_text or out["result"].temperature > 0.5:                # :706-708
+                tr.prompt_reset_since = len(tr.all_tokens)
+        tr.seek += max(int(adv), 1) if adv is not None else int(item["audio"].shape[-1])
+
     if batch_size:
         # ---- window-parallel driver: fixed stride, no prompt carry-over
         # the loader hands out the windows in order (a streamed source only moves forward); chunks are short-lived
@@ -423,7 +451,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             preds = [None] * len(group)
             if pool is not None and len(group) > 1:
                 preds = list(pool.map(lambda g: nonspeech.predict(host_copy(g[1]), offset=g[0] / SAMPLE_RATE), group))
-            items = [window_input(sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
+            items = [window_input(tr0, sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
             live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
             if lanes and len(live) >= len(lanes):
                 per = (len(live) + len(lanes) - 1) // len(lanes)
@@ -432,7 +460,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             else:
                 outs = _process_batch(model, tokenizer, live, o) if live else []
             for it, out in zip(live, outs):
-                commit(it, out)
+                commit(tr0, it, out)
             done += len(items)
             if progress_callback is not None:
                 total = loader.get_total_samples()
@@ -442,37 +470,47 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
         if pool is not None:
             pool.shutdown()
     else:
-        # ---- sequential driver (reference control flow)
-        prompt_reset_since = 0
-        while True:
-            seg, seek = loader.next_valid_chunk(seek, N_SAMPLES)                                # :494-500
-            if seg is None:
+        # ---- sequential driver (reference control flow); with several tracks the tracks advance in lockstep, one window
+        # of each per device batch -- every track still sees exactly the reference's sequence of windows and prompts
+        active = list(tracks)
+        while active:
+            items = [(tr, it) for tr in active if (it := next_live_item(tr)) is not None]
+            if not items:
                 break
-            item = window_input(seek, seg, all_tokens[prompt_reset_since:])
-            n_seg = int(item["audio"].shape[-1])
-            if n_seg == 0:
-                break
-            if item["skip"]:
-                seek += item.get("skip_samples", n_seg)
-                continue
-            out = _process_batch(model, tokenizer, [item], o)[0]
-            adv = commit(item, out)
-            if out["segments"]:
-                if not condition_on_previous_text or out["result"].temperature > 0.5:            # :706-708
-                    prompt_reset_since = len(all_tokens)
-            seek += max(int(adv), 1) if adv is not None else n_seg
+            outs = _process_batch(model, tokenizer, [it for _, it in items], o)
+            for (tr, it), out in zip(items, outs):
+                advance(tr, it, out)
+            active = [tr for tr, _ in items]
             if progress_callback is not None:
                 total = loader.get_total_samples()
-                progress_callback(min(seek, total) / SAMPLE_RATE, total / SAMPLE_RATE)
+                at = sum(min(tr.seek, tr.loader.get_total_samples()) for tr in tracks)
+                progress_callback(min(at, total) / SAMPLE_RATE, total / SAMPLE_RATE)
     loader.terminate()                                                                          # :731
 
-    text = tokenizer.decode(all_tokens[len(initial_prompt_tokens):])
-    result = WhisperResult(dict(text=text, segments=all_segments, language=language), force_order=not word_timestamps)
-    if nonspeech is not None and suppress_silence:
-        result.nonspeech_sections = nonspeech.sections()
-    if word_timestamps and regroup:
-        from .regroup import regroup_default
-        regroup_default(result, regroup)
+    def finish(tr: _Track) -> WhisperResult:
+        text = tokenizer.decode(tr.all_tokens[len(initial_prompt_tokens):])
+        result = WhisperResult(dict(text=text, segments=tr.all_segments, language=language), force_order=not word_timestamps)
+        if tr.nonspeech is not None and suppress_silence:
+            result.nonspeech_sections = tr.nonspeech.sections()
+        if word_timestamps and regroup:
+            from .regroup import regroup_default
+            regroup_default(result, regroup)
+        return result
+
+    if _span_bounds:
+        return [(tr.offset, finish(tr)) for tr in tracks]
+    result = finish(tr0)
     if len(result.text) == 0:
         warnings.warn(f"Failed to {task} audio. Result contains no text. ")
     return result
+
+
+class _Track:
+    """State of one run of the reference's sequential window loop (seek, prompt history, segments, silence analysis)."""
+    __slots__ = ("loader", "nonspeech", "all_tokens", "all_segments", "prompt_reset_since", "seek", "offset")
+
+    def __init__(self, loader: AudioLoader, nonspeech, prompt_tokens: List[int], offset: int = 0):
+        self.loader, self.nonspeech, self.all_tokens, self.offset = loader, nonspeech, prompt_tokens, offset
+        self.all_segments: List[dict] = []
+        self.prompt_reset_since = 0
+        self.seek = 0
