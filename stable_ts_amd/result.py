@@ -26,15 +26,47 @@ def _blend(a, b):
     return None if b is None else (a + b) / 2
 
 
+def format_timestamp(seconds: float, always_include_hours: bool = False, decimal_marker: str = ".") -> str:
+    """utils.py:47-65: ``[HH:]MM:SS.mmm``"""
+    assert seconds >= 0, "non-negative timestamp expected"
+    ms = round(seconds * 1000.0)
+    hours, ms = divmod(ms, 3_600_000)
+    minutes, ms = divmod(ms, 60_000)
+    secs, ms = divmod(ms, 1_000)
+    head = f"{hours:02d}:" if always_include_hours or hours > 0 else ""
+    return f"{head}{minutes:02d}:{secs:02d}{decimal_marker}{ms:03d}"
+
+
+def group_by_lock(words: List["WordTiming"], only_text: bool = False, include_single: bool = False) -> list:
+    """result.py:260-274: runs of words that lock flags tie together (a boundary is tied when the left word is
+    right-locked or the right word is left-locked)."""
+    runs: List[list] = []
+    for w in words:
+        if runs and (runs[-1][-1].right_locked or w.left_locked):
+            runs[-1].append(w)
+        else:
+            runs.append([w])
+    if not include_single:
+        runs = [r for r in runs if len(r) > 1]
+    return [[w.word for w in r] for r in runs] if only_text else runs
+
+
+def _deprecated(what: str, instead: str):
+    warnings.warn(f"``{what}`` is deprecated and will be removed in future versions. {instead}", stacklevel=3)
+
+
 class WordTiming:
-    __slots__ = ("word", "_start", "_end", "probability", "tokens", "left_locked", "right_locked", "id", "segment")
+    __slots__ = ("word", "_start", "_end", "probability", "tokens", "left_locked", "right_locked", "id", "segment",
+                 "round_ts")
 
     def __init__(self, word: str, start: float, end: float, probability: Optional[float] = None,
                  tokens: Optional[List[int]] = None, left_locked: bool = False, right_locked: bool = False,
-                 segment_id: Optional[int] = None, id: Optional[int] = None, segment: Optional["Segment"] = None, **_):
+                 segment_id: Optional[int] = None, id: Optional[int] = None, segment: Optional["Segment"] = None,
+                 round_ts: bool = True, **_):
+        self.round_ts = round_ts
         self.word = word
-        self._start = _ms(start)
-        self._end = _ms(end)
+        self._start = self.round(start)
+        self._end = self.round(end)
         self.probability = probability
         self.tokens = tokens
         self.left_locked = bool(left_locked)
@@ -49,7 +81,7 @@ class WordTiming:
 
     @start.setter
     def start(self, v):
-        self._start = _ms(v)
+        self._start = self.round(v)
 
     @property
     def end(self):
@@ -57,11 +89,29 @@ class WordTiming:
 
     @end.setter
     def end(self, v):
-        self._end = _ms(v)
+        self._end = self.round(v)
 
     @property
     def duration(self):
-        return _ms(self._end - self._start)
+        return self.round(self._end - self._start)
+
+    def round(self, timestamp):
+        return _ms(timestamp) if self.round_ts else timestamp
+
+    def round_all_timestamps(self):
+        _deprecated(".round_all_timestamps()", "Use ``.round_ts=True`` to round timestamps by default instead.")
+        self.round_ts = True
+
+    def to_display_str(self) -> str:
+        return f'[{format_timestamp(self.start)}] -> [{format_timestamp(self.end)}] "{self.word}"'
+
+    def set_segment(self, segment: "Segment"):
+        _deprecated(".set_segment(current_segment_instance)", "Use ``.segment = current_segment`` instead.")
+        self.segment = segment
+
+    def get_segment(self) -> Optional["Segment"]:
+        warnings.warn("``.get_segment()`` will be removed in future versions. Use ``.segment`` instead.", stacklevel=2)
+        return self.segment
 
     @property
     def segment_id(self):
@@ -73,12 +123,19 @@ class WordTiming:
     def __repr__(self):
         return f'WordTiming(start={self.start}, end={self.end}, word="{self.word}")'
 
-    def copy(self, copy_tokens: bool = False) -> "WordTiming":
+    def copy(self, keep_segment: bool = False, copy_tokens: bool = False) -> "WordTiming":
         toks = self.tokens
         if toks is not None and copy_tokens:
             toks = list(toks)
         return WordTiming(self.word, self._start, self._end, self.probability, toks, self.left_locked,
-                          self.right_locked, id=self.id)
+                          self.right_locked, id=self.id, segment=self.segment if keep_segment else None,
+                          round_ts=self.round_ts)
+
+    def __copy__(self):
+        return self.copy()
+
+    def __deepcopy__(self, memo=None):
+        return self.copy(copy_tokens=True)
 
     def joined(self, other: "WordTiming") -> "WordTiming":
         """result.py:111-127 (``a + b``): text concatenated, span = union, probability averaged, tokens chained."""
@@ -136,11 +193,12 @@ class Segment:
                  seek: Optional[float] = None, tokens: Optional[List[int]] = None, temperature: Optional[float] = None,
                  avg_logprob: Optional[float] = None, compression_ratio: Optional[float] = None,
                  no_speech_prob: Optional[float] = None, words: Optional[List[Union[WordTiming, dict]]] = None,
-                 id: Optional[int] = None, result: Optional["WhisperResult"] = None, **_):
+                 id: Optional[int] = None, result: Optional["WhisperResult"] = None, round_ts: bool = True, **_):
         if words:                                   # with words, start/end/text/tokens are views of the words
             start = end = text = tokens = None
-        self._default_start = _ms(start) if start else 0.0
-        self._default_end = _ms(end) if end else 0.0
+        self.round_ts = round_ts
+        self._default_start = self.round(start) if start else 0.0
+        self._default_end = self.round(end) if end else 0.0
         self._default_text = text or ""
         self._default_tokens = tokens or []
         self.seek = seek
@@ -152,7 +210,7 @@ class Segment:
         self.result = result
         self.words: Optional[List[WordTiming]] = None
         if words is not None:
-            self.words = [w if isinstance(w, WordTiming) else WordTiming(**w) for w in words]
+            self.words = [w if isinstance(w, WordTiming) else WordTiming(**w, round_ts=round_ts) for w in words]
             self.reassign_ids()
 
     # -- views
@@ -173,7 +231,7 @@ class Segment:
         if self.words:
             self.words[0].start = v
         else:
-            self._default_start = _ms(v)
+            self._default_start = self.round(v)
 
     @property
     def end(self):
@@ -184,7 +242,7 @@ class Segment:
         if self.words:
             self.words[-1].end = v
         else:
-            self._default_end = _ms(v)
+            self._default_end = self.round(v)
 
     @property
     def text(self) -> str:
@@ -219,8 +277,135 @@ class Segment:
             raise ValueError("segment contains no words")
         return self.words[i]
 
+    def __delitem__(self, i):
+        if self.words is None:
+            raise ValueError("segment contains no words")
+        del self.words[i]
+        self.reassign_ids(i)
+
     def __repr__(self):
         return f'Segment(start={self.start}, end={self.end}, text="{self.text}")'
+
+    def round(self, timestamp):
+        return _ms(timestamp) if self.round_ts else timestamp
+
+    def round_all_timestamps(self):
+        _deprecated(".round_all_timestamps()", "Use ``.round_ts=True`` to round timestamps by default instead.")
+        self.round_ts = True
+
+    def to_display_str(self, only_segment: bool = False) -> str:
+        line = f'[{format_timestamp(self.start)} --> {format_timestamp(self.end)}] "{self.text}"'
+        if self.words and not only_segment:
+            line += "\n" + "\n".join(f"-{w.to_display_str()}" for w in self.words) + "\n"
+        return line
+
+    def set_result(self, result: "WhisperResult"):
+        _deprecated(".set_result(current_result_instance)", "Use ``.result = current_result_instance`` instead.")
+        self.result = result
+
+    def get_result(self) -> Optional["WhisperResult"]:
+        warnings.warn("``.get_result()`` will be removed in future versions. Use ``.result`` instead.", stacklevel=2)
+        return self.result
+
+    def update_seg_with_words(self):
+        _deprecated("update_seg_with_words()", "Use ``.reassign_ids()`` to manually update ids")
+        self.reassign_ids()
+
+    def __copy__(self):
+        return self.copy()
+
+    def __deepcopy__(self, memo=None):
+        return self.copy(copy_words=True, copy_tokens=True)
+
+    # -- word-level surgery and the index pickers of the regrouping methods (result.py:464-560, 707-902)
+    def add(self, other: "Segment", copy_words: bool = False, newline: bool = False, reassign_ids: bool = True) -> "Segment":
+        """the two segments fused into a new one: words concatenated, decode statistics averaged (:464-493)"""
+        from .regroup import _fuse
+        if self.ori_has_words != other.ori_has_words:
+            a, b = ("with" if s.ori_has_words else "without" for s in (self, other))
+            raise ValueError(f"Can't merge segment {a} words and a segment {b} words.")
+        left, right = (self.copy(copy_words=True), other.copy(copy_words=True)) if copy_words else (self, other)
+        fused = _fuse(left, right, newline)
+        if reassign_ids:
+            fused.reassign_ids()
+        return fused
+
+    def __add__(self, other: "Segment") -> "Segment":
+        return self.add(other, copy_words=True)
+
+    def add_words(self, index0: int, index1: int, inplace: bool = False) -> Optional[WordTiming]:
+        if not self.words:
+            return None
+        joined = self.words[index0] + self.words[index1]
+        if inplace:
+            i0, i1 = sorted([index0, index1])
+            self.words[i0] = joined
+            del self.words[i1]
+        return joined
+
+    def apply_min_dur(self, min_dur: float, inplace: bool = False) -> "Segment":
+        """Words shorter than ``min_dur`` are joined with a neighbour -- the shorter one when both exist (:536-560)."""
+        seg = self if inplace else self.copy(copy_words=True, copy_tokens=True)
+        if not self.words or len(seg.words) < 2:
+            return seg
+        last = len(seg.words) - 1
+        for i in reversed(range(len(seg.words))):
+            if last == 0:
+                break
+            if seg.words[i].duration < min_dur:
+                if i == last:
+                    seg.add_words(i - 1, i, inplace=True)
+                elif i == 0:
+                    seg.add_words(i, i + 1, inplace=True)
+                elif seg.words[i + 1].duration < seg.words[i - 1].duration:
+                    seg.add_words(i - 1, i, inplace=True)
+                else:
+                    seg.add_words(i, i + 1, inplace=True)
+                last -= 1
+        return seg
+
+    def words_by_lock(self, only_text: bool = True, include_single: bool = False) -> list:
+        return group_by_lock(self.words, only_text=only_text, include_single=include_single)
+
+    def get_locked_indices(self) -> List[int]:
+        from .regroup import _locked_cuts
+        return _locked_cuts(self.words)
+
+    def get_gaps(self, as_ndarray: bool = False):
+        import numpy as np
+        if not self.words:
+            return []
+        gaps = np.array([w.start for w in self.words])[1:] - np.array([w.end for w in self.words])[:-1]
+        return gaps if as_ndarray else gaps.tolist()
+
+    def get_gap_indices(self, max_gap: float = 0.1) -> List[int]:
+        from .regroup import gap_cuts
+        return gap_cuts(self, max_gap)
+
+    def get_punctuation_indices(self, punctuation) -> List[int]:
+        from .regroup import punctuation_cuts
+        return punctuation_cuts(self, punctuation)
+
+    def get_length_indices(self, max_chars: int = None, max_words: int = None, even_split: bool = True,
+                           include_lock: bool = False, ignore_special_periods: bool = False) -> List[int]:
+        from .regroup import length_cuts
+        return [int(i) for i in length_cuts(self, max_chars, max_words, even_split, include_lock, ignore_special_periods)]
+
+    def get_duration_indices(self, max_dur: float, even_split: bool = True, include_lock: bool = False,
+                             ignore_special_periods: bool = False) -> List[int]:
+        from .regroup import duration_cuts
+        return [int(i) for i in duration_cuts(self, max_dur, even_split, include_lock, ignore_special_periods)]
+
+    def split(self, indices: List[int], reassign_ids: bool = True) -> List["Segment"]:
+        """pieces that end after the words ``indices`` (:886-902); the words are shared, not copied"""
+        if len(indices) == 0:
+            return []
+        from .regroup import _pieces
+        parts = _pieces(self, [i for i in indices if i != len(self.words) - 1])
+        if reassign_ids:
+            for p in parts:
+                p.reassign_ids()
+        return parts
 
     # -- construction helpers used by the regrouping functions
     def spawn(self, words: Optional[List[WordTiming]]) -> "Segment":
@@ -230,13 +415,20 @@ class Segment:
         s.words = words
         return s
 
-    def copy(self, copy_words: bool = True) -> "Segment":
-        s = self.spawn(None if self.words is None else
-                       ([w.copy(copy_tokens=True) for w in self.words] if copy_words else self.words))
-        s._default_start, s._default_end = self._default_start, self._default_end
-        s._default_text, s._default_tokens = self._default_text, list(self._default_tokens)
-        if copy_words:
-            s.reassign_ids()
+    def copy(self, new_words: Optional[List[WordTiming]] = None, keep_result: bool = False, copy_words: bool = False,
+             copy_tokens: bool = False) -> "Segment":
+        """result.py:356-396: same decode statistics; the words are shared unless ``copy_words``; with ``new_words`` the
+        copy owns those words instead and drops the segment-level defaults."""
+        src = self.words if new_words is None else new_words
+        words = None if src is None or (new_words is None and not self.words) else (
+            [w.copy(copy_tokens=copy_tokens) for w in src] if copy_words else src)
+        s = Segment(seek=self.seek, temperature=self.temperature, avg_logprob=self.avg_logprob,
+                    compression_ratio=self.compression_ratio, no_speech_prob=self.no_speech_prob, id=self.id,
+                    result=self.result if keep_result else None, round_ts=self.round_ts)
+        s.words = words
+        if new_words is None:
+            s._default_start, s._default_end = self._default_start, self._default_end
+            s._default_text, s._default_tokens = self._default_text, self._default_tokens
         return s
 
     def reassign_ids(self, start: Optional[int] = None):
@@ -468,6 +660,132 @@ class WhisperResult:
     def rescale_time(self, factor: float):
         for s in self.segments:
             s.rescale_time(factor)
+
+    def update_all_segs_with_words(self):
+        _deprecated("update_all_segs_with_words()", "Use ``.reassign_ids()`` to manually update ids")
+        self.reassign_ids()
+
+    def __copy__(self):
+        return self.__deepcopy__()
+
+    def __deepcopy__(self, memo=None):
+        import copy
+        other = WhisperResult.__new__(WhisperResult)
+        for k, v in self.__dict__.items():
+            if k != "segments":
+                setattr(other, k, copy.deepcopy(v, memo))
+        other.segments = [sg.copy(copy_words=True, copy_tokens=True) for sg in self.segments]
+        other.reassign_ids()
+        return other
+
+    def apply_min_dur(self, min_dur: float, inplace: bool = False) -> "WhisperResult":
+        """Segments, then words, shorter than ``min_dur`` are merged into a neighbour -- the shorter one when both exist
+        (result.py:1106-1131)."""
+        res = self if inplace else self.__deepcopy__()
+        last = len(res.segments) - 1
+        if last == 0:
+            return res
+        for i in reversed(range(len(res.segments))):
+            if last == 0:
+                break
+            if res.segments[i].duration < min_dur:
+                if i == last:
+                    res.add_segments(i - 1, i, inplace=True, reassign_ids=False)
+                elif i == 0:
+                    res.add_segments(i, i + 1, inplace=True, reassign_ids=False)
+                elif res.segments[i + 1].duration < res.segments[i - 1].duration:
+                    res.add_segments(i - 1, i, inplace=True, reassign_ids=False)
+                else:
+                    res.add_segments(i, i + 1, inplace=True, reassign_ids=False)
+                last -= 1
+        res.reassign_ids()
+        for sg in res.segments:
+            sg.apply_min_dur(min_dur, inplace=True)
+        return res
+
+    def adjust_by_silence(self, audio, vad=False, *, verbose: Optional[bool] = False, sample_rate: Optional[int] = None,
+                          vad_onnx: bool = False, vad_threshold: float = 0.35, q_levels: int = 20, k_size: int = 5,
+                          min_word_dur: Optional[float] = None, min_silence_dur: Optional[float] = None,
+                          word_level: bool = True, nonspeech_error: float = 0.3,
+                          use_word_position: bool = True) -> "WhisperResult":
+        """Silence detection on ``audio`` (the loudness-based detector) + :meth:`suppress_silence` with its timings
+        (result.py:1191-1285).  ``audio``: waveform at ``sample_rate`` (16 kHz when None), path or file bytes."""
+        if vad is not False:
+            raise NotImplementedError("vad needs the Silero model (torch.hub, network) -- out of scope offline")
+        from .audio import SAMPLE_RATE
+        from .audio_io import audio_to_tensor_resample
+        from .stabilization import mask2timing, wav2mask
+        wave = audio_to_tensor_resample(audio, sample_rate, SAMPLE_RATE)
+        timings = mask2timing(wav2mask(wave, q_levels=q_levels, k_size=k_size))
+        if timings is None:
+            return self
+        if min_silence_dur:
+            keep = (timings[1] - timings[0]) >= min_silence_dur
+            timings = (timings[0][keep], timings[1][keep])
+        self.suppress_silence(*timings, min_word_dur=min_word_dur, word_level=word_level, nonspeech_error=nonspeech_error,
+                              use_word_position=use_word_position)
+        self.update_nonspeech_sections(*timings)
+        return self
+
+    def adjust_by_result(self, other_result: "WhisperResult", min_word_dur: Optional[float] = None, verbose: bool = False):
+        """Each word is narrowed to its overlap with the same word of ``other_result`` when at least ``min_word_dur``
+        remains (result.py:1287-1325)."""
+        if not (self.has_words and other_result.has_words):
+            raise NotImplementedError("This operation can only be performed on results with word timestamps")
+        mine, theirs = self.all_words(), other_result.all_words()
+        assert [w.word for w in mine] == [w.word for w in theirs], "The words in [other_result] do not match the current words."
+        mwd = 0.1 if min_word_dur is None else min_word_dur
+        for w, o in zip(mine, theirs):
+            if w.end <= o.start:
+                continue
+            lo, hi = max(w.start, o.start), min(w.end, o.end)
+            if hi - lo < mwd:
+                continue
+            note = ""
+            if w.start != lo:
+                note += f"[Start:{w.start:.3f}->{lo:.3f}] "
+                w.start = lo
+            if w.end != hi:
+                note += f"[End:{w.end:.3f}->{hi:.3f}]  "
+                w.end = hi
+            if note and verbose:
+                print(f'{note}"{w.word}"')
+
+    # -- boundary pickers of the merge operations (result.py:1341-1379) and lock groups
+    def get_locked_indices(self) -> List[int]:
+        from .regroup import _locked_joins
+        return sorted(_locked_joins(self))
+
+    def get_gaps(self, as_ndarray: bool = False):
+        import numpy as np
+        gaps = np.array([sg.start for sg in self.segments])[1:] - np.array([sg.end for sg in self.segments])[:-1]
+        return gaps if as_ndarray else gaps.tolist()
+
+    def get_gap_indices(self, min_gap: float = 0.1) -> List[int]:
+        from .regroup import gap_joins
+        return gap_joins(self, min_gap)
+
+    def get_punctuation_indices(self, punctuation) -> List[int]:
+        from .regroup import punctuation_joins
+        return punctuation_joins(self, punctuation)
+
+    def all_words_by_lock(self, only_text: bool = True, by_segment: bool = False, include_single: bool = False) -> list:
+        if by_segment:
+            return [sg.words_by_lock(only_text=only_text, include_single=include_single) for sg in self.segments]
+        return group_by_lock(self.all_words(), only_text=only_text, include_single=include_single)
+
+    def segments_to_dicts(self) -> List[dict]:
+        return [sg.to_dict() for sg in self.segments]
+
+    def find(self, pattern: str, word_level: bool = True, flags=None) -> "WhisperResultMatches":
+        """Regular-expression search over the text; the matches carry the segments / words they span (result.py:3026)."""
+        return WhisperResultMatches(self).find(pattern, word_level=word_level, flags=flags)
+
+    def show_regroup_history(self):
+        if not self._regroup_history:
+            print("Result has no history.")
+        for *_, msg in self.parse_regroup_algo(self._regroup_history):
+            print(f".{msg}")
 
     def add_segments(self, index0: int, index1: int, inplace: bool = False, lock: bool = False, newline: bool = False,
                      reassign_ids: bool = True) -> Segment:
@@ -822,3 +1140,98 @@ class WhisperResult:
     def parse_regroup_algo(self, regroup_algo: str, include_str: bool = True):
         from . import regroup as R
         return R.parse_regroup_algo(self, regroup_algo, include_str)
+
+
+class SegmentMatch:
+    """One regular-expression match: the segments it touches and, for a word-level search, the words (result.py:3105)."""
+
+    def __init__(self, segments: Union[List[Segment], Segment], _word_indices: Optional[List[List[int]]] = None,
+                 _text_match: Optional[str] = None):
+        self.segments = [segments] if isinstance(segments, Segment) else segments
+        self.word_indices = [] if _word_indices is None else _word_indices
+        self.words = [self.segments[i].words[j] for i, idx in enumerate(self.word_indices) for j in idx]
+        self.text = "".join(w.word for w in self.words) if self.words else "".join(sg.text for sg in self.segments)
+        self.text_match = _text_match
+
+    @property
+    def start(self):
+        if self.words:
+            return self.words[0].start
+        return self.segments[0].start if self.segments else None
+
+    @property
+    def end(self):
+        if self.words:
+            return self.words[-1].end
+        return self.segments[-1].end if self.segments else None
+
+    def __len__(self):
+        return len(self.segments)
+
+    def __repr__(self):
+        return repr(self.__dict__)
+
+    __str__ = __repr__
+
+
+class WhisperResultMatches:
+    """Matches of ``WhisperResult.find``; ``find`` on it searches again inside the matched segments (result.py:3152)."""
+
+    def __init__(self, matches: Union[List[SegmentMatch], WhisperResult], _segment_indices: Optional[List[List[int]]] = None):
+        if isinstance(matches, WhisperResult):
+            self.matches = [SegmentMatch(sg) for sg in matches.segments]
+            self._segment_indices = [[i] for i in range(len(matches.segments))]
+        else:
+            assert _segment_indices is not None and len(matches) == len(_segment_indices)
+            assert all(len(m.segments) == len(_segment_indices[i]) for i, m in enumerate(matches))
+            self.matches, self._segment_indices = matches, _segment_indices
+
+    @property
+    def segment_indices(self) -> List[List[int]]:
+        return self._segment_indices
+
+    def _runs(self) -> List[List[tuple]]:
+        """the distinct matched segments as (index, segment) in order, cut into runs of consecutive indices -- with the
+        reference's cut placement (a run is closed when the segment just added does NOT follow its predecessor)"""
+        runs, cur, top = [], [], -1
+        for idx, match in zip(self._segment_indices, self.matches):
+            for i, sg in zip(sorted(idx), match.segments):
+                if i > top:
+                    cur.append((i, sg))
+                    if i - 1 != top:
+                        runs.append(cur)
+                        cur = []
+                    top = i
+        if cur:
+            runs.append(cur)
+        return runs
+
+    def find(self, pattern: str, word_level: bool = True, flags=None) -> "WhisperResultMatches":
+        import re
+        if word_level and not all(sg.has_words for m in self.matches for sg in m.segments):
+            warnings.warn("Cannot perform word-level search with segment(s) missing word timestamps.")
+            word_level = False
+        found, found_idx = [], []
+        for run in self._runs():
+            if word_level:
+                owner = [(i, j) for i, sg in run for j, w in enumerate(sg.words) for _ in w.word]
+                text = "".join(w.word for _, sg in run for w in sg.words)
+            else:
+                owner = [(i, None) for i, sg in run for _ in sg.text]
+                text = "".join(sg.text for _, sg in run)
+            for m in re.finditer(pattern, text, flags=flags or 0):
+                span = owner[m.start(): m.end()]
+                seg_ids = sorted({i for i, _ in span})
+                words = [sorted({j for i, j in span if i == k}) for k in seg_ids] if word_level else None
+                found.append(SegmentMatch([sg for i, sg in run if i in seg_ids], _word_indices=words, _text_match=m.group()))
+                found_idx.append(seg_ids)
+        return WhisperResultMatches(found, found_idx)
+
+    def __len__(self):
+        return len(self.matches)
+
+    def __bool__(self):
+        return len(self.matches) != 0
+
+    def __getitem__(self, i) -> SegmentMatch:
+        return self.matches[i]
