@@ -19,6 +19,7 @@ from .audio_io import AudioLoader, load_audio, prep_audio  # noqa: F401
 from .alignment import align, align_words, refine  # noqa: F401
 from .locator import locate  # noqa: F401
 from .spans import plan_spans, transcribe_spans  # noqa: F401
+from .non_whisper import transcribe_any  # noqa: F401
 from .audio import (  # noqa: F401
     SAMPLE_RATE, N_FFT, HOP_LENGTH, CHUNK_LENGTH, N_SAMPLES, N_FRAMES, N_SAMPLES_PER_TOKEN, FRAMES_PER_SECOND,
     TOKENS_PER_SECOND, pad_or_trim,
