@@ -131,10 +131,10 @@ def write_wav(path: str, audio: Union[np.ndarray, torch.Tensor], sr: int):
         w.setnchannels(a.shape[0])
         w.setsampwidth(2)
         w.setframerate(sr)
-        w.writeframes(_to_s16(a.T.reshape(-1)).tobytes())
+        w.writeframes(to_s16(a.T.reshape(-1)).tobytes())
 
 
-def _to_s16(x: np.ndarray) -> np.ndarray:
+def to_s16(x: np.ndarray) -> np.ndarray:
     return np.clip(np.rint(np.asarray(x, np.float64) * 32768.0), -32768, 32767).astype("<i2")
 
 
@@ -242,7 +242,7 @@ def _ffmpeg_cmd(source: str, sr: int, mono: bool = True) -> List[str]:
             "-ac", "1" if mono else "2", "-acodec", "pcm_s16le", "-ar", str(sr), "-"]
 
 
-def _check_source(file: Union[str, bytes]):
+def check_source(file: Union[str, bytes]):
     if isinstance(file, str) and "://" in file:
         raise NotImplementedError("URL sources need yt-dlp / network access -- out of scope (DESIGN.md section 7)")
 
@@ -251,7 +251,7 @@ def load_audio(file: Union[str, bytes], sr: int = SAMPLE_RATE, verbose: Optional
                mono: bool = True) -> np.ndarray:
     """File path or file bytes -> f32 waveform at ``sr`` ([n] mono, [2, n] otherwise), values on the s16 grid like the
     reference's ``-f s16le`` pipe (audio/utils.py:63-125)."""
-    _check_source(file)
+    check_source(file)
     if is_wav(file):
         x, in_sr = read_wav(file)
         if mono:
@@ -260,7 +260,7 @@ def load_audio(file: Union[str, bytes], sr: int = SAMPLE_RATE, verbose: Optional
         else:
             x = x if x.shape[1] == 2 else np.repeat(x.mean(axis=1, keepdims=True), 2, axis=1)
             y = resample(torch.from_numpy(np.ascontiguousarray(x.T)), in_sr, sr).numpy()
-        return _to_s16(y).astype(np.float32) / 32768.0
+        return to_s16(y).astype(np.float32) / 32768.0
     if shutil.which("ffmpeg") is None:
         raise RuntimeError("Failed to load audio: only RIFF/WAVE sources can be decoded without ffmpeg on PATH")
     is_bytes = isinstance(file, (bytes, bytearray))
@@ -319,7 +319,7 @@ def audio_to_tensor_resample(audio, original_sample_rate: Optional[int] = None, 
     return audio
 
 
-def _no_denoiser(denoiser, demucs=None):
+def reject_denoiser(denoiser, demucs=None):
     if denoiser or demucs:
         raise NotImplementedError("denoisers (demucs / dfnet / noisereduce) need their model files -- out of scope "
                                   "(DESIGN.md section 7)")
@@ -330,7 +330,7 @@ def prep_audio(audio: Union[str, np.ndarray, torch.Tensor, bytes], denoiser: Opt
                verbose: Optional[bool] = False, sr: Optional[int] = None, demucs=None, demucs_options=None) -> torch.Tensor:
     """Any supported input -> mono waveform tensor (audio/__init__.py:74-149).  Arrays and tensors are taken as already
     sampled at ``sr`` and are returned as they are (same object, same device) unless ``only_voice_freq``."""
-    _no_denoiser(denoiser, demucs)
+    reject_denoiser(denoiser, demucs)
     sr = sr or SAMPLE_RATE
     if isinstance(audio, (str, bytes)):
         audio = torch.from_numpy(load_audio(audio, sr=sr, verbose=verbose, only_ffmpeg=only_ffmpeg))
@@ -342,7 +342,7 @@ def prep_audio(audio: Union[str, np.ndarray, torch.Tensor, bytes], denoiser: Opt
 
 
 # ------------------------------------------------------------------------------------------------- streamed PCM source
-class _PcmStream:
+class PcmStream:
     """s16le mono bytes at the target rate, pulled on demand: the role of the reference's ffmpeg child process
     (audio/__init__.py:552-591).  ``read(n_bytes)`` returns fewer bytes only at the end of the source."""
 
@@ -374,7 +374,7 @@ class _PcmStream:
             self._closer = None
 
 
-def _wav_pcm_stream(source: Union[str, bytes], sr: int, frames_per_read: int = 1 << 18) -> _PcmStream:
+def _wav_pcm_stream(source: Union[str, bytes], sr: int, frames_per_read: int = 1 << 18) -> PcmStream:
     f = _open_binary(source)
     info = _parse_wav(f)
 
@@ -389,10 +389,10 @@ def _wav_pcm_stream(source: Union[str, bytes], sr: int, frames_per_read: int = 1
             x = _decode_frames(raw[: k * info.block], info)
             yield x.mean(axis=1, dtype=np.float64).astype(np.float32) if x.shape[1] > 1 else np.ascontiguousarray(x[:, 0])
 
-    return _PcmStream((_to_s16(b).tobytes() for b in resample_blocks(mono_blocks(), info.sr, sr)), f.close)
+    return PcmStream((to_s16(b).tobytes() for b in resample_blocks(mono_blocks(), info.sr, sr)), f.close)
 
 
-def _ffmpeg_pcm_stream(source: str, sr: int) -> _PcmStream:
+def _ffmpeg_pcm_stream(source: str, sr: int) -> PcmStream:
     try:
         p = subprocess.Popen(_ffmpeg_cmd(source, sr), stdout=subprocess.PIPE)
     except (subprocess.SubprocessError, OSError) as e:
@@ -409,11 +409,11 @@ def _ffmpeg_pcm_stream(source: str, sr: int) -> _PcmStream:
         if p.poll() is None:
             p.terminate()
 
-    return _PcmStream(chunks(), close)
+    return PcmStream(chunks(), close)
 
 
-def open_pcm_stream(source: Union[str, bytes], sr: int) -> _PcmStream:
-    _check_source(source)
+def open_pcm_stream(source: Union[str, bytes], sr: int) -> PcmStream:
+    check_source(source)
     if is_wav(source):
         return _wav_pcm_stream(source, sr)
     if isinstance(source, str) and shutil.which("ffmpeg") is not None:
@@ -442,7 +442,7 @@ class AudioLoader:
                  demucs=None, demucs_options=None, load_sections: Optional[List[Section]] = None, negate_load: bool = False):
         if stream and not isinstance(source, str):
             raise NotImplementedError(f"``stream=True`` only supported for string ``source`` but got {type(source)}.")
-        _no_denoiser(denoiser, demucs)
+        reject_denoiser(denoiser, demucs)
         self.source = source
         self._sr = sr or SAMPLE_RATE
         self.load_sections = self.negate_ts_sections(load_sections) if (negate_load and load_sections) else load_sections
@@ -464,7 +464,7 @@ class AudioLoader:
         self._total_sample_estimation = round(self._duration_estimation * self._sr)
         self._prev_seek: Optional[int] = None
         self._buffered_samples = torch.tensor([])
-        self._pcm: Optional[_PcmStream] = open_pcm_stream(source, self._sr) if (self._stream and isinstance(source, str)) else None
+        self._pcm: Optional[PcmStream] = open_pcm_stream(source, self._sr) if (self._stream and isinstance(source, str)) else None
         if test_first_chunk and self.next_chunk(0) is None:
             raise RuntimeError(f'FFmpeg failed to read "{source}".' if isinstance(source, str) else "Failed to load audio.")
 
@@ -671,7 +671,7 @@ class AudioLoader:
             raise NotImplementedError("vad=True needs the Silero model (torch.hub, network) -- out of scope offline")
         if stream and not self._stream:
             warnings.warn("``stream=True`` will have no effect unless specified at AudioLoader initialization.", stacklevel=2)
-        _no_denoiser(denoiser)
+        reject_denoiser(denoiser)
         if only_voice_freq and not self._only_voice_freq:
             warnings.warn("``only_voice_freq=True`` will have no effect unless specified at AudioLoader initialization.",
                           stacklevel=2)

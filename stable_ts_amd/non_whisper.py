@@ -16,8 +16,8 @@ from typing import Callable, Optional, Union
 import numpy as np
 import torch
 
-from .audio_io import (AudioLoader, audio_to_tensor_resample, get_samplerate, load_audio, resample, voice_freq_filter,
-                       write_wav, _check_source, _no_denoiser)
+from .audio_io import (AudioLoader, audio_to_tensor_resample, check_source, get_samplerate, load_audio, reject_denoiser,
+                       resample, to_s16, voice_freq_filter, write_wav)
 from .result import WhisperResult
 
 AUDIO_TYPES = ("str", "byte", "torch", "numpy")
@@ -34,8 +34,7 @@ def _wav_bytes(audio: torch.Tensor, sr: int) -> bytes:
             w.setnchannels(a.shape[0])
             w.setsampwidth(2)
             w.setframerate(sr)
-            from .audio_io import _to_s16
-            w.writeframes(_to_s16(a.T.reshape(-1)).tobytes())
+            w.writeframes(to_s16(a.T.reshape(-1)).tobytes())
         return f.getvalue()
 
 
@@ -49,7 +48,7 @@ def transcribe_any(inference_func: Callable, audio: Union[str, np.ndarray, torch
                    min_silence_dur: Optional[float] = None, nonspeech_error: float = 0.1, use_word_position: bool = True,
                    only_voice_freq: bool = False, only_ffmpeg: bool = False, force_order: bool = False,
                    check_sorted: bool = True) -> WhisperResult:
-    _no_denoiser(denoiser, demucs)
+    reject_denoiser(denoiser, demucs)
     if vad:
         raise NotImplementedError("vad needs the Silero model (torch.hub, network) -- out of scope offline")
     if audio_type is not None and (audio_type := audio_type.lower()) not in AUDIO_TYPES:
@@ -66,7 +65,7 @@ def transcribe_any(inference_func: Callable, audio: Union[str, np.ndarray, torch
     if model_sr is None and isinstance(audio, (str, bytes)) and audio_type in ("torch", "numpy"):
         raise ValueError('``model_sr`` is required when ``audio_type`` is a "pytorch" or "numpy".')
     if isinstance(audio, str):
-        _check_source(audio)
+        check_source(audio)
     inference_kwargs = {} if inference_kwargs is None else inference_kwargs
     temp_file = os.path.abspath(temp_file or "./_temp_stable-ts_audio_.wav")
     temp_audio_file = None

@@ -91,7 +91,7 @@ def test_load_audio_wav_paths(tmp_path):
     # stereo 44.1 kHz: down-mix, resample, s16 grid; stereo output keeps both channels
     t = np.arange(44100) / 44100.0
     st = np.stack([0.4 * np.sin(2 * np.pi * 300 * t), 0.2 * np.sin(2 * np.pi * 1200 * t)], 1)
-    raw = AIO._to_s16(st.reshape(-1)).tobytes()
+    raw = AIO.to_s16(st.reshape(-1)).tobytes()
     blob = _wav_bytes(1, 16, 2, 44100, raw)
     y = load_audio(blob)
     assert y.shape == (16000,) and y.dtype == np.float32 and np.array_equal(y * 32768, np.rint(y * 32768))
@@ -297,7 +297,7 @@ def test_audioloader_matches_reference(seed, monkeypatch):
         monkeypatch.setattr(RA.AudioLoader, "_audio_loading_process", lambda self: _FakePopen(pcm.tobytes()))
         monkeypatch.setattr(AIO, "get_metadata", lambda src: dict(sr=44100, duration=est))
         step = int(g.integers(1, 70000))
-        monkeypatch.setattr(AIO, "open_pcm_stream", lambda src, sr: AIO._PcmStream(
+        monkeypatch.setattr(AIO, "open_pcm_stream", lambda src, sr: AIO.PcmStream(
             iter([pcm.tobytes()[i:i + 2 * step] for i in range(0, 2 * n, 2 * step)])))
         src_ref = src_mine = "fake.mp3"
     else:
@@ -345,7 +345,7 @@ def test_audioloader_wav_stream_equals_memory(tmp_path):
     p44 = str(tmp_path / "s44.wav")
     with wave.open(p44, "wb") as w:
         w.setnchannels(2), w.setsampwidth(2), w.setframerate(44100)
-        w.writeframes(AIO._to_s16(st.reshape(-1)).tobytes())
+        w.writeframes(AIO.to_s16(st.reshape(-1)).tobytes())
     whole = torch.from_numpy(load_audio(p44))
     save = str(tmp_path / "final.wav")
     with AudioLoader(p44, stream=True, buffer_size=5000, save_path=save) as L:
