@@ -136,6 +136,16 @@ int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int
               const int32_t *h_n_frames, float qk_scale, int medfilt_width, const void *d_xkv,
               float *d_token_probs, float *d_neg_matrix, void *stream);
 
+/* raw attention scores of the configured alignment heads from the same teacher-forced pass (what timing.py:41-67
+ * _compute_qks hooks out of every cross-attention layer), for the head-selection variants of the alignment stage that
+ * work on per-head scores: dynamic heads (timing.py:87-103), the 'new' aligner (timing.py:115-163).  Configure the
+ * handle with every (layer, head) pair to get all heads.
+ *  d_qk f32 [W][n_align][n_rows][1500]: (q * scale) . (k * scale) of token rows row0 .. row0+n_rows-1 (row0 + n_rows <= max_n),
+ *       heads in the order of swx_set_alignment_heads sorted by (layer, head); pre-softmax, qk_scale not applied
+ *  d_token_probs as in swx_score, or NULL */
+int swx_score_qk(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot, int eot,
+                 int row0, int n_rows, const void *d_xkv, float *d_token_probs, float *d_qk, void *stream);
+
 /* full-sequence logits of a teacher-forced pass (model(mel, tokens) as used by refine/locate; also a test hook):
  * d_logits f32 [W][max_n][n_vocab].  Language detection (model.detect_language, original_whisper.py:329) is this call
  * with tokens = [[sot]]. */

@@ -10,6 +10,7 @@ run() { name=$1; shift; ( timeout ${T:-240} "$@" 2>&1 | tail -${L:-25} ) > gpuru
 run chk_splitk   python tests/hw_checks/splitk_hook_check.py
 run chk_glds     python tests/hw_checks/gemm_glds_check.py
 run chk_melrag   python tests/hw_checks/mel_ragged_check.py
+run chk_scoreqk  python tests/hw_checks/score_qk_check.py
 run chk_b3       python tests/hw_checks/b3_check.py
 SWX_PG_POLICY="1536x384=1,1152x384=1,384x384=1,384x1536=2" run chk_policy_tiny python tests/hw_checks/pg_policy_check.py tiny.en
 SWX_PG_POLICY="2048x512=1,1536x512=1,512x512=2,512x2048=4" run chk_policy_base python tests/hw_checks/pg_policy_check.py base.en

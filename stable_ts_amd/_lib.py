@@ -56,6 +56,8 @@ SYMBOLS = {
     "swx_decode_gout": (c_int, [POINTER(swx_decode_cfg)]),
     "swx_score": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_int, c_int, POINTER(c_int32), c_float,
                           c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "swx_score_qk": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                             c_void_p, c_void_p, c_void_p]),
     "swx_forward_logits": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "swx_align_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int32), c_float, c_int, c_void_p,
                                   c_void_p]),

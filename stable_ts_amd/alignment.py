@@ -21,9 +21,11 @@ from .tokenizer import get_tokenizer
 from .aligner import WordToken  # noqa: E402,F401  (re-exported: the seam-B2 callable takes these)
 
 
-def make_alignment_func(model, tokenizer):
+def make_alignment_func(model, tokenizer, extra_models: Optional[list] = None, dynamic_heads=None,
+                        aligner: Union[str, dict] = "legacy"):
     """alignment.py:396-429: inference_func(audio_segment f32[n<=480000], word_tokens) -> list of word dicts with times
-    relative to the segment start."""
+    relative to the segment start.  ``extra_models`` / ``dynamic_heads`` / ``aligner`` select the head-selection variants
+    of the attention stage (timing.py)."""
 
     def compute_timestamps(audio_segment: torch.Tensor, word_tokens: List[WordToken]) -> List[dict]:
         return compute_timestamps_batch([audio_segment], [word_tokens])[0]
@@ -38,7 +40,8 @@ def make_alignment_func(model, tokenizer):
             windows.append(dict(segments=[seg], num_samples=k))
         add_word_timestamps_batch(model=model, tokenizer=tokenizer, windows=windows, xkv=xkv,
                                   split_callback=lambda x, _: x, gap_padding=None,
-                                  prepend_punctuations="", append_punctuations="")
+                                  prepend_punctuations="", append_punctuations="", extra_models=extra_models,
+                                  dynamic_heads=dynamic_heads, aligner=aligner, mel=mel if extra_models else None)
         return [w["segments"][0]["words"] for w in windows]
 
     compute_timestamps.batch = compute_timestamps_batch
@@ -90,7 +93,8 @@ def align(model, audio, text: Union[str, List[int], WhisperResult], language: st
         tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language or "en",
                                   task="transcribe")
     lang_code = getattr(tokenizer, "language_code", None) or getattr(tokenizer, "language", None)
-    aligner = Aligner(inference_func=make_alignment_func(model, tokenizer), decode=tokenizer.decode, encode=tokenizer.encode,
+    variant = {k: options.pop(k) for k in ("extra_models", "dynamic_heads", "aligner") if k in options}
+    aligner = Aligner(inference_func=make_alignment_func(model, tokenizer, **variant), decode=tokenizer.decode, encode=tokenizer.encode,
                       split_words_by_space=lang_code not in {"zh", "ja", "th", "lo", "my"}, sample_rate=SAMPLE_RATE,
                       max_segment_length=N_SAMPLES, remove_instant_words=remove_instant_words, token_step=token_step,
                       original_split=original_split, word_dur_factor=word_dur_factor, max_word_dur=max_word_dur,
@@ -118,7 +122,8 @@ def align_words(model, audio, result: Union[WhisperResult, List[dict]], language
         tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language or "en",
                                   task="transcribe")
     lang_code = getattr(tokenizer, "language_code", None) or getattr(tokenizer, "language", None)
-    func = make_alignment_func(model, tokenizer)
+    variant = {k: options.pop(k) for k in ("extra_models", "dynamic_heads", "aligner") if k in options}
+    func = make_alignment_func(model, tokenizer, **variant)
 
     def clipped(fn):        # a segment longer than one window is aligned against its first 30 s (the reference trims the mel)
         return lambda chunks, words: fn([c[..., :N_SAMPLES] for c in chunks], words)

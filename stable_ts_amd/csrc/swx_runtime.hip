@@ -894,8 +894,9 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
 }
 
 // ------------------------------------------------------------------------------------------------------ score
-static int score_forward(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot,
-                         const void *d_xkv, bool capture, hipStream_t s)
+// capture: raw qk of the alignment heads for token rows cap_row0 .. cap_row0 + cap_rows - 1 -> L.cap [W][n_align][cap_ld][1500]
+static int score_forward(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int cap_row0,
+                         int cap_rows, int cap_ld, const void *d_xkv, bool capture, hipStream_t s)
 {
     const swx_dims &D = m->dims;
     if (W > m->max_windows) return -8;
@@ -908,43 +909,19 @@ static int score_forward(swx_model *m, const int32_t *d_tokens, const int32_t *h
     f.kcache = m->ws + m->L.sk; f.vcache = m->ws + m->L.sv; f.layer_stride = 0; f.cache_rows = m->max_windows;
     f.anc = nullptr; f.xkv = (const unsigned char *)d_xkv;
     f.capture = capture;
-    f.cap_row0 = n_sot; f.cap_rows = max_n - n_sot - 1; f.cap_ld_n = max_n;
-    if (capture && f.cap_rows <= 0) return -1;
+    f.cap_row0 = cap_row0; f.cap_rows = cap_rows; f.cap_ld_n = cap_ld;
+    if (capture && (cap_rows <= 0 || cap_row0 < 0 || cap_row0 + cap_rows > max_n || cap_ld < cap_rows)) return -1;
     return decoder_forward(m, f, s);
 }
 
-int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot, int eot,
-              const int32_t *h_n_frames, float qk_scale, int medfilt_width, const void *d_xkv, float *d_token_probs,
-              float *d_neg_matrix, void *stream)
+// token probabilities of a scoring pass: rows n_sot .. n_sot+T-1 of the final-LN'd hidden states -> logits[:, :eot] ->
+// softmax -> gather at the next token (timing.py:62-64); d_token_probs f32 [W][max_n]
+static int score_token_probs(swx_model *m, const int32_t *d_tokens, int W, int max_n, int n_sot, int eot, float *d_token_probs,
+                             hipStream_t s)
 {
-    if (!m || !m->arena || !m->ws) return -9;
-    if (W <= 0) return 0;
-    if (m->n_align != m->ws_n_align || m->n_align <= 0) return -8;
-    if (2 * W + 16 > SMALL_I32) return -8;
     const swx_dims &D = m->dims;
-    hipStream_t s = S(stream);
     const int d = D.n_text_state;
     const size_t e = m->esz;
-    SWX_TRY(score_forward(m, d_tokens, h_n_tok, W, max_n, n_sot, d_xkv, true, s));
-
-    // per-window row / frame counts on the device
-    std::vector<int32_t> hv(2 * W);
-    for (int w = 0; w < W; ++w) {
-        const int T = h_n_tok[w] - n_sot - 2;
-        if (T < 0) return -1;
-        hv[w] = T + 1;
-        int F = h_n_frames[w];
-        if (F < 1) F = 1;
-        if (F > D.n_audio_ctx) F = D.n_audio_ctx;
-        hv[W + w] = F;
-    }
-    int32_t *d_small = m->Wp<int32_t>(m->L.small_i32);
-    hipError_t er = hipMemcpyAsync(d_small, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, s);
-    if (er != hipSuccess) return -100 - (int)er;
-    er = hipStreamSynchronize(s);     // hv goes out of scope; pageable copies are staged synchronously anyway
-    if (er != hipSuccess) return -100 - (int)er;
-
-    // token probabilities: rows n_sot .. n_sot+T-1 of the final-LN'd hidden states -> logits[:, :eot] -> softmax -> gather
     unsigned char *x = m->ws + m->L.x, *hh = m->ws + m->L.h;
     const int rows = W * max_n;
     SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, rows, d, s));
@@ -966,11 +943,61 @@ int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int
         }
         SWX_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot, int eot,
+              const int32_t *h_n_frames, float qk_scale, int medfilt_width, const void *d_xkv, float *d_token_probs,
+              float *d_neg_matrix, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (W <= 0) return 0;
+    if (m->n_align != m->ws_n_align || m->n_align <= 0) return -8;
+    if (2 * W + 16 > SMALL_I32) return -8;
+    const swx_dims &D = m->dims;
+    hipStream_t s = S(stream);
+    SWX_TRY(score_forward(m, d_tokens, h_n_tok, W, max_n, n_sot, max_n - n_sot - 1, max_n, d_xkv, true, s));
+
+    // per-window row / frame counts on the device
+    std::vector<int32_t> hv(2 * W);
+    for (int w = 0; w < W; ++w) {
+        const int T = h_n_tok[w] - n_sot - 2;
+        if (T < 0) return -1;
+        hv[w] = T + 1;
+        int F = h_n_frames[w];
+        if (F < 1) F = 1;
+        if (F > D.n_audio_ctx) F = D.n_audio_ctx;
+        hv[W + w] = F;
+    }
+    int32_t *d_small = m->Wp<int32_t>(m->L.small_i32);
+    hipError_t er = hipMemcpyAsync(d_small, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, s);
+    if (er != hipSuccess) return -100 - (int)er;
+    er = hipStreamSynchronize(s);     // hv goes out of scope; pageable copies are staged synchronously anyway
+    if (er != hipSuccess) return -100 - (int)er;
+
+    SWX_TRY(score_token_probs(m, d_tokens, W, max_n, n_sot, eot, d_token_probs, s));
     // alignment matrix
     SWX_TRY(swx_align_weights_launch(m->Wp<float>(m->L.cap), m->Wp<float>(m->L.cap), m->Wp<float>(m->L.mean), m->Wp<float>(m->L.sd),
                                      W, m->n_align, max_n, D.n_audio_ctx, d_small, d_small + W, qk_scale, medfilt_width,
                                      d_neg_matrix, max_n, D.n_audio_ctx, s));
     return 0;
+}
+
+int swx_score_qk(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot, int eot,
+                 int row0, int n_rows, const void *d_xkv, float *d_token_probs, float *d_qk, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (W <= 0) return 0;
+    if (m->n_align != m->ws_n_align || m->n_align <= 0) return -8;
+    if (!d_qk) return -1;
+    for (int w = 0; w < W; ++w) if (h_n_tok[w] - n_sot - 2 < 0) return -1;
+    hipStream_t s = S(stream);
+    // the capture buffer is written densely ([W][n_align][n_rows][1500]) so that one copy hands it over
+    SWX_TRY(score_forward(m, d_tokens, h_n_tok, W, max_n, row0, n_rows, n_rows, d_xkv, true, s));
+    if (d_token_probs) SWX_TRY(score_token_probs(m, d_tokens, W, max_n, n_sot, eot, d_token_probs, s));
+    const size_t bytes = (size_t)W * m->n_align * n_rows * m->dims.n_audio_ctx * sizeof(float);
+    hipError_t er = hipMemcpyAsync(d_qk, m->Wp<float>(m->L.cap), bytes, hipMemcpyDeviceToDevice, s);
+    return er == hipSuccess ? 0 : -100 - (int)er;
 }
 
 int swx_forward_logits(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, const void *d_xkv,
@@ -981,7 +1008,7 @@ int swx_forward_logits(swx_model *m, const int32_t *d_tokens, const int32_t *h_n
     const swx_dims &D = m->dims;
     hipStream_t s = S(stream);
     const int d = D.n_text_state;
-    SWX_TRY(score_forward(m, d_tokens, h_n_tok, W, max_n, 0, d_xkv, false, s));
+    SWX_TRY(score_forward(m, d_tokens, h_n_tok, W, max_n, 0, 0, max_n, d_xkv, false, s));
     unsigned char *x = m->ws + m->L.x, *hh = m->ws + m->L.h;
     const int rows = W * max_n;
     SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, rows, d, s));

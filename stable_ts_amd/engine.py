@@ -258,6 +258,38 @@ class Engine:
         p = probs.cpu().numpy()
         return [p[w, :T[w]].astype(np.float64).tolist() for w in range(W)], neg, T
 
+    def score_qk(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], *, n_sot: int, eot: int, row0: int, n_rows: int):
+        """Teacher-forced pass that hands out the raw (pre-softmax) attention scores of this engine's alignment heads
+        for token rows ``row0 .. row0 + n_rows - 1``: (token_probs list, f32 device tensor [W, heads, n_rows, 1500]).
+        ``all_heads()`` gives a view of the same weights that captures every head of the decoder."""
+        W = len(tokens)
+        n_tok = [len(t) for t in tokens]
+        max_n = max(n_tok)
+        self.reserve(max(W, self.max_windows), max(self.max_rows, 1))
+        pad = np.full((W, max_n), eot, dtype=np.int32)
+        for w, t in enumerate(tokens):
+            pad[w, :len(t)] = t
+        d_tok = torch.tensor(pad, device=self.device)
+        probs = torch.zeros(W, max_n, dtype=torch.float32, device=self.device)
+        qk = torch.empty(W, self.n_alignment_heads, n_rows, self.dims.n_audio_ctx, dtype=torch.float32, device=self.device)
+        check(self.lib.swx_score_qk(self.h, _ptr(d_tok), _i32arr(n_tok), W, max_n, n_sot, eot, int(row0), int(n_rows),
+                                    _ptr(xkv), _ptr(probs), _ptr(qk), self.stream), "swx_score_qk")
+        p = probs.cpu().numpy()
+        return [p[w, :n_tok[w] - n_sot - 2].astype(np.float64).tolist() for w in range(W)], qk
+
+    def all_heads(self) -> "Engine":
+        """An engine on the same weights whose alignment heads are ALL (layer, head) pairs in layer-major order, with a
+        one-window workspace (the capture buffer of 640 heads x 448 rows x 1500 frames is 1.7 GB for large-v3)."""
+        view = getattr(self, "_all_heads_view", None)
+        if view is None:
+            view = self.clone_shared(max_windows=1, max_rows=1)
+            view.set_alignment_heads([(l, h) for l in range(self.dims.n_text_layer) for h in range(self.dims.n_text_head)])
+            self._all_heads_view = view
+        return view
+
+    def median_filter(self, x: torch.Tensor, width: int) -> torch.Tensor:
+        return median_filter(x, width)
+
     def forward_logits(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], pad_token: int = 0) -> torch.Tensor:
         W = len(tokens)
         n_tok = [len(t) for t in tokens]

@@ -5,8 +5,12 @@ add_word_timestamps_stable :411-500).  The teacher-forced decoder pass, the head
 median filter / head-mean and the DTW all run on the GPU (csrc/swx_runtime.hip::swx_score, swx_align.hip,
 swx_dtw.hip); what stays here is the token<->word bookkeeping, which is string work.
 
-Scope of this round: the reference's default ('legacy') aligner with the model's alignment heads.
-``dynamic_heads``, ``aligner='new'`` and ``extra_models`` need the all-heads capture mode.
+The default ('legacy') aligner with the model's alignment heads is one fused device call (``swx_score``).  The
+head-selection variants -- ``dynamic_heads`` (timing.py:87-103), ``aligner='new'`` (timing.py:115-163) and
+``extra_models`` (timing.py:177-189) -- work on per-head scores: the raw scores come from ``swx_score_qk`` (for the
+dynamic / new variants from an engine view configured with every head), the selection arithmetic is a handful of tensor
+expressions on that device tensor written exactly as the reference writes them, the median filter and the DTW are the
+same kernels as on the default path.
 """
 import string
 from dataclasses import dataclass
@@ -142,14 +146,141 @@ class AlignmentJob:
         self.n_frames = round(num_samples / N_SAMPLES_PER_TOKEN)
 
 
+def parse_dynamic_heads(dynamic_heads) -> tuple:
+    """timing.py:255-268: True -> 6 heads, int -> that many, "k,n" -> k heads refined over n iterations"""
+    if not dynamic_heads:
+        return None, None
+    if dynamic_heads is True:
+        return 6, None
+    if isinstance(dynamic_heads, int):
+        return dynamic_heads, None
+    assert "," in dynamic_heads
+    k, n = dynamic_heads.split(",")[:2]
+    return int(k), int(n)
+
+
+def _znorm_medfilt(eng, weights, medfilt_width: int):
+    """timing.py:108-110: normalise every (head, frame) column over the tokens (population std), median over frames"""
+    import torch
+    std, mean = torch.std_mean(weights, dim=-2, keepdim=True, unbiased=False)
+    return eng.median_filter((weights - mean) / std, medfilt_width)
+
+
+def _legacy_head_weights(eng, xkv_w, job: AlignmentJob, n_sot: int, eot: int, qk_scale: float, medfilt_width: int,
+                         dynamic_count: Optional[int], jump_indices: Optional[np.ndarray]):
+    """``_compute_atten_weights`` (timing.py:70-112) for one window on one model.  Returns (token probabilities, weights
+    [heads, T+1, frames]).  With ``dynamic_count`` the heads are picked per token from ALL heads: those whose attention
+    mass lies closest to the token's expected frame (its own peak, or the previous pass's jump midpoints)."""
+    import torch
+    n = len(job.tokens)
+    F = job.n_frames
+    src = eng.all_heads() if dynamic_count else eng
+    probs, qk = src.score_qk(xkv_w, [job.tokens], n_sot=n_sot, eot=eot, row0=n_sot, n_rows=n - n_sot - 1)
+    qk = (qk[0, :, :, :F] * qk_scale).softmax(dim=-1)                                   # [heads, T+1, F]
+    if not dynamic_count:
+        return probs[0], _znorm_medfilt(eng, qk, medfilt_width)
+    if jump_indices is None:
+        peaks = qk.topk(1, dim=-1).indices
+    else:
+        j = np.pad(jump_indices, (0, 1), constant_values=F)
+        peaks = torch.from_numpy(j[:-1] + ((j[1:] - j[:-1]) * 0.5)).to(qk.device)[None, :, None]
+    distances = (peaks.expand_as(qk) - torch.arange(qk.size(-1), device=qk.device)).abs() / 1500
+    scores = (distances * qk).sum(dim=-1)
+    heads = [sc.topk(dynamic_count, largest=False).indices for sc in scores.T]
+    weights = torch.stack([qk[h, i] for i, h in enumerate(heads)], dim=1)
+    return probs[0], _znorm_medfilt(eng, weights, medfilt_width)
+
+
+def _new_aligner_matrix(eng, xkv_w, job: AlignmentJob, n_sot: int, eot: int, qk_scale: float, medfilt_width: int,
+                        topk: int = 20, w_colnorm: float = 1, w_rownorm: float = 1, w_coverage: float = 0):
+    """``_compute_atten_weights_new`` (timing.py:115-163, arXiv:2509.09987): the ``topk`` heads of the whole decoder
+    with the sharpest attention maps (column / row norms, optional coverage penalty), column-normalised and averaged."""
+    import torch
+    n = len(job.tokens)
+    L, H = eng.dims.n_text_layer, eng.dims.n_text_head
+    probs, qk = eng.all_heads().score_qk(xkv_w, [job.tokens], n_sot=n_sot, eot=eot, row0=0, n_rows=n)
+    w = qk[0].reshape(L, H, n, -1)[..., :job.n_frames]
+    w = (eng.median_filter(w, medfilt_width) * qk_scale).softmax(dim=-1)
+    score = torch.zeros(L, H, device=w.device)
+    if w_colnorm > 0:
+        score += w_colnorm * w.norm(dim=-2).sum(-1)
+    if w_rownorm > 0:
+        score += w_rownorm * w.norm(dim=-1).sum(-1)
+    if w_coverage > 0:
+        coverage = torch.sum(w, dim=2)
+        penalty = torch.max(coverage, coverage.clone().fill_(0.5)).sum(-1) - coverage.size(-1) * 0.5
+        score -= w_coverage * penalty
+    top = score.flatten().topk(topk).indices
+    m = w[top // H, top % H]
+    m = torch.mean(m / m.norm(dim=-2, keepdim=True), 0)
+    return probs[0], m[n_sot:-1]
+
+
+def _find_alignment_variants(model, jobs, xkv, *, medfilt_width, qk_scale, dynamic_heads, aligner, extra_models, mel,
+                             return_debug):
+    """timing.py:166-198 + 202-306 for the head-selection variants, one window at a time."""
+    import torch
+    from .transcribe import _xkv_select
+    assert isinstance(aligner, dict) or aligner in ("new", "legacy"), f'aligner must be "new"/"legacy", got "{aligner}"'
+    if extra_models and (bad := set(map(type, extra_models)) - {type(model)}):
+        raise NotImplementedError(f"Got unsupported model type(s): {bad}")
+    tok = jobs[0].tokenizer
+    n_sot, eot = len(tok.sot_sequence), tok.eot
+    count, iterations = parse_dynamic_heads(dynamic_heads)
+    new = aligner != "legacy"
+    if not new and getattr(model, "missing_alignment_heads", False) and not count:
+        count = 6
+    extras = []
+    if extra_models and not new:
+        if mel is None:
+            raise ValueError("extra_models need the windows' log-mel (each model encodes the audio itself)")
+        extras = [(m, m.cross_kv(m.encoder(mel))) for m in extra_models]
+    out = []
+    for w, job in enumerate(jobs):
+        eng = model.engine
+        xkv_w = _xkv_select(model, xkv, [w])
+        jump, probs = None, None
+        for _ in range(iterations or 1):
+            if new:
+                p, matrix = _new_aligner_matrix(eng, xkv_w, job, n_sot, eot, qk_scale, medfilt_width,
+                                                **(aligner if isinstance(aligner, dict) else {}))
+                probs = p
+            else:
+                p, weights = _legacy_head_weights(eng, xkv_w, job, n_sot, eot, qk_scale, medfilt_width, count, jump)
+                probs = p if probs is None else probs          # the main model's pass is cached across iterations
+                if extras:
+                    stacks, extra_probs = [weights], []
+                    for m, xkv_m in extras:
+                        pe, we = _legacy_head_weights(m.engine, _xkv_select(m, xkv_m, [w]), job, n_sot, eot, qk_scale,
+                                                      medfilt_width, count, None)
+                        stacks.append(we)
+                        extra_probs.append(pe)
+                    weights = torch.cat(stacks, dim=0)
+                    probs = torch.tensor(extra_probs + [probs]).mean(dim=0).tolist()       # timing.py:183-189
+                matrix = weights.mean(dim=0)
+            neg = (-matrix).contiguous()[None]
+            (text_idx, time_idx), = eng.dtw(neg, [neg.shape[1]], [neg.shape[2]])
+            jumps = np.pad(np.diff(text_idx), (1, 0), constant_values=1).astype(bool)
+            jump = time_idx[jumps].clip(min=0)
+        out.append((probs, text_idx, time_idx))
+    return out
+
+
 def find_alignment_batch(model, jobs: Sequence[AlignmentJob], xkv, *, medfilt_width: int = 7, qk_scale: float = 1.0,
-                         return_debug: bool = False) -> List[List[WordTiming]]:
+                         dynamic_heads=None, aligner: Union[str, dict] = "legacy", extra_models: Optional[list] = None,
+                         mel=None, return_debug: bool = False) -> List[List[WordTiming]]:
     """timing.py:202-306 for W windows at once: scoring pass + alignment matrix + DTW on the device."""
     tok = jobs[0].tokenizer
     eng = model.engine
-    probs, neg, T = eng.score(xkv, [j.tokens for j in jobs], [j.n_frames for j in jobs], n_sot=len(tok.sot_sequence),
-                              eot=tok.eot, qk_scale=qk_scale, medfilt_width=medfilt_width)
-    paths = eng.dtw(neg, [t + 1 for t in T], [j.n_frames for j in jobs])
+    if dynamic_heads or extra_models or aligner != "legacy" or getattr(model, "missing_alignment_heads", False):
+        res = _find_alignment_variants(model, jobs, xkv, medfilt_width=medfilt_width, qk_scale=qk_scale,
+                                       dynamic_heads=dynamic_heads, aligner=aligner, extra_models=extra_models, mel=mel,
+                                       return_debug=return_debug)
+        probs, paths = [r[0] for r in res], [(r[1], r[2]) for r in res]
+    else:
+        probs, neg, T = eng.score(xkv, [j.tokens for j in jobs], [j.n_frames for j in jobs], n_sot=len(tok.sot_sequence),
+                                  eot=tok.eot, qk_scale=qk_scale, medfilt_width=medfilt_width)
+        paths = eng.dtw(neg, [t + 1 for t in T], [j.n_frames for j in jobs])
     out = []
     for w, job in enumerate(jobs):
         text_idx, time_idx = paths[w]
@@ -170,7 +301,8 @@ def add_word_timestamps_batch(*, model, tokenizer, windows: Sequence[dict], xkv,
                               prepend_punctuations: str = None, append_punctuations: str = None,
                               min_word_dur: float = 0.1, split_callback: Callable = None,
                               gap_padding: Optional[str] = " ...", pad_first_seg: bool = True,
-                              medfilt_width: int = 7, qk_scale: float = 1.0):
+                              medfilt_width: int = 7, qk_scale: float = 1.0, dynamic_heads=None,
+                              aligner: Union[str, dict] = "legacy", extra_models: Optional[list] = None, mel=None):
     """timing.py:411-500 for several windows at once.  windows[w] = dict(segments=[...], num_samples=int); the window
     order matches the batch order inside `xkv`.  Mutates segments[i]['words'] / ['start'] / ['end'] in place."""
     prepend_punctuations = PREPEND_PUNCTUATIONS if prepend_punctuations is None else prepend_punctuations
@@ -185,7 +317,8 @@ def add_word_timestamps_batch(*, model, tokenizer, windows: Sequence[dict], xkv,
                                                            split_callback=split_callback, pad_first_seg=pad_first_seg)
         jobs.append(AlignmentJob(tokenizer, flat, wd["num_samples"], token_split))
         seg_maps.append(seg_of_word)
-    alignments = find_alignment_batch(model, jobs, xkv, medfilt_width=medfilt_width, qk_scale=qk_scale)
+    alignments = find_alignment_batch(model, jobs, xkv, medfilt_width=medfilt_width, qk_scale=qk_scale,
+                                      dynamic_heads=dynamic_heads, aligner=aligner, extra_models=extra_models, mel=mel)
     for wd, alignment, seg_of_word in zip(windows, alignments, seg_maps):
         segments = wd["segments"]
         lead = pop_empty_alignment(alignment, seg_of_word)

@@ -224,7 +224,9 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
                 windows=[dict(segments=outs[w]["segments"], num_samples=outs[w]["num_samples"]) for w in idx],
                 xkv=_xkv_select(model, xkv, idx), prepend_punctuations=o["prepend_punctuations"],
                 append_punctuations=o["append_punctuations"], min_word_dur=o["min_word_dur"],
-                split_callback=o["split_callback"], gap_padding=o["gap_padding"])
+                split_callback=o["split_callback"], gap_padding=o["gap_padding"], dynamic_heads=o.get("dynamic_heads"),
+                aligner=o.get("aligner", "legacy"), extra_models=o.get("extra_models"),
+                mel=mel[idx] if o.get("extra_models") else None)
         for w in idx:
             out = outs[w]
             segs = out["segments"]
@@ -266,7 +268,9 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                       batch_size: Optional[int] = None, clip_timestamps: Optional[Union[str, List[float]]] = None,
                       streams: int = 1, stream: Optional[bool] = None, only_voice_freq: bool = False,
                       only_ffmpeg: bool = False, denoiser: Optional[str] = None, denoiser_options: Optional[dict] = None,
-                      _span_bounds: Optional[List[Tuple[int, int]]] = None, **decode_options) -> WhisperResult:
+                      extra_models: Optional[list] = None, dynamic_heads: Optional[Union[bool, int, str]] = None,
+                      aligner: Union[str, dict] = "legacy", _span_bounds: Optional[List[Tuple[int, int]]] = None,
+                      **decode_options) -> WhisperResult:
     """Same keyword surface as the reference's ``model.transcribe`` for the options that reach the hot path
     (original_whisper.py:27-79); ``batch_size`` (window-parallel mode) and ``streams`` are the only additions.
     ``audio``: waveform (tensor / array, 16 kHz), file path or file bytes, or an ``AudioLoader``; ``stream`` loads files
@@ -345,7 +349,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
              append_punctuations=APPEND_PUNCTUATIONS if append_punctuations is None else append_punctuations,
              min_word_dur=0.1 if min_word_dur is None else min_word_dur, split_callback=split_callback,
              gap_padding=gap_padding, max_instant_words=max_instant_words, avg_prob_threshold=avg_prob_threshold,
-             suppress_ts_tokens=suppress_ts_tokens)
+             suppress_ts_tokens=suppress_ts_tokens, extra_models=extra_models, dynamic_heads=dynamic_heads, aligner=aligner)
 
     def host_copy(seg: torch.Tensor) -> torch.Tensor:
         return seg.detach().float().cpu()                       # silence analysis is host-side vector code (CPU)

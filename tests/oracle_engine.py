@@ -114,6 +114,42 @@ class OracleEngine:
         return probs, neg, T
 
     @torch.no_grad()
+    def score_qk(self, xkv, tokens, *, n_sot, eot, row0, n_rows):
+        """raw scores of the alignment heads (or of every head on the ``all_heads()`` view), rows row0 .. row0+n_rows-1"""
+        from oracle.whisper.model import disable_sdpa
+        W = len(tokens)
+        heads = ([(l, h) for l in range(self.dims.n_text_layer) for h in range(self.dims.n_text_head)] if self._every_head
+                 else [tuple(int(v) for v in p) for p in self.m.alignment_heads.indices().T])
+        out = torch.zeros(W, len(heads), n_rows, self.dims.n_audio_ctx)
+        probs = []
+        for w, tk in enumerate(tokens):
+            text = list(tk[n_sot + 1:-1])
+            qks = [None] * self.dims.n_text_layer
+            hooks = [blk.cross_attn.register_forward_hook(lambda _, i, o, k=k: qks.__setitem__(k, o[-1]))
+                     for k, blk in enumerate(self.m.decoder.blocks)]
+            with _SDPA_LOCK, disable_sdpa():
+                logits = self.m.decoder(torch.tensor([list(tk)]), xkv.xa[w:w + 1])[0]
+            for h in hooks:
+                h.remove()
+            p = logits[n_sot:, :eot].softmax(dim=-1)
+            probs.append([float(p[i, t]) if t < eot else 0.0 for i, t in enumerate(text)])
+            rows = min(n_rows, len(tk) - row0)
+            for k, (l, h) in enumerate(heads):
+                out[w, k, :rows] = qks[l][0, h, row0: row0 + rows]
+        return probs, out
+
+    _every_head = False
+
+    def all_heads(self):
+        view = OracleEngine(self.m)
+        view._every_head = True
+        return view
+
+    def median_filter(self, x, width):
+        from oracle.whisper.timing import median_filter
+        return median_filter(x, width)
+
+    @torch.no_grad()
     def forward_logits(self, xkv, tokens, pad_token=0):
         n = max(len(t) for t in tokens)
         out = torch.zeros(len(tokens), n, self.dims.n_vocab)

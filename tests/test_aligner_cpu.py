@@ -238,3 +238,35 @@ def test_aligner_degenerate_inputs_match_reference(text, seconds):
             except Exception as e:
                 outs.append(type(e).__name__)
     assert outs[0] == outs[1], (text, seconds, outs)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
+@pytest.mark.parametrize("variant", [dict(), dict(dynamic_heads="4,2"), dict(aligner="new"), dict(extra=True)])
+def test_align_on_standin_matches_reference_align(monkeypatch, variant):
+    """stable_ts_amd.alignment.align end to end on the CPU stand-in (its own seam-B2 callable, incl. the head-selection
+    variants) vs the reference's model.align on the same oracle model"""
+    import warnings
+    import make_golden as G
+    import stable_ts_amd.alignment as A
+    sw = G.import_reference()
+    from oracle.whisper.model import build_model
+    from oracle_engine import CpuWhisper, install
+    install(monkeypatch)
+    ref = build_model("tiny.en", seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5)
+    sw.modify_model(ref)
+    mine = CpuWhisper(ref)
+    kw_ref, kw_mine = dict(variant), dict(variant)
+    if kw_ref.pop("extra", None):
+        kw_mine.pop("extra")
+        other = build_model("tiny.en", seed=99, std=0.02, embed_gain=2.0, ts_gain=0.5)
+        sw.modify_model(other)
+        kw_ref["extra_models"], kw_mine["extra_models"] = [other], [CpuWhisper(other)]
+    audio = G.synth_audio(50.0, seed=4)
+    text = " aaat aaau. aaax aabc, aaat aaau aaax. aabc aaat? aaau aaax aabc aaat."
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref.align(audio, text, language="en", verbose=None, ignore_compatibility=True, **kw_ref)
+        got = A.align(mine, audio, text, language="en", **kw_mine)
+    snap = lambda r: [(w.word, w.start, w.end, round(float(w.probability), 9), list(w.tokens)) for w in r.all_words()]
+    assert snap(got) == snap(want) and len(snap(want)) > 5
+    assert [(s.start, s.end, s.text) for s in got.segments] == [(s.start, s.end, s.text) for s in want.segments]

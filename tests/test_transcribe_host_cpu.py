@@ -223,3 +223,40 @@ def test_config0_demo_wav_plumbing(models, monkeypatch):
     # which leaves the synthetic-weight transcript intact here (asserted, not assumed)
     assert _snap(got) == _snap(want)
     assert got.text == want.text and got.language == "en" and len(want.segments) > 0 and want.has_words
+
+
+VARIANTS = {
+    "dynamic_heads": dict(dynamic_heads=4),
+    "dynamic_true": dict(dynamic_heads=True, regroup=False),
+    "dynamic_iterations": dict(dynamic_heads="3,2"),
+    "new_aligner": dict(aligner="new"),
+    "new_aligner_opts": dict(aligner=dict(topk=12, w_coverage=0.5, w_rownorm=0), regroup=False),
+}
+
+
+@pytest.mark.parametrize("name", list(VARIANTS) + ["extra_models", "extra_models_dynamic"])
+def test_head_selection_variants_match_reference(models, monkeypatch, name):
+    """dynamic heads (timing.py:87-103), the 'new' aligner (timing.py:115-163) and extra models (timing.py:177-189):
+    the raw per-head scores come from the stand-in's ``score_qk``, the selection arithmetic is the product's"""
+    G, ref_model, mine = models
+    from oracle_engine import CpuWhisper, install
+    install(monkeypatch)
+    opts = dict(BASE, **VARIANTS.get(name, {}))
+    extra_ref = extra_mine = None
+    if name.startswith("extra_models"):
+        from oracle.whisper.model import build_model
+        sw = G.import_reference()
+        others = [build_model("tiny.en", seed=77 + k, std=0.02, embed_gain=2.0, ts_gain=0.5) for k in range(2)]
+        for m in others:
+            sw.modify_model(m)
+        extra_ref, extra_mine = others, [CpuWhisper(m) for m in others]
+        if name.endswith("dynamic"):
+            opts["dynamic_heads"] = "4,2"
+    audio = G.synth_audio(41.0, seed=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, extra_models=extra_ref, **opts)
+        got = mine.transcribe(audio, language="en", extra_models=extra_mine, **opts)
+        plain = mine.transcribe(audio, language="en", **BASE)
+    assert _snap(got) == _snap(want) and len(want.segments) > 0
+    assert _snap(got) != _snap(plain)                     # the variant really changes the word times
