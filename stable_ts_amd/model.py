@@ -209,6 +209,33 @@ class Whisper:
         """model(mel, tokens) / model.logits: teacher-forced full-sequence logits, f32 [W, n, n_vocab]."""
         return self.engine.forward_logits(self.cross_kv(audio_features), tokens)
 
+    def decoder(self, tokens: torch.Tensor, audio_features: torch.Tensor, kv_cache=None) -> torch.Tensor:
+        """``model.decoder(tokens, xa)`` as the reference's glue calls it (timing.py:61, alignment.py:988): tokens int
+        [B, n] (tensor or nested list) -> logits f32 [B, n, n_vocab] of a teacher-forced pass.  The incremental KV-cached
+        form belongs to the on-device decode loop (``swx_decode``); a ``kv_cache`` dict cannot be honoured here."""
+        if kv_cache:
+            raise NotImplementedError("kv_cache is internal to the device decode loop (swx_decode); call model.decoder "
+                                      "with the full token sequence")
+        toks = tokens.tolist() if torch.is_tensor(tokens) else [list(t) for t in tokens]
+        if toks and not isinstance(toks[0], list):
+            toks = [toks]
+        xa = audio_features if audio_features.ndim == 3 else audio_features[None]
+        if len(toks) != xa.shape[0]:
+            if xa.shape[0] != 1:
+                raise ValueError(f"{len(toks)} token rows for {xa.shape[0]} audio windows")
+            xa = xa.expand(len(toks), -1, -1)
+        return self.logits(toks, xa)
+
+    def __call__(self, mel: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+        """``model(mel, tokens)`` (alignment.py:660-667)"""
+        return self.decoder(tokens, self.encoder(mel))
+
+    forward = __call__
+
+    def install_kv_cache_hooks(self, cache=None):
+        raise NotImplementedError("there are no torch modules to hook: the KV cache lives inside swx_decode "
+                                  "(include/swx.h); use model.decoder(tokens, xa) for teacher-forced passes")
+
     def detect_language(self, mel_or_features: torch.Tensor, tokenizer=None):
         """model.detect_language (original_whisper.py:329): argmax / softmax over the language tokens at <|sot|>."""
         from .tokenizer import get_tokenizer

@@ -109,3 +109,36 @@ def test_result_container():
     assert d["text"] == " a b" and d["segments"][0]["words"][1]["end"] == 1.0 and r.has_words and len(r.all_words()) == 2
     with pytest.raises(UnsortedException):
         WhisperResult(dict(segments=[dict(start=2.0, end=1.0, text="x")]))
+
+
+def test_model_decoder_and_call_surface():
+    """model.decoder(tokens, xa) / model(mel, tokens) (seam B1): argument normalisation in front of the device call"""
+    import types
+    import pytest
+    import torch
+    from stable_ts_amd.model import Whisper
+    seen = {}
+
+    class Fake:
+        def logits(self, toks, xa):
+            seen["toks"], seen["xa"] = toks, tuple(xa.shape)
+            return torch.zeros(len(toks), len(toks[0]), 7)
+
+        def encoder(self, mel):
+            return torch.zeros(mel.shape[0] if mel.ndim == 3 else 1, 1500, 8)
+
+    f = Fake()
+    f.decoder = types.MethodType(Whisper.decoder, f)
+    out = Whisper.decoder(f, torch.tensor([[1, 2, 3]]), torch.zeros(1, 1500, 8))
+    assert out.shape == (1, 3, 7) and seen["toks"] == [[1, 2, 3]]
+    Whisper.decoder(f, torch.tensor([4, 5]), torch.zeros(1500, 8))                 # 1-D tokens, 2-D features
+    assert seen["toks"] == [[4, 5]] and seen["xa"] == (1, 1500, 8)
+    Whisper.decoder(f, [[1, 2], [3, 4]], torch.zeros(1, 1500, 8))                  # one window shared by two rows
+    assert seen["xa"] == (2, 1500, 8)
+    with pytest.raises(ValueError):
+        Whisper.decoder(f, [[1], [2], [3]], torch.zeros(2, 1500, 8))
+    with pytest.raises(NotImplementedError):
+        Whisper.decoder(f, [[1]], torch.zeros(1, 1500, 8), kv_cache={1: 2})
+    assert Whisper.__call__(f, torch.zeros(2, 80, 3000), torch.tensor([[1, 2], [3, 4]])).shape == (2, 2, 7)
+    with pytest.raises(NotImplementedError):
+        Whisper.install_kv_cache_hooks(f)
