@@ -294,6 +294,32 @@ def _read_checkpoint(path: str):
     return dims, ckpt["model_state_dict"]
 
 
+# The cross-attention heads upstream marks as time-aligned for its official checkpoints (whisper/__init__.py
+# ``_ALIGNMENT_HEADS``, stored there as base85-packed boolean masks; the (layer, head) lists below are the same data as
+# published in the checkpoints' generation configs).  Restated from memory -- there is no copy of either source in this
+# container to diff against, so re-check this table against upstream before relying on it with real weights.  Models
+# that are not listed fall back to upstream's constructor default: every head of the upper half of the decoder.
+OFFICIAL_ALIGNMENT_HEADS = {
+    "tiny.en": [(1, 0), (2, 0), (2, 5), (3, 0), (3, 1), (3, 2), (3, 3), (3, 4)],
+    "tiny": [(2, 2), (3, 0), (3, 2), (3, 3), (3, 4), (3, 5)],
+    "base.en": [(3, 3), (4, 7), (5, 1), (5, 5), (5, 7)],
+    "base": [(3, 1), (4, 2), (4, 3), (4, 7), (5, 1), (5, 2), (5, 4), (5, 6)],
+    "small.en": [(6, 6), (7, 0), (7, 3), (7, 8), (8, 2), (8, 5), (8, 7), (9, 0), (9, 4), (9, 8), (9, 10), (10, 0), (10, 1),
+                 (10, 2), (10, 3), (10, 6), (10, 11), (11, 2), (11, 4)],
+    "small": [(5, 3), (5, 9), (8, 0), (8, 4), (8, 7), (8, 8), (9, 0), (9, 7), (9, 9), (10, 5)],
+    "medium.en": [(11, 4), (14, 1), (14, 12), (14, 14), (15, 4), (16, 0), (16, 4), (16, 9), (17, 12), (17, 14), (18, 7),
+                  (18, 10), (18, 15), (20, 0), (20, 3), (20, 9), (20, 14), (21, 12)],
+    "medium": [(13, 15), (15, 4), (15, 15), (16, 1), (20, 0), (23, 4)],
+    "large-v1": [(9, 19), (11, 2), (11, 4), (11, 17), (22, 7), (22, 11), (22, 17), (23, 2), (23, 15)],
+    "large-v2": [(10, 12), (13, 17), (16, 11), (16, 12), (16, 13), (17, 15), (17, 16), (18, 4), (18, 11), (18, 19), (19, 11),
+                 (21, 2), (21, 3), (22, 3), (22, 9), (22, 12), (23, 5), (23, 7), (23, 13), (25, 5), (26, 1), (26, 12), (27, 15)],
+    "large-v3": [(7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)],
+    "large": [(7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)],
+    "large-v3-turbo": [(2, 4), (2, 11), (3, 3), (3, 6), (3, 11), (3, 14)],
+    "turbo": [(2, 4), (2, 11), (3, 3), (3, 6), (3, 11), (3, 14)],
+}
+
+
 def load_model(name: str, device: Optional[Union[str, torch.device]] = None, download_root: str = None,
                in_memory: bool = False, cpu_preload: bool = True, dq: bool = False, engine: Optional[str] = None, *,
                dtype: Optional[str] = None, weights: Optional[str] = None, seed: int = 1234,
@@ -328,6 +354,10 @@ def load_model(name: str, device: Optional[Union[str, torch.device]] = None, dow
                                f"pass a path, or weights='random' for seeded random weights")
     else:
         raise RuntimeError(f"Model {name} not found; available models = {available_models()}")
+    if alignment_heads is None and sd is not None and name in OFFICIAL_ALIGNMENT_HEADS:
+        heads = OFFICIAL_ALIGNMENT_HEADS[name]                  # upstream load_model: model.set_alignment_heads(...)
+        if all(l < dims.n_text_layer and h < dims.n_text_head for l, h in heads):
+            alignment_heads = heads
     model = Whisper(dims, device=device, dtype=dtype, alignment_heads=alignment_heads, **model_kwargs)
     if sd is None:
         sd = random_state_dict(dims, seed=seed)
