@@ -16,9 +16,9 @@ Synthetic text vocabulary (ids < eot):
 Every token string is unique and `decode` is plain concatenation, so
 ``encode(decode(ids)) == ids`` for any id list without specials.
 
-With a real vocabulary at hand (upstream's ``gpt2.tiktoken`` / ``multilingual.tiktoken`` in a directory named by
-``SWX_TIKTOKEN_DIR`` or ``get_tokenizer(..., vocab_dir=...)``) `TiktokenEncoding` takes the synthetic vocabulary's
-place: same interface, tiktoken's byte-pair algorithm, upstream's special-token layout (tests/test_tokenizer_cpu.py).
+With a real vocabulary at hand (upstream's ``gpt2.tiktoken`` / ``multilingual.tiktoken``, or a HuggingFace
+``tokenizer.json`` of a Whisper checkpoint, in a directory named by ``SWX_TIKTOKEN_DIR`` or
+``get_tokenizer(..., vocab_dir=...)``) `TiktokenEncoding` takes the synthetic vocabulary's place: same interface, tiktoken's byte-pair algorithm, upstream's special-token layout (tests/test_tokenizer_cpu.py).
 """
 import string
 from dataclasses import dataclass, field
@@ -163,15 +163,9 @@ class TiktokenEncoding:
     PATTERN = r"""'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"""
 
     def __init__(self, path: str, name: str, num_languages: int):
-        import base64
         import regex
         self.name = name
-        self.ranks: Dict[bytes, int] = {}
-        with open(path, "rb") as f:
-            for line in f:
-                if line.strip():
-                    tok, rank = line.split()
-                    self.ranks[base64.b64decode(tok)] = int(rank)
+        self.ranks: Dict[bytes, int] = self._read_hf_json(path) if path.endswith(".json") else self._read_tiktoken(path)
         self.n_text = len(self.ranks)
         self._bytes_by_id = {v: k for k, v in self.ranks.items()}
         specials = [
@@ -186,6 +180,49 @@ class TiktokenEncoding:
         self.eot_token = self.special_tokens["<|endoftext|>"]
         self._special_by_id = {v: k for k, v in self.special_tokens.items()}
         self._pat = regex.compile(self.PATTERN)
+
+    @staticmethod
+    def _read_tiktoken(path: str) -> Dict[bytes, int]:
+        import base64
+        ranks: Dict[bytes, int] = {}
+        with open(path, "rb") as f:
+            for line in f:
+                if line.strip():
+                    tok, rank = line.split()
+                    ranks[base64.b64decode(tok)] = int(rank)
+        return ranks
+
+    @staticmethod
+    def _read_hf_json(path: str) -> Dict[bytes, int]:
+        """The text vocabulary of a HuggingFace ``tokenizer.json`` (byte-level BPE as shipped with the HF Whisper
+        checkpoints; whisper_word_level/hf_whisper.py loads those): token strings are written in GPT-2's printable
+        byte alphabet and, for a GPT-2-derived vocabulary, the ids ARE the merge ranks (256 bytes first, then one token
+        per merge in merge order), which is checked here.  Special tokens are not taken from the file: the hot path
+        relies on upstream's layout after the text vocabulary, and the HF files follow it."""
+        import json
+        with open(path, "r", encoding="utf-8") as f:
+            model = json.load(f)["model"]
+        if model.get("type") != "BPE":
+            raise ValueError(f"{path}: expected a BPE tokenizer, got {model.get('type')!r}")
+        bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\u00a1"), ord("\u00ac") + 1)) + list(range(ord("\u00ae"), ord("\u00ff") + 1))
+        cs, extra = bs[:], 0
+        for b in range(256):
+            if b not in bs:
+                bs.append(b)
+                cs.append(256 + extra)
+                extra += 1
+        to_byte = {chr(c): b for b, c in zip(bs, cs)}
+        vocab = {bytes(to_byte[ch] for ch in tok): int(i) for tok, i in model["vocab"].items()
+                 if all(ch in to_byte for ch in tok)}
+        text = {t: i for t, i in vocab.items() if i < len(vocab)}
+        if sorted(text.values()) != list(range(len(text))):
+            raise ValueError(f"{path}: text-vocabulary ids are not contiguous from 0")
+        for k, m in enumerate(model.get("merges", [])):
+            a, b = m.split(" ") if isinstance(m, str) else m
+            tok = bytes(to_byte[ch] for ch in a) + bytes(to_byte[ch] for ch in b)
+            if text.get(tok) != 256 + k:
+                raise ValueError(f"{path}: ids do not follow the merge order (merge {k}); not a GPT-2 style vocabulary")
+        return text
 
     def _bpe(self, piece: bytes) -> List[int]:
         parts = [piece[i:i + 1] for i in range(len(piece))]
@@ -371,8 +408,9 @@ def _vocab_file(name: str, vocab_dir: Optional[str]) -> Optional[str]:
     for d in (vocab_dir, os.environ.get("SWX_TIKTOKEN_DIR")):
         if d:
             p = os.path.join(d, f"{name}.tiktoken")
-            if os.path.isfile(p):
-                return p
+            for cand in (p, os.path.join(d, f"{name}.json"), os.path.join(d, "tokenizer.json")):
+                if os.path.isfile(cand):
+                    return cand
             if d is vocab_dir:
                 raise FileNotFoundError(p)
     return None

@@ -105,3 +105,39 @@ def test_tokenizer_conventions_on_real_vocabulary_path(vocab_dir):
     assert len(ns) > 10 and en.encode(" -")[0] in ns and all(0 <= t < len(vocab) for t in ns)
     with pytest.raises(FileNotFoundError):
         get_tokenizer(False, num_languages=98, vocab_dir=os.path.join(d, "missing"))
+
+
+def test_hf_tokenizer_json_gives_the_same_encoder(vocab_dir, tmp_path):
+    """a HuggingFace ``tokenizer.json`` built from the same merges loads into the same byte-pair encoder as the
+    ``.tiktoken`` rank file (ids = merge ranks, special tokens in upstream's layout after the text vocabulary)"""
+    tokenizers = pytest.importorskip("tokenizers")
+    import json
+    from tokenizers import Tokenizer, models
+    d, vocab = vocab_dir
+    b2u = _bytes_to_unicode()
+    uni = ["".join(b2u[b] for b in tok) for tok in vocab]
+    merges = []
+    for tok in vocab[256:]:
+        for k in range(1, len(tok)):
+            if tok[:k] in vocab[:vocab.index(tok)] and tok[k:] in vocab[:vocab.index(tok)]:
+                a, b = tok[:k], tok[k:]
+        merges.append(("".join(b2u[x] for x in a), "".join(b2u[x] for x in b)))
+    hf = Tokenizer(models.BPE(vocab={u: i for i, u in enumerate(uni)}, merges=merges))
+    hf.add_special_tokens(["<|endoftext|>", "<|startoftranscript|>"])
+    hf_dir = tmp_path / "hf"
+    hf_dir.mkdir()
+    hf.save(str(hf_dir / "tokenizer.json"))
+    a = TiktokenEncoding(os.path.join(d, "gpt2.tiktoken"), "gpt2", 99)
+    b = TiktokenEncoding(str(hf_dir / "tokenizer.json"), "gpt2", 99)
+    assert a.ranks == b.ranks and a.special_tokens == b.special_tokens and a.n_vocab == b.n_vocab
+    for text in [" the quick brown fox", " naïve café 日本語", "they're here!  12 345", ""]:
+        assert a.encode(text) == b.encode(text) and b.decode(b.encode(text)) == text
+    tok = get_tokenizer(False, num_languages=97, vocab_dir=str(hf_dir))
+    assert isinstance(tok.encoding, TiktokenEncoding) and tok.eot == len(vocab)
+    # a vocabulary whose ids do not follow the merge order is refused instead of silently mis-tokenising
+    data = json.loads((hf_dir / "tokenizer.json").read_text(encoding="utf-8"))
+    data["model"]["merges"] = data["model"]["merges"][1:] + data["model"]["merges"][:1]
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps(data), encoding="utf-8")
+    with pytest.raises(ValueError):
+        TiktokenEncoding(str(bad), "gpt2", 99)
