@@ -294,6 +294,53 @@ def _read_checkpoint(path: str):
     return dims, ckpt["model_state_dict"]
 
 
+# HuggingFace parameter names -> upstream checkpoint names (the inverse of the table the reference keeps for its HF back
+# end, whisper_word_level/hf_whisper.py:30-51): applied as ordered prefix / infix rewrites
+_HF_RENAMES = (
+    ("model.", ""), ("encoder.embed_positions.weight", "encoder.positional_embedding"),
+    ("decoder.embed_positions.weight", "decoder.positional_embedding"), ("decoder.embed_tokens", "decoder.token_embedding"),
+    ("encoder.layer_norm", "encoder.ln_post"), ("decoder.layer_norm", "decoder.ln"), (".layers.", ".blocks."),
+    (".encoder_attn_layer_norm", ".cross_attn_ln"), (".encoder_attn.", ".cross_attn."), (".self_attn_layer_norm", ".attn_ln"),
+    (".self_attn.", ".attn."), (".final_layer_norm", ".mlp_ln"), (".fc1", ".mlp.0"), (".fc2", ".mlp.2"),
+    (".q_proj", ".query"), (".k_proj", ".key"), (".v_proj", ".value"), (".out_proj", ".out"),
+)
+
+
+def read_hf_checkpoint(path: str):
+    """A HuggingFace Whisper checkpoint directory (``config.json`` + ``model.safetensors`` / ``pytorch_model.bin``
+    [+ ``generation_config.json``]) -> (dims, upstream-named state dict, alignment heads or None).  The projection
+    ``proj_out`` is tied to the token embedding upstream and is dropped."""
+    import json
+    with open(os.path.join(path, "config.json"), "r", encoding="utf-8") as f:
+        c = json.load(f)
+    dims = ModelDimensions(n_mels=c["num_mel_bins"], n_audio_ctx=c["max_source_positions"], n_audio_state=c["d_model"],
+                           n_audio_head=c["encoder_attention_heads"], n_audio_layer=c["encoder_layers"],
+                           n_vocab=c["vocab_size"], n_text_ctx=c["max_target_positions"], n_text_state=c["d_model"],
+                           n_text_head=c["decoder_attention_heads"], n_text_layer=c["decoder_layers"])
+    st = os.path.join(path, "model.safetensors")
+    if os.path.isfile(st):
+        from safetensors.torch import load_file
+        raw = load_file(st)
+    elif os.path.isfile(os.path.join(path, "pytorch_model.bin")):
+        raw = torch.load(os.path.join(path, "pytorch_model.bin"), map_location="cpu", weights_only=True)
+    else:
+        raise RuntimeError(f"no model.safetensors / pytorch_model.bin under {path} (sharded checkpoints: merge them first)")
+    sd = {}
+    for k, v in raw.items():
+        if k.startswith("proj_out."):
+            continue
+        for a, b in _HF_RENAMES:
+            k = (b + k[len(a):] if k.startswith(a) else k) if a == "model." else k.replace(a, b)
+        sd[k] = v
+    heads = None
+    gen = os.path.join(path, "generation_config.json")
+    if os.path.isfile(gen):
+        with open(gen, "r", encoding="utf-8") as f:
+            heads = json.load(f).get("alignment_heads")
+        heads = [tuple(int(x) for x in p) for p in heads] if heads else None
+    return dims, sd, heads
+
+
 # The cross-attention heads upstream marks as time-aligned for its official checkpoints (whisper/__init__.py
 # ``_ALIGNMENT_HEADS``, stored there as base85-packed boolean masks; the (layer, head) lists below are the same data as
 # published in the checkpoints' generation configs).  Restated from memory -- there is no copy of either source in this
@@ -326,7 +373,9 @@ def load_model(name: str, device: Optional[Union[str, torch.device]] = None, dow
                alignment_heads: Optional[Sequence[Tuple[int, int]]] = None, **model_kwargs) -> Whisper:
     """Same signature as stable_whisper.load_model (original_whisper.py:953-1009) plus keyword-only extensions.
 
-    name     an official model name or a path to an upstream ``.pt`` checkpoint ({dims, model_state_dict})
+    name     an official model name, a path to an upstream ``.pt`` checkpoint ({dims, model_state_dict}), or a
+             HuggingFace Whisper checkpoint directory (config.json + model.safetensors; its generation config's
+             alignment heads are used)
     dtype    'f16' (default, what the reference uses on a GPU) or 'f32' (strict parity with the reference's CPU path)
     weights  'random' -> seeded random initialisation at the architecture `name` (no network / no checkpoint offline)
     """
@@ -341,7 +390,11 @@ def load_model(name: str, device: Optional[Union[str, torch.device]] = None, dow
         raise RuntimeError("stable_ts_amd runs on an MI355X only (device='cuda[:i]'); there is no CPU path")
     dtype = dtype or "f16"
     sd = None
-    if os.path.isfile(name):
+    if os.path.isdir(name) and os.path.isfile(os.path.join(name, "config.json")):
+        dims, sd, hf_heads = read_hf_checkpoint(name)           # a HuggingFace checkpoint directory
+        if alignment_heads is None:
+            alignment_heads = hf_heads
+    elif os.path.isfile(name):
         dims, sd = _read_checkpoint(name)
     elif name in _DIMS:
         dims = dims_for(name)

@@ -139,3 +139,37 @@ def test_model_matches_hf():
     with torch.no_grad():
         logits2 = m.decoder(tokens, m.encoder(mel))
     torch.testing.assert_close(logits, logits2, rtol=1e-4, atol=1e-5)
+
+
+def test_hf_checkpoint_reader_round_trip(tmp_path):
+    """stable_ts_amd.model.read_hf_checkpoint: a HuggingFace checkpoint directory written by ``save_pretrained`` comes
+    back as upstream-named weights that reproduce the HF model's logits on the oracle (and the oracle's own weights)."""
+    import json
+    from stable_ts_amd.model import read_hf_checkpoint
+    from transformers import WhisperForConditionalGeneration
+    torch.manual_seed(0)
+    m = om.build_model("tiny.en", seed=7, std=0.05)
+    hf_base = _hf_model_from(m)
+    full = WhisperForConditionalGeneration(hf_base.config).eval()
+    full.model.load_state_dict(hf_base.state_dict())
+    full.proj_out.weight = full.model.decoder.embed_tokens.weight
+    d = tmp_path / "hf"
+    full.save_pretrained(str(d), safe_serialization=True)
+    (d / "generation_config.json").write_text(json.dumps(dict(alignment_heads=[[2, 1], [3, 4]])))
+    dims, sd, heads = read_hf_checkpoint(str(d))
+    assert heads == [(2, 1), (3, 4)]
+    assert (dims.n_mels, dims.n_audio_ctx, dims.n_audio_state, dims.n_text_layer, dims.n_vocab) == \
+        (m.dims.n_mels, m.dims.n_audio_ctx, m.dims.n_audio_state, m.dims.n_text_layer, m.dims.n_vocab)
+    want = m.state_dict()
+    assert set(sd) == {k for k in want if k not in ("decoder.mask", "alignment_heads")}
+    for k, v in sd.items():
+        assert torch.equal(v, want[k]), k
+    back = om.Whisper(om.ModelDimensions(**dims.__dict__))
+    back.load_state_dict(sd, strict=False)
+    back.eval()
+    mel = torch.randn(1, dims.n_mels, 3000) * 0.1
+    tokens = torch.tensor([[50257, 50362, 11, 22, 33]])
+    with torch.no_grad():
+        ours = back(mel, tokens)
+        theirs = full(input_features=mel, decoder_input_ids=tokens).logits
+    assert (ours - theirs).abs().max().item() < 2e-4
