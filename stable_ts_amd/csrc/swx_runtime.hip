@@ -50,6 +50,7 @@ struct swx_model {
     std::vector<std::vector<int>> heads_by_layer;   // per decoder layer
     std::vector<int> head_slot0;                    // first capture slot of each layer
     int n_align = 0;
+    std::vector<int32_t> heads_flat;      // heads of all layers, layer-major (device copy: ws + L.heads)
     // workspace
     unsigned char *ws = nullptr;
     size_t ws_bytes = 0;
@@ -58,7 +59,7 @@ struct swx_model {
         size_t melT, h1, x, h, qkv, att, u, gmax, small_i32, zeros_i32;
         size_t tokens0, tokens1, anc0, anc1, pos0, sum_lp, sum_lp_next, row_done, win_done, win_done_prev, n_done;
         size_t fin_tokens, fin_score, fin_len, fin_count, cand_lp, cand_tok, logits, hid2;
-        size_t kcache, vcache, sk, sv, cap, mean, sd, suppress, slabs;
+        size_t kcache, vcache, sk, sv, cap, mean, sd, suppress, slabs, heads;
         size_t total;
         int64_t rows_big, logits_rows;
     } L;
@@ -171,8 +172,11 @@ int upload_heads(swx_model *m)
         for (int h : m->heads_by_layer[l]) flat.push_back(h);
     }
     m->n_align = (int)flat.size();
-    if (m->arena && !flat.empty()) {
-        hipError_t e = hipMemcpy(m->A<int32_t>(m->o_heads), flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
+    m->heads_flat = flat;
+    // same count as the bound workspace was laid out for: refresh its copy in place; a different count needs a re-bind
+    // (swx_score / swx_score_qk refuse to run until then), which uploads the list
+    if (m->ws && m->n_align == m->ws_n_align && !flat.empty()) {
+        hipError_t e = hipMemcpy(m->ws + m->L.heads, flat.data(), flat.size() * 4, hipMemcpyHostToDevice);
         if (e != hipSuccess) return -100 - (int)e;
     }
     return 0;
@@ -237,6 +241,9 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
         for (auto &sh : shapes) { const size_t f = swx_skinny_slab_floats(128, sh[0], sh[1]); if (f > mx) mx = f; }
         L.slabs = take(mx * 4 + 256);
     }
+    // the alignment-head list lives with the workspace, not with the weights: views that share one weight arena
+    // (swx_bind_weights on the same buffer) may be configured with different heads
+    L.heads = take(sizeof(int32_t) * (size_t)D.n_text_layer * D.n_text_head);
     L.total = cur;
 }
 
@@ -412,7 +419,7 @@ int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
         SWX_TRY(swx_attention(m->dtype, ca, 0, s));
         if (f.capture && !m->heads_by_layer[l].empty()) {
             SWX_TRY(swx_qk_capture(m->dtype, qkv, d, f.rpw * f.n_new, f.cap_row0, f.cap_rows, kl, d, chunk, D.n_audio_ctx,
-                                   m->A<int32_t>(m->o_heads) + m->head_slot0[l], (int)m->heads_by_layer[l].size(),
+                                   m->Wp<int32_t>(m->L.heads) + m->head_slot0[l], (int)m->heads_by_layer[l].size(),
                                    m->head_slot0[l], m->n_align, f.W, m->Wp<float>(m->L.cap), f.cap_ld_n, D.n_audio_ctx, s));
         }
         SWX_TRY(gemm_residual(m, att, d, w.wco, w.bco, x, d, rows, d, d, s));
@@ -656,6 +663,10 @@ int swx_bind_workspace(swx_model *m, void *d_ws, size_t bytes, int max_windows, 
     m->L = L;
     hipError_t e = hipMemset(m->ws + L.zeros_i32, 0, (size_t)(max_rows > max_windows ? max_rows : max_windows) * 4 + 256);
     if (e != hipSuccess) return -100 - (int)e;
+    if (!m->heads_flat.empty()) {
+        e = hipMemcpy(m->ws + L.heads, m->heads_flat.data(), m->heads_flat.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return -100 - (int)e;
+    }
     return 0;
 }
 
