@@ -22,7 +22,7 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 import torch
 
-from .audio import FRAMES_PER_SECOND, HOP_LENGTH, N_FFT, N_FRAMES, N_SAMPLES, SAMPLE_RATE
+from .audio import FRAMES_PER_SECOND, N_FFT, N_FRAMES, N_SAMPLES, SAMPLE_RATE
 from .decoding import DecodingOptions, DecodingPlan
 from .result import Segment
 from .timing import add_word_timestamps_batch, split_word_tokens
