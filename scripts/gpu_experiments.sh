@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: gpurun --timeout 900 -- 'bash scripts/gpu_experiments.sh'
+# usage: gpurun --timeout 1800 -- 'bash scripts/gpu_experiments.sh'
 # First hardware run of everything that was written without GPU access (end of round 1): correctness checks first, then
 # the A/B timings that decide which experiments become defaults.  Every step writes its own log under gpurun_out/.
 mkdir -p gpurun_out
