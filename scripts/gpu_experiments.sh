@@ -4,7 +4,7 @@
 # the A/B timings that decide which experiments become defaults.  Every step writes its own log under gpurun_out/.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-run() { name=$1; shift; ( timeout ${T:-240} "$@" 2>&1 | tail -${L:-25} ) > gpurun_out/$name.log; echo "== $name: exit $?"; tail -${L:-25} gpurun_out/$name.log; }
+run() { name=$1; shift; timeout ${T:-240} "$@" > /tmp/swx_step.log 2>&1; rc=$?; tail -${L:-25} /tmp/swx_step.log > gpurun_out/$name.log; echo "== $name: exit $rc"; cat gpurun_out/$name.log; }
 
 # 1. correctness of the new device paths (each exits 0 on parity)
 run chk_splitk   python tests/hw_checks/splitk_hook_check.py
