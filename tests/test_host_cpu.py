@@ -142,3 +142,54 @@ def test_model_decoder_and_call_surface():
     assert Whisper.__call__(f, torch.zeros(2, 80, 3000), torch.tensor([[1, 2], [3, 4]])).shape == (2, 2, 7)
     with pytest.raises(NotImplementedError):
         Whisper.install_kv_cache_hooks(f)
+
+
+def test_ctypes_table_matches_header_prototypes():
+    """every prototype of include/swx.h, parameter by parameter, against the ctypes signature the Python host binds
+    (stable_ts_amd/_lib.py): count, pointer-ness, integer width, float"""
+    import ctypes
+    from stable_ts_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "swx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    protos = re.findall(r"\n\s*([A-Za-z_][\w \*]*?)\b(swx_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr)
+    assert len(protos) >= 25
+
+    def kind(decl: str) -> str:
+        decl = decl.strip()
+        if "*" in decl:
+            return "ptr"
+        base = re.sub(r"\b(const|unsigned|struct)\b", "", decl).split()[0]
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "size_t": "size", "float": "f32", "uint64_t": "u64"}[base]
+
+    def ckind(t) -> str:
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, "contents") or getattr(t, "_type_", None) not in (None, "i", "l", "q", "f", "L", "Q", "I"):
+            return "ptr"
+        return {ctypes.c_int: "i32", ctypes.c_int32: "i32", ctypes.c_int64: "i64", ctypes.c_size_t: "size", ctypes.c_float: "f32",
+                ctypes.c_uint64: "u64"}[t]
+
+    checked = 0
+    for ret, name, params in protos:
+        if name not in _lib.SYMBOLS:
+            continue
+        res, args = _lib.SYMBOLS[name]
+        plist = [p for p in (x.strip() for x in params.split(",")) if p and p != "void"]
+        assert len(plist) == len(args), (name, plist, args)
+        for decl, t in zip(plist, args):
+            k = kind(decl)
+            if k == "size":
+                assert t is ctypes.c_size_t, (name, decl)
+            else:
+                assert ckind(t) == k, (name, decl, t)
+        if ret.strip() == "void":
+            assert res is None, name
+            checked += 1
+            continue
+        rk = "ptr" if "*" in ret else kind(ret)
+        if rk == "ptr":
+            assert res in (ctypes.c_char_p, ctypes.c_void_p), name
+        elif rk == "size":
+            assert res is ctypes.c_size_t, name
+        else:
+            assert res is ctypes.c_int, name
+        checked += 1
+    assert checked == len(_lib.SYMBOLS), (checked, len(_lib.SYMBOLS))
