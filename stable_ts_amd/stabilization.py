@@ -100,6 +100,7 @@ class NonSpeechPredictor:
         self.loudness = loudness
         mwd = 0.1 if min_word_dur is None else min_word_dur
         self.min_units_per_word = max(round(mwd * FRAMES_PER_SECOND), 1)
+        self.min_samples_per_word = round(mwd * 16000)
         self._starts: List[float] = []
         self._ends: List[float] = []
 
@@ -116,7 +117,10 @@ class NonSpeechPredictor:
         if not self.loudness:
             # :271-286 with get_mask: one flag per 20-ms unit, True where EVERY sample of the unit is non-zero
             if not self.get_mask:
-                return dict(timings=None, mask=None, is_silent=False)
+                # :277-281: without a mask the window counts as silent when fewer than min_word_dur worth of samples
+                # are non-zero
+                silent = bool(int(audio.count_nonzero()) < self.min_samples_per_word)
+                return dict(timings=None, mask=None, is_silent=silent)
             extra = audio.shape[-1] % N_SAMPLES_PER_TOKEN
             if extra:
                 audio = F.pad(audio, (0, N_SAMPLES_PER_TOKEN - extra))

@@ -223,7 +223,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
                 model=model, tokenizer=tokenizer,
                 windows=[dict(segments=outs[w]["segments"], num_samples=outs[w]["num_samples"]) for w in idx],
                 xkv=_xkv_select(model, xkv, idx), prepend_punctuations=o["prepend_punctuations"],
-                append_punctuations=o["append_punctuations"], min_word_dur=o["min_word_dur"],
+                append_punctuations=o["append_punctuations"],     # min_word_dur stays at the callee's 0.1 (:636-652)
                 split_callback=o["split_callback"], gap_padding=o["gap_padding"], dynamic_heads=o.get("dynamic_heads"),
                 aligner=o.get("aligner", "legacy"), extra_models=o.get("extra_models"),
                 mel=mel[idx] if o.get("extra_models") else None)
@@ -325,11 +325,13 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
         initial_prompt_tokens = tokenizer.encode(" " + initial_prompt.strip())
 
     def new_track(source: AudioLoader, offset: int = 0) -> _Track:
-        predictor = None
-        if suppress_silence or suppress_ts_tokens or nonspeech_skip:
-            from .stabilization import NonSpeechPredictor
-            predictor = NonSpeechPredictor(q_levels=q_levels, k_size=k_size, min_word_dur=min_word_dur,
-                                           min_silence_dur=min_silence_dur, get_mask=suppress_ts_tokens)
+        from .stabilization import NonSpeechPredictor
+        # :427-441: one predictor per run, always (an all-zero window is fast-forwarded in every mode); the
+        # loudness-based detector only with suppress_silence, otherwise it looks at exact-zero samples and yields no
+        # timings (so nonspeech_skip has nothing to act on, as in the reference)
+        predictor = NonSpeechPredictor(q_levels=q_levels, k_size=k_size, min_word_dur=min_word_dur,
+                                       min_silence_dur=min_silence_dur, get_mask=suppress_ts_tokens,
+                                       loudness=bool(suppress_silence))
         return _Track(source, predictor, list(initial_prompt_tokens), offset)
 
     # one track = one run of the reference's sequential algorithm; ``_span_bounds`` (transcribe_spans) makes several

@@ -260,3 +260,45 @@ def test_head_selection_variants_match_reference(models, monkeypatch, name):
         plain = mine.transcribe(audio, language="en", **BASE)
     assert _snap(got) == _snap(want) and len(want.segments) > 0
     assert _snap(got) != _snap(plain)                     # the variant really changes the word times
+
+
+FUZZ_REGRESSIONS = [
+    # found by random option sets (kept as fixed cases): the word-timestamp stage keeps its own min_word_dur = 0.1 whatever
+    # the caller passes (original_whisper.py:636-652 does not forward it) ...
+    (47.0, 674, dict(sample_len=48, regroup=False, min_word_dur=0.2, initial_prompt=" aaat aaau")),
+    # ... and without suppress_silence the predictor only looks at exact-zero samples: no timings, so nonspeech_skip is inert
+    (31.0, 612, dict(sample_len=24, suppress_silence=False, k_size=3, nonspeech_skip=0.4, max_instant_words=1.0)),
+    (65.0, 208, dict(sample_len=36, regroup=False, k_size=3, min_word_dur=0.2, suppress_ts_tokens=True, max_instant_words=1.0,
+                     avg_prob_threshold=2e-05, nonspeech_skip=0.4, min_silence_dur=0.2)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(FUZZ_REGRESSIONS)))
+def test_transcribe_fuzz_regressions(models, monkeypatch, case):
+    G, ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    seconds, seed, extra = FUZZ_REGRESSIONS[case]
+    opts = dict(BASE, **extra)
+    audio = G.synth_audio(seconds, seed=seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **opts)
+        got = mine.transcribe(audio, language="en", **opts)
+    assert _snap(got) == _snap(want) and len(want.segments) > 0
+
+
+def test_transcribe_all_zero_audio_without_silence_suppression(models, monkeypatch):
+    # the per-run predictor exists in every mode: exact-zero windows are fast-forwarded even with suppress_silence=False
+    G, ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    audio = torch.zeros(16000 * 35)
+    audio[16000 * 31:] = torch.as_tensor(G.synth_audio(4.0, seed=2))
+    calls = mine.engine.n_decode_calls
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, suppress_silence=False, **BASE)
+        got = mine.transcribe(audio, language="en", suppress_silence=False, **BASE)
+    assert _snap(got) == _snap(want)
+    assert mine.engine.n_decode_calls - calls == 1                 # only the window that holds sound reached the decoder
