@@ -412,7 +412,13 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
         if out["segments"]:
             if not condition_on_previous_text or out["result"].temperature > 0.5:                # :706-708
                 tr.prompt_reset_since = len(tr.all_tokens)
-        tr.seek += max(int(adv), 1) if adv is not None else int(item["audio"].shape[-1])
+        n_seg = int(item["audio"].shape[-1])
+        if adv is not None and int(adv) <= 0:
+            # the reference adds 0 to its seek here and never returns (:629-633 with avg_prob_threshold when the last
+            # word ends at the window start); a recording must not be able to hang the loop: skip the window instead
+            warnings.warn(f"window at {tr.seek / SAMPLE_RATE:.2f}s produced no forward progress; skipping it")
+            adv = n_seg
+        tr.seek += int(adv) if adv is not None else n_seg
 
     if batch_size:
         # ---- window-parallel driver: fixed stride, no prompt carry-over

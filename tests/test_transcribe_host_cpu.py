@@ -302,3 +302,17 @@ def test_transcribe_all_zero_audio_without_silence_suppression(models, monkeypat
         got = mine.transcribe(audio, language="en", suppress_silence=False, **BASE)
     assert _snap(got) == _snap(want)
     assert mine.engine.n_decode_calls - calls == 1                 # only the window that holds sound reached the decoder
+
+
+def test_transcribe_zero_progress_window_is_skipped(models, monkeypatch):
+    # found by the random option sets: with avg_prob_threshold + max_instant_words=1 the last kept word can end at the
+    # window start; the reference then adds 0 to its seek and never returns.  This port warns and skips the window.
+    G, ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    opts = dict(temperature=(0.0, 0.6, 1.0), logprob_threshold=-1.0, compression_ratio_threshold=1.0, no_speech_threshold=0.6,
+                sample_len=36, regroup=False, k_size=3, max_instant_words=1.0, avg_prob_threshold=2e-05, best_of=2, length_penalty=0.5)
+    torch.manual_seed(0)
+    with pytest.warns(UserWarning, match="no forward progress"):
+        got = mine.transcribe(G.synth_audio(47.0, seed=143), language="en", **opts)
+    assert len(got.segments) > 0
