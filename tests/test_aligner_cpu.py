@@ -78,7 +78,7 @@ def test_aligner_matches_reference_live():
     import_reference()
     from stable_whisper.non_whisper.alignment import Aligner as RefAligner
     tok = _tok()
-    for seed in range(1000, 1030):
+    for seed in range(1000, 1018):
         want, ref_calls = mg.run(RefAligner, seed, tok, extra=dict(verbose=None))
         got, calls = mg.run(Aligner, seed, tok)
         assert calls == ref_calls, (seed, mg.synth_case(seed)[2])         # same windows, same word batches
