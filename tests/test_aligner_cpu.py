@@ -267,6 +267,10 @@ def test_align_on_standin_matches_reference_align(monkeypatch, variant):
         warnings.simplefilter("ignore")
         want = ref.align(audio, text, language="en", verbose=None, ignore_compatibility=True, **kw_ref)
         got = A.align(mine, audio, text, language="en", **kw_mine)
-    snap = lambda r: [(w.word, w.start, w.end, round(float(w.probability), 9), list(w.tokens)) for w in r.all_words()]
+    snap = lambda r: [(w.word, w.start, w.end, list(w.tokens)) for w in r.all_words()]
     assert snap(got) == snap(want) and len(snap(want)) > 5
+    # probabilities to 1e-5 relative: the reference's align runs its encoder inside disable_sdpa() (timing.py:58-60), the
+    # stand-in's encoder uses the oracle's SDPA path -- an artefact of the CPU stand-in, not of the product
+    for a, b in zip(got.all_words(), want.all_words()):
+        assert abs(a.probability - b.probability) <= 1e-5 * abs(b.probability) + 1e-12
     assert [(s.start, s.end, s.text) for s in got.segments] == [(s.start, s.end, s.text) for s in want.segments]
