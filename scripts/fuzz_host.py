@@ -46,7 +46,9 @@ WORDS = [" aaat", " aaau", " aaax", " aabc", " aabd", " aabg", " aacc", " aadd"]
 
 
 def words_of(r):
-    return None if r is None else [(w.word, w.start, w.end, float(w.probability), list(w.tokens or [])) for w in r.all_words()]
+    if r is None or not r.has_words:            # the reference's all_words() raises on segment-level results
+        return None if r is None else []
+    return [(w.word, w.start, w.end, float(w.probability), list(w.tokens or [])) for w in r.all_words()]
 
 
 def close(a, b, rel):
@@ -60,6 +62,7 @@ def main():
     ap.add_argument("what", choices=["transcribe", "align", "refine"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("-n", type=int, default=20)
+    ap.add_argument("--only", type=int, default=None, help="replay the option stream but run only this iteration")
     args = ap.parse_args()
     import make_golden as G
     sw = G.import_reference()
@@ -101,6 +104,8 @@ def main():
             ra, rb = stable_whisper.WhisperResult(copy.deepcopy(d)), WhisperResult(copy.deepcopy(d))
             run = [lambda: ref.refine(audio, ra, verbose=None, **opts), lambda: A.refine(mine, audio, rb, **opts)]
             rel = 1e-8
+        if args.only is not None and it != args.only:
+            continue
         print("START", it, seed, opts, flush=True)                         # a run that stalls shows its options
         res = []
         for f in run:
@@ -110,6 +115,10 @@ def main():
                 res.append(("ok", words_of(r), None if r is None else [(s.start, s.end, s.text) for s in r.segments]))
             except Exception as e:                                         # noqa: BLE001
                 res.append(("raised", type(e).__name__))
+                print("   raised:", type(e).__name__, str(e)[:300], flush=True)
+                if args.only is not None:
+                    import traceback
+                    traceback.print_exc(limit=-5)
         if res[0][0] == res[1][0] == "ok":
             same = res[0][2] == res[1][2] and close(res[0][1], res[1][1], rel)
         else:
