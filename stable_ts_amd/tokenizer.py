@@ -95,6 +95,7 @@ class SyntheticEncoding:
         self._special_by_id = {v: k for k, v in self.special_tokens.items()}
 
     def token_str(self, t: int) -> str:
+        t = int(t)                      # callers hand over 0-dim tensors too (alignment.py:1002-1003); never mutate them
         if t >= self.n_text:
             return self._special_by_id[t]
         if t < len(_PUNCT):
@@ -246,6 +247,7 @@ class TiktokenEncoding:
         return out
 
     def decode_bytes(self, tokens: List[int]) -> bytes:
+        tokens = [int(t) for t in tokens]          # 0-dim tensors are accepted like ints
         return b"".join(self._bytes_by_id[t] if t < self.n_text else self._special_by_id[t].encode() for t in tokens)
 
     def decode(self, tokens: List[int]) -> str:

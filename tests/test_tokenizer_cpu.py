@@ -141,3 +141,14 @@ def test_hf_tokenizer_json_gives_the_same_encoder(vocab_dir, tmp_path):
     bad.write_text(json.dumps(data), encoding="utf-8")
     with pytest.raises(ValueError):
         TiktokenEncoding(str(bad), "gpt2", 99)
+
+
+def test_decode_accepts_tensors_without_mutating_them():
+    # found by fuzzing locate(): the reference hands 0-dim tensors to tokenizer.decode (alignment.py:1002-1003); an in-place
+    # floor division inside the synthetic vocabulary's letter code used to overwrite the caller's tensor
+    import torch
+    tok = get_tokenizer(False, num_languages=99)
+    t = torch.tensor(28054)
+    ids = [t, torch.tensor(19)]
+    assert tok.decode(ids) == tok.decode([28054, 19])
+    assert int(t) == 28054 and int(ids[1]) == 19
