@@ -1,11 +1,13 @@
 """Random option sets against the reference on CPU: the host side of transcribe() / align() / refine() on the oracle-backed
 stand-in (tests/oracle_engine.py) next to the reference's own functions on the same oracle model.  This is how the two
 host-logic differences fixed in round 1 were found (tests/test_transcribe_host_cpu.py::test_transcribe_fuzz_regressions).
-Needs /root/reference.  Probabilities are compared to 1e-5 relative in align (the reference runs its encoder inside
-disable_sdpa() there; the stand-in's encoder does not -- a stand-in artefact).
+Needs /root/reference.  The reference runs its encoder inside disable_sdpa() in the alignment flows and with SDPA in
+transcribe; the stand-in follows (``manual_attention_encoder``), because the oracle's two attention code paths differ
+by ~1e-7 and that is enough to move a DTW path on the near-uniform attention of random weights.
 
     python scripts/fuzz_host.py transcribe --seed 3 -n 40
     python scripts/fuzz_host.py align --seed 9 -n 45
+    python scripts/fuzz_host.py align_words --seed 3 -n 25
     python scripts/fuzz_host.py refine --seed 3 -n 8
 """
 import argparse
@@ -38,6 +40,10 @@ ALIGN = dict(
     remove_instant_words=[False, True], suppress_silence=[True, False], suppress_word_ts=[True, False], q_levels=[20, 10],
     k_size=[5, 3], min_word_dur=[0.1, 0.2, None], nonspeech_error=[0.1, 0.3], use_word_position=[True, False],
     regroup=[True, False, "sg=.3"], presplit=[True, False], gap_padding=[" ...", None], dynamic_heads=[3], aligner=["legacy", "new"])
+ALIGN_WORDS = dict(
+    normalize_text=[True, False], inplace=[True, False], suppress_silence=[True, False], suppress_word_ts=[True, False],
+    min_word_dur=[0.1, 0.2], nonspeech_error=[0.1, 0.3], use_word_position=[True, False], regroup=[True, False], q_levels=[20, 10],
+    k_size=[5, 3], min_silence_dur=[None, 0.2], presplit=[True, False], gap_padding=[" ...", None], word_dur_factor=[None, None, 2.0])
 REFINE = dict(
     steps=[None, "s", "e", "se"], rel_prob_decrease=[0.03, 0.1], abs_prob_decrease=[0.05, 0.01], rel_rel_prob_decrease=[None, 0.1],
     prob_threshold=[0.5, 0.05], rel_dur_change=[0.5, None, 0.2], abs_dur_change=[None, 0.3], word_level=[True, False],
@@ -59,7 +65,7 @@ def close(a, b, rel):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["transcribe", "align", "refine"])
+    ap.add_argument("what", choices=["transcribe", "align", "align_words", "refine"])
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("-n", type=int, default=20)
     ap.add_argument("--only", type=int, default=None, help="replay the option stream but run only this iteration")
@@ -77,7 +83,8 @@ def main():
     sw.modify_model(ref)
     mine = CpuWhisper(ref)
     rnd = random.Random(args.seed)
-    pool = dict(transcribe=TRANSCRIBE, align=ALIGN, refine=REFINE)[args.what]
+    mine.manual_attention_encoder = args.what in ("align", "align_words")
+    pool = dict(transcribe=TRANSCRIBE, align=ALIGN, align_words=ALIGN_WORDS, refine=REFINE)[args.what]
     warnings.simplefilter("ignore")
     bad = 0
     for it in range(args.n):
@@ -96,7 +103,22 @@ def main():
             audio = G.synth_audio(rnd.choice([8.0, 31.0, 55.0]), seed=seed)
             run = [lambda: ref.align(audio, text, language="en", verbose=None, ignore_compatibility=True, **opts),
                    lambda: A.align(mine, audio, text, language="en", **opts)]
-            rel = 1e-5
+            rel = 1e-8
+        elif args.what == "align_words":
+            audio = G.synth_audio(rnd.choice([31.0, 62.0]), seed=seed)
+            d = ref.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, sample_len=rnd.choice([24, 40]),
+                               regroup=rnd.choice([True, False]), **BASE).to_dict()
+            as_dicts = rnd.random() < 0.4
+            bs = rnd.choice([1, 3, 8])
+
+            def given(cls):
+                if as_dicts:
+                    return [dict(start=s["start"], end=s["end"], text=s["text"]) for s in d["segments"]]
+                return cls(copy.deepcopy(d))
+            run = [lambda: ref.align_words(audio, given(stable_whisper.WhisperResult), language="en", verbose=None,
+                                           ignore_compatibility=True, **opts),
+                   lambda: A.align_words(mine, audio, given(WhisperResult), language="en", batch_size=bs, **opts)]
+            rel = 1e-8
         else:
             opts.setdefault("precision", 0.5)
             audio = G.synth_audio(rnd.choice([12.0, 20.0]), seed=seed)

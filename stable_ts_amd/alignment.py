@@ -114,6 +114,12 @@ def align_words(model, audio, result: Union[WhisperResult, List[dict]], language
     reference's on CPU, batched and unbatched."""
     from .aligner import Aligner
     from .transcribe import as_waveform, pop_audio_options
+    # the fallback machinery of align() does not exist here: its options are refused like any unknown keyword
+    # (options.py:16-18 via AllOptions at alignment.py:350)
+    extras = [k for k in options if k in ("remove_instant_words", "token_step", "original_split", "word_dur_factor",
+                                          "max_word_dur", "nonspeech_skip", "fast_mode", "failure_threshold")]
+    if extras:
+        raise TypeError(f"got unexpected keyword argument(s): {', '.join(extras)}")
     audio_options = pop_audio_options(options)
     if tokenizer is None:
         language = language or getattr(result, "language", None)

@@ -195,9 +195,18 @@ class CpuWhisper:
             return pad_or_trim(log_mel_spectrogram(torch.stack(audios), self.dims.n_mels, padding=padding), N_FRAMES)
         return torch.stack([pad_or_trim(log_mel_spectrogram(a, self.dims.n_mels, padding=padding), N_FRAMES) for a in audios])
 
+    # the reference encodes inside ``disable_sdpa()`` in its alignment flows (timing.py:58-60) and with SDPA in transcribe
+    # (decode.py:27-30); the two attention code paths of the oracle differ by ~1e-7, enough to move a DTW path on the
+    # near-uniform attention of random weights.  Tests of align / align_words / refine / locate set this to True.
+    manual_attention_encoder = False
+
     @torch.no_grad()
     def encoder(self, mel):
         with _SDPA_LOCK:
+            if self.manual_attention_encoder:
+                from oracle.whisper.model import disable_sdpa
+                with disable_sdpa():
+                    return self.om.encoder(mel)
             return self.om.encoder(mel)
 
     def cross_kv(self, xa):
