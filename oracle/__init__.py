@@ -8,7 +8,7 @@ Pinning status: the reference holds no golden vectors or known-answer tests for 
 algorithm is restated here (openai-whisper==20250625) is absent offline, so against upstream itself the arithmetic is
 "parity unpinned".  What pins it instead (tests/test_oracle_pinning.py, tests/golden/): the independent ports shipped
 with ``transformers`` (log-mel, encoder / decoder outputs through the reference's own weight-name map, median filter,
-DTW incl. the known-answer vector of SURVEY.md 8c), and the reference's OWN glue (decode.py, timing.py, transcribe,
+DTW incl. the known-answer vector of SURVEY.md 8c, the timestamp / blank / token suppression rules of the decode loop), and the reference's OWN glue (decode.py, timing.py, transcribe,
 align, Aligner, Refiner, locate, WhisperResult.regroup) imported from /root/reference and run on top of this package.
 
 Layout

@@ -173,3 +173,55 @@ def test_hf_checkpoint_reader_round_trip(tmp_path):
         ours = back(mel, tokens)
         theirs = full(input_features=mel, decoder_input_ids=tokens).logits
     assert (ours - theirs).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize("max_initial", [None, 50, 0])
+def test_timestamp_rules_match_hf_port(max_initial):
+    """oracle ApplyTimestampRules (upstream whisper/decoding.py, the filter the on-device decode loop re-implements) vs
+    ``transformers``' WhisperTimeStampLogitsProcessor -- an independent port of the same upstream rule set -- on random
+    logits after random (rule-conforming and rule-breaking) token histories, incl. the first sampled position."""
+    from types import SimpleNamespace
+    from transformers.generation.logits_process import (SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor,
+                                                         WhisperTimeStampLogitsProcessor)
+    from oracle.whisper.decoding import ApplyTimestampRules, SuppressBlank, SuppressTokens
+    from oracle.whisper.tokenizer import get_tokenizer
+    tok = get_tokenizer(False, num_languages=99)
+    V = tok.timestamp_begin + 1501
+    begin = 3
+    cfg = SimpleNamespace(no_timestamps_token_id=tok.no_timestamps, eos_token_id=tok.eot, bos_token_id=tok.sot,
+                          max_initial_timestamp_index=max_initial)
+    hf = WhisperTimeStampLogitsProcessor(cfg, begin_index=begin)
+    ours = ApplyTimestampRules(tok, begin, max_initial)
+    g = torch.Generator().manual_seed(0 if max_initial is None else max_initial + 1)
+    tb = tok.timestamp_begin
+    for trial in range(60):
+        n = int(torch.randint(0, 9, (1,), generator=g))
+        rows = []
+        for _ in range(3):
+            hist, last_ts = [], tb
+            for i in range(n):
+                if torch.rand(1, generator=g) < 0.45:
+                    last_ts = min(tb + 1500, last_ts + int(torch.randint(0, 40, (1,), generator=g)))
+                    hist.append(last_ts)
+                else:
+                    hist.append(int(torch.randint(0, tok.eot, (1,), generator=g)))
+            rows.append([tok.sot, tok.sot + 1, tok.sot + 2][:begin] + hist)
+        tokens = torch.tensor(rows)
+        logits = torch.randn(3, V, generator=g) * 3
+        logits[:, tb:] += float(torch.randn(1, generator=g)) * 4            # sometimes the timestamp mass wins, sometimes not
+        want = hf(tokens, logits.clone())
+        got = logits.clone()
+        ours.apply(got, tokens)
+        assert torch.equal(torch.isinf(got), torch.isinf(want)), trial
+        assert torch.equal(got[~torch.isinf(got)], want[~torch.isinf(want)])
+    # the two simple filters next to their HF counterparts
+    sup = [1, 5, 77, tok.sot, tok.no_speech]
+    lg = torch.randn(2, V, generator=g)
+    a = lg.clone()
+    SuppressTokens(sup).apply(a, torch.zeros(2, 4, dtype=torch.long))
+    assert torch.equal(a, SuppressTokensLogitsProcessor(sup)(torch.zeros(2, 4, dtype=torch.long), lg.clone()))
+    blank = tok.encode(" ") + [tok.eot]
+    for length in (begin, begin + 1):
+        a = lg.clone()
+        SuppressBlank(tok, begin).apply(a, torch.zeros(2, length, dtype=torch.long))
+        assert torch.equal(a, SuppressTokensAtBeginLogitsProcessor(blank, begin)(torch.zeros(2, length, dtype=torch.long), lg.clone()))
