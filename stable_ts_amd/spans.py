@@ -6,6 +6,8 @@ shard by window.  It does shard by *span*: cut the recording at quiet places int
 algorithm on every span independently (fresh prompt at each span start) and concatenate the results shifted by their
 span offsets.  The oracle for this mode is exact by construction -- the reference's ``transcribe()`` run once per span
 and concatenated (``tests/test_spans_cpu.py``) -- unlike ``batch_size=N`` (fixed 30-s stride, no prompt carry-over).
+The equality is for deterministic decoding (greedy / beam at temperature 0, thresholds that do not trigger the sampling
+fallback); sampled fallbacks draw random numbers, and the spans' draws interleave here.
 
 On one GPU the spans advance in lockstep: every device batch holds the current window of each live span, so the encoder,
 the decode loop and the scoring pass run at batch = number of spans while each span still sees exactly the windows and
