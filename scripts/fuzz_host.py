@@ -14,6 +14,7 @@ import argparse
 import copy
 import os
 import random
+import signal
 import sys
 import warnings
 
@@ -28,7 +29,7 @@ TRANSCRIBE = dict(
     condition_on_previous_text=[True, False], word_timestamps=[True, True, False], regroup=[True, False, "sg=.3_sl=25"],
     suppress_silence=[True, False], suppress_word_ts=[True, False], use_word_position=[True, False], q_levels=[20, 10],
     k_size=[5, 3], min_word_dur=[0.1, 0.2, None], nonspeech_error=[0.1, 0.3], suppress_ts_tokens=[False, True],
-    gap_padding=[" ...", None], max_instant_words=[0.5, 0.2, 1.0], nonspeech_skip=[0.4, 1.0], beam_size=[2, 3],
+    gap_padding=[" ...", None], max_instant_words=[0.5, 0.2, 1.0], avg_prob_threshold=[0.00002], nonspeech_skip=[0.4, 1.0], beam_size=[2, 3],
     initial_prompt=[" aaat aaau"], prefix=[" aaaw"], dynamic_heads=[3, "3,2"], aligner=["legacy", "legacy", "new"],
     min_silence_dur=[0.2], clip_timestamps=[[2.0, 20.0, 26.0]], temperature=[0.0, (0.0, 0.4), (0.0, 0.6, 1.0)],
     compression_ratio_threshold=[None, 2.4, 1.0], logprob_threshold=[None, -1.0, -30.0], no_speech_threshold=[None, 0.6, 0.01],
@@ -51,6 +52,14 @@ REFINE = dict(
 WORDS = [" aaat", " aaau", " aaax", " aabc", " aabd", " aabg", " aacc", " aadd"]
 
 
+class _Stall(Exception):
+    pass
+
+
+def _on_alarm(signum, frame):
+    raise _Stall()
+
+
 def words_of(r):
     if r is None or not r.has_words:            # the reference's all_words() raises on segment-level results
         return None if r is None else []
@@ -69,6 +78,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("-n", type=int, default=20)
     ap.add_argument("--only", type=int, default=None, help="replay the option stream but run only this iteration")
+    ap.add_argument("--timeout", type=int, default=180, help="seconds per call; a reference call that does not return (its "
+                    "window loop can stall, DESIGN.md section 7) is reported as STALL and not counted")
     args = ap.parse_args()
     import make_golden as G
     sw = G.import_reference()
@@ -86,6 +97,7 @@ def main():
     mine.manual_attention_encoder = args.what in ("align", "align_words")
     pool = dict(transcribe=TRANSCRIBE, align=ALIGN, align_words=ALIGN_WORDS, refine=REFINE)[args.what]
     warnings.simplefilter("ignore")
+    signal.signal(signal.SIGALRM, _on_alarm)
     bad = 0
     for it in range(args.n):
         opts = {k: rnd.choice(v) for k, v in pool.items() if rnd.random() < (0.3 if args.what == "transcribe" else 0.4)}
@@ -133,14 +145,22 @@ def main():
         for f in run:
             torch.manual_seed(0)
             try:
+                signal.alarm(args.timeout)
                 r = f()
+                signal.alarm(0)
                 res.append(("ok", words_of(r), None if r is None else [(s.start, s.end, s.text) for s in r.segments]))
+            except _Stall:
+                res.append(("stall",))
             except Exception as e:                                         # noqa: BLE001
+                signal.alarm(0)
                 res.append(("raised", type(e).__name__))
                 print("   raised:", type(e).__name__, str(e)[:300], flush=True)
                 if args.only is not None:
                     import traceback
                     traceback.print_exc(limit=-5)
+        if res[0][0] == "stall":
+            print(it, "STALL (reference)", res[1][0], flush=True)
+            continue
         if res[0][0] == res[1][0] == "ok":
             same = res[0][2] == res[1][2] and close(res[0][1], res[1][1], rel)
         else:
