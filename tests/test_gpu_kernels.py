@@ -316,5 +316,5 @@ def test_new_kernel_paths_in_subprocess(check):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "hw_checks", check)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(here, "hw_checks", check)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])

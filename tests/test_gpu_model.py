@@ -316,5 +316,5 @@ def test_decode_f16_unsplit_gemm_policy(name, policy):
     import sys
     env = dict(os.environ, SWX_PG_POLICY=policy)
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hw_checks", "pg_policy_check.py"), name],
-                       capture_output=True, text=True, timeout=600, env=env)
+                       capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
