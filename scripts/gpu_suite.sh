@@ -4,7 +4,7 @@
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ( timeout 60 python __graft_entry__.py smoke 2>&1 | tail -3 ) > gpurun_out/smoke.log
-( timeout 300 python -m pytest tests -m gpu -q -n 4 --timeout=280 2>&1 | tail -8 ) > gpurun_out/gpu_tests.log
+( timeout 900 python -m pytest tests -m gpu -q -n 4 --timeout=400 2>&1 | tail -8 ) > gpurun_out/gpu_tests.log
 ( timeout 240 python bench.py 2> gpurun_out/bench.err | tail -2 ) > gpurun_out/bench.log
 cd /tmp && ( timeout 200 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline 2>&1 | tail -3 ) > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log
 cd $GRAFT_REPO_ROOT
