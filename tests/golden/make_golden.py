@@ -141,5 +141,40 @@ def run_refine_case(sw):
                 top1_prob=probs.max(-1).values.tolist())
 
 
+VARIANT_CASES = [
+    dict(name="tiny_en_dynamic_heads", model="tiny.en", gain=2.0, ts_gain=0.5, seconds=47.0, seed=1,
+         opts=dict(temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+                   sample_len=40, suppress_silence=True, dynamic_heads="4,2")),
+    dict(name="tiny_en_new_aligner", model="tiny.en", gain=2.0, ts_gain=0.5, seconds=47.0, seed=1,
+         opts=dict(temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+                   sample_len=40, suppress_silence=False, aligner="new")),
+]
+
+
+def run_variants():
+    """Head-selection variants of the attention stage (timing.py:87-103, 115-163) through the reference's transcribe on the
+    oracle; written to reference_variants.json (reference_glue.json and the tests that read it stay untouched)."""
+    sw = import_reference()
+    from oracle.whisper.model import build_model
+    out = {}
+    for c in VARIANT_CASES:
+        model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+        sw.modify_model(model)
+        res = model.transcribe(synth_audio(c["seconds"], c["seed"]), language="en", verbose=None, ignore_compatibility=True,
+                               regroup=False, word_timestamps=True, **c["opts"])
+        d = res.to_dict()
+        segs = [dict(start=float(s["start"]), end=float(s["end"]), seek=float(s["seek"]), tokens=[int(t) for t in s["tokens"]],
+                     words=[dict(word=w["word"], start=float(w["start"]), end=float(w["end"]),
+                                 probability=float(w["probability"]), tokens=[int(t) for t in w["tokens"]])
+                            for w in s["words"]]) for s in d["segments"]]
+        out[c["name"]] = dict(case=c, segments=segs, text=d["text"])
+        print(c["name"], len(segs), "segments", sum(len(s["words"]) for s in segs), "words")
+    with open(os.path.join(HERE, "reference_variants.json"), "w") as f:
+        json.dump(out, f, indent=0)
+
+
 if __name__ == "__main__":
-    run()
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        run_variants()
+    else:
+        run()

@@ -148,3 +148,26 @@ def test_transcribe_spans_equals_sequential_per_span():
         for wa, wb in zip(x["words"], y["words"]):
             assert wa["word"] == wb["word"]
             assert abs(wa["start"] - wb["start"]) < 2e-3 and abs(wa["end"] - wb["end"]) < 2e-3
+
+
+@pytest.mark.xfail(strict=False, reason="head-selection variants written after the round's GPU minutes ran out: first hardware run decides")
+@pytest.mark.parametrize("name", ["tiny_en_dynamic_heads", "tiny_en_new_aligner"])
+def test_transcribe_variants_match_reference_glue(name):
+    # dynamic heads / the 'new' aligner (timing.py:87-103, 115-163): the reference's transcribe on the oracle
+    # (tests/golden/reference_variants.json) vs this package on the device, strict f32.  Same bar as the default path.
+    with open(os.path.join(HERE, "golden", "reference_variants.json")) as f:
+        g = json.load(f)[name]
+    case = g["case"]
+    model = _model(case)
+    audio = _synth_audio(case["seconds"], case["seed"])
+    res = model.transcribe(audio, language="en", regroup=False, word_timestamps=True, **case["opts"])
+    segs = res.to_dict()["segments"]
+    eot = 50256
+    assert len(segs) == len(g["segments"])
+    for a, b in zip(segs, g["segments"]):
+        assert [t for t in a["tokens"] if t < eot] == [t for t in b["tokens"] if t < eot]
+        assert len(a["words"]) == len(b["words"])
+        for wa, wb in zip(a["words"], b["words"]):
+            assert wa["word"] == wb["word"] and wa["tokens"] == wb["tokens"]
+            assert abs(wa["start"] - wb["start"]) <= 0.02 + 1e-9 and abs(wa["end"] - wb["end"]) <= 0.02 + 1e-9, (wa, wb)
+            assert abs(wa["probability"] - wb["probability"]) <= 1e-3 * max(wb["probability"], 1e-3) + 1e-9
