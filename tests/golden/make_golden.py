@@ -169,8 +169,50 @@ def run_variants():
                             for w in s["words"]]) for s in d["segments"]]
         out[c["name"]] = dict(case=c, segments=segs, text=d["text"])
         print(c["name"], len(segs), "segments", sum(len(s["words"]) for s in segs), "words")
+    out["locate_tiny_en"] = run_locate_cases(sw)
     with open(os.path.join(HERE, "reference_variants.json"), "w") as f:
         json.dump(out, f, indent=0)
+
+
+LOCATE_CASES = [
+    dict(text=" bpna", mode=2, count=3, start=2.0),
+    dict(text=" bpna", mode=1, count=2, probability_threshold=0.0, duration_window=[2.0, 4.0]),
+    dict(text=" bpna", mode=0, count=2, probability_threshold=0.0, max_token_per_seg=8),
+]
+
+
+def plain_locate(matches):
+    """JSON form of locate()'s return value: dict matches as they are, Segment matches as seek + words"""
+    out = []
+    for m in matches:
+        if isinstance(m, dict):
+            out.append({k: ([dict(w, probability=float(w["probability"])) for w in v] if k == "duration_window_word" else
+                            (float(v) if isinstance(v, float) else v)) for k, v in m.items()})
+        else:
+            out.append(dict(seek=float(m.seek), words=[dict(word=w.word, start=float(w.start), end=float(w.end),
+                                                             probability=float(w.probability), tokens=[int(t) for t in w.tokens])
+                                                        for w in m.words]))
+    return out
+
+
+def run_locate_cases(sw):
+    """alignment.py:756-1116 on the oracle model, modes 2 / 1 / 0"""
+    import contextlib
+    import io
+    from oracle.whisper.model import build_model
+    c = dict(model="tiny.en", gain=2.0, ts_gain=0.5, seconds=75.0, seed=12)
+    model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+    sw.modify_model(model)
+    audio = synth_audio(c["seconds"], c["seed"])
+    results = []
+    for kw in LOCATE_CASES:
+        kw = dict(kw)
+        text = kw.pop("text")
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = sw.alignment.locate(model, audio, text, "en", verbose=None, **kw)
+        results.append(plain_locate(r))
+        print("locate", kw, len(r), "matches")
+    return dict(case=c, calls=LOCATE_CASES, results=results)
 
 
 if __name__ == "__main__":

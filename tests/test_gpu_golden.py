@@ -171,3 +171,37 @@ def test_transcribe_variants_match_reference_glue(name):
             assert wa["word"] == wb["word"] and wa["tokens"] == wb["tokens"]
             assert abs(wa["start"] - wb["start"]) <= 0.02 + 1e-9 and abs(wa["end"] - wb["end"]) <= 0.02 + 1e-9, (wa, wb)
             assert abs(wa["probability"] - wb["probability"]) <= 1e-3 * max(wb["probability"], 1e-3) + 1e-9
+
+
+@pytest.mark.xfail(strict=False, reason="locate() on the device written after the round's GPU minutes ran out: first hardware run decides")
+def test_locate_matches_reference_glue():
+    # the reference's locate (alignment.py:756-1116, modes 2 / 1 / 0) on the oracle model vs this package on the device
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    with open(os.path.join(HERE, "golden", "reference_variants.json")) as f:
+        g = json.load(f)["locate_tiny_en"]
+    model = _model(g["case"])
+    audio = _synth_audio(g["case"]["seconds"], g["case"]["seed"])
+
+    def close(a, b, path=""):
+        if isinstance(b, dict):
+            assert set(a) == set(b), path
+            for k in b:
+                close(a[k], b[k], f"{path}.{k}")
+        elif isinstance(b, list):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                close(x, y, f"{path}[{i}]")
+        elif isinstance(b, float):
+            tol = 1e-3 * max(abs(b), 1e-3) + 1e-9 if "probability" in path else 0.02 + 1e-9
+            assert abs(a - b) <= tol, (path, a, b)
+        else:
+            assert a == b, (path, a, b)
+
+    for kw, want in zip(g["calls"], g["results"]):
+        kw = dict(kw)
+        text = kw.pop("text")
+        got = mg.plain_locate(model.locate(audio, text, "en", verbose=None, **kw))
+        close(got, want, str(kw))
