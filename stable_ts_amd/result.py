@@ -1085,15 +1085,15 @@ class WhisperResult:
     def remove_word(self, word, reassign_ids: bool = True, verbose: bool = True, record: bool = True):
         """result.py:2149-2194.  ``word`` is a WordTiming, a (segment, word) index pair or "seg,word"."""
         if isinstance(word, WordTiming):
-            if self.segments[word.segment_id].words[word.id] is not word:
+            if self[word.segment_id][word.id] is not word:
                 self.reassign_ids()
-                if self.segments[word.segment_id].words[word.id] is not word:
+                if self[word.segment_id][word.id] is not word:
                     raise ValueError("word not in result")
             si, wi = word.segment_id, word.id
         else:
             si, wi = map(int, word.split(",")) if isinstance(word, str) else word
         if verbose:
-            print(f"Removed: {self.segments[si].words[wi].to_dict()}")
+            print(f"Removed: {self[si][wi].to_dict()}")       # a segment without words raises ValueError here, as upstream
         del self.segments[si].words[wi]
         if not reassign_ids:
             return self
