@@ -48,6 +48,10 @@ void swx_model_destroy(swx_model *m);
 /* size of the packed weight arena for this model/dtype */
 size_t swx_weights_bytes(const swx_model *m);
 int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes);
+/* a further handle (same dims and dtype) on the arena of `owner`, which stays the owner of the memory: the weights are
+ * shared, nothing is cleared; each handle has its own workspace, alignment heads and stream, so host threads can drive
+ * them concurrently (stream lanes) or with different head sets (the every-head view of swx_score_qk) */
+int swx_share_weights(swx_model *m, const swx_model *owner);
 /* copy one checkpoint tensor (upstream state_dict key, fp32, device memory) into its packed slot,
  * converting/re-laying it out (QKV fusion, conv tap-major layout, fp16 cast) on the device */
 int swx_load_tensor(swx_model *m, const char *name, const float *d_src, int64_t numel, void *stream);

@@ -39,6 +39,7 @@ SYMBOLS = {
     "swx_model_destroy": (None, [c_void_p]),
     "swx_weights_bytes": (c_size_t, [c_void_p]),
     "swx_bind_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "swx_share_weights": (c_int, [c_void_p, c_void_p]),
     "swx_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_void_p]),
     "swx_weights_complete": (c_int, [c_void_p]),
     "swx_missing_tensor": (c_int, [c_void_p, c_int, c_char_p, c_int]),

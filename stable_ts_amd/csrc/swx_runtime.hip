@@ -585,6 +585,21 @@ int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes)
     return upload_heads(m);
 }
 
+int swx_share_weights(swx_model *m, const swx_model *owner)
+{
+    // a second handle on an arena that is already populated: nothing is cleared or re-initialised (swx_bind_weights
+    // zeroes the arena), the bookkeeping of which tensors are present is taken over from the owner
+    if (!m || !owner || !owner->arena || m == owner) return -1;
+    if (m->dtype != owner->dtype || m->arena_bytes != owner->arena_bytes || memcmp(&m->dims, &owner->dims, sizeof(swx_dims)) != 0)
+        return -1;
+    m->arena = owner->arena;
+    for (auto &kv : m->slots) {
+        auto it = owner->slots.find(kv.first);
+        kv.second.loaded = it != owner->slots.end() && it->second.loaded;
+    }
+    return upload_heads(m);
+}
+
 int swx_load_tensor(swx_model *m, const char *name, const float *d_src, int64_t numel, void *stream)
 {
     if (!m || !m->arena) return -9;

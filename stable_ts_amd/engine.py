@@ -73,8 +73,8 @@ class Engine:
         h = ctypes.c_void_p()
         check(self.lib.swx_model_create(ctypes.byref(cd), self.dtype, ctypes.byref(h)), "swx_model_create")
         e.h = h
-        e.arena = self.arena
-        check(self.lib.swx_bind_weights(e.h, _ptr(e.arena), e.arena.numel()), "swx_bind_weights")
+        e.arena = self.arena                     # keeps the tensor alive; the C side shares it without clearing it
+        check(self.lib.swx_share_weights(e.h, self.h), "swx_share_weights")
         e._heads = None
         if self._heads is not None:
             e.set_alignment_heads(self._heads)
