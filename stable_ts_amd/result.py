@@ -185,7 +185,7 @@ class WordTiming:
 
     def to_dict(self) -> dict:
         return dict(word=self.word, start=self.start, end=self.end, probability=self.probability,
-                    tokens=None if self.tokens is None else list(self.tokens), segment_id=self.segment_id, id=self.id)
+                    tokens=None if self.tokens is None else list(self.tokens))
 
 
 class Segment:

@@ -83,7 +83,7 @@ def test_result_schema_and_rounding():
     d = seg.to_dict()
     assert list(d) == ["start", "end", "text", "seek", "tokens", "temperature", "avg_logprob", "compression_ratio",
                        "no_speech_prob", "words"]
-    assert list(d["words"][0]) == ["word", "start", "end", "probability", "tokens", "segment_id", "id"]
+    assert list(d["words"][0]) == ["word", "start", "end", "probability", "tokens"]            # result.py:192-204
     res = WhisperResult([seg.to_dict()])
     assert list(res.to_dict()) == ["text", "segments", "language", "ori_dict", "regroup_history", "nonspeech_sections",
                                    "unfinished"]

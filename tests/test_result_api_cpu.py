@@ -99,9 +99,8 @@ def test_pickers_and_lock_groups(ref, seed):
     assert a.all_words_by_lock(by_segment=True, include_single=True) == b.all_words_by_lock(by_segment=True, include_single=True)
     assert [[w.word for w in g] for g in a.all_words_by_lock(only_text=False)] == \
         [[w.word for w in g] for g in b.all_words_by_lock(only_text=False)]
-    assert a.segments_to_dicts() == [{k: v for k, v in d.items()} for d in
-                                     [{**sd, "words": [{k: w[k] for k in ("word", "start", "end", "probability", "tokens")} for w in sd["words"]]}
-                                      if "words" in sd else sd for sd in b.segments_to_dicts()]]
+    assert a.segments_to_dicts() == b.segments_to_dicts()
+    assert a.to_dict() == b.to_dict()
 
 
 @pytest.mark.parametrize("seed", range(12))
