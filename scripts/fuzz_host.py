@@ -148,7 +148,8 @@ def main():
                 signal.alarm(args.timeout)
                 r = f()
                 signal.alarm(0)
-                res.append(("ok", words_of(r), None if r is None else [(s.start, s.end, s.text) for s in r.segments]))
+                res.append(("ok", words_of(r), None if r is None else [(s.start, s.end, s.text) for s in r.segments],
+                            None if (r is None or rel > 1e-8) else r.to_dict()))
             except _Stall:
                 res.append(("stall",))
             except Exception as e:                                         # noqa: BLE001
@@ -162,7 +163,7 @@ def main():
             print(it, "STALL (reference)", res[1][0], flush=True)
             continue
         if res[0][0] == res[1][0] == "ok":
-            same = res[0][2] == res[1][2] and close(res[0][1], res[1][1], rel)
+            same = res[0][2] == res[1][2] and close(res[0][1], res[1][1], rel) and res[0][3] == res[1][3]
         else:
             same = res[0] == res[1]
         print(it, "OK" if same else "DIFF", res[0][0], res[1][0], flush=True)

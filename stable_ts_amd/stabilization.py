@@ -223,6 +223,14 @@ def suppress_segment_silence(seg: dict, starts, ends, min_word_dur: float = 0.1,
         for i, w in enumerate(sel, 1):
             keep_end = (not (w["word"][-1] in APPEND_PUNCTUATIONS or i == len(sel))) if use_word_position else None
             _snap(w, starts, ends, min_word_dur, nonspeech_error, keep_end)
+        for w in words:                                      # WordTiming stores millisecond-rounded stamps (result.py:38-41)
+            w["start"], w["end"] = (round(w["start"], 3) if w["start"] else w["start"]), (round(w["end"], 3) if w["end"] else w["end"])
         seg["start"], seg["end"] = words[0]["start"], words[-1]["end"]
+        # the reference round-trips the dict through Segment(...).to_dict() here (original_whisper.py:684-695): with
+        # words present, text and tokens become views of the words (timestamp tokens drop out of ``tokens``)
+        seg["text"] = "".join(w["word"] for w in words)
+        if words[0].get("tokens"):
+            seg["tokens"] = [t for w in words for t in w["tokens"]]
     else:
         _snap(seg, starts, ends, min_word_dur, nonspeech_error, True)
+        seg["start"], seg["end"] = (round(seg["start"], 3) if seg["start"] else 0.0), (round(seg["end"], 3) if seg["end"] else 0.0)

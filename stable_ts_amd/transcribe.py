@@ -404,6 +404,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             if n_seg == 0:
                 return None
             if not item["skip"]:
+                tr.started = True
                 return item
             tr.seek += item.get("skip_samples", n_seg)
 
@@ -465,6 +466,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                 preds = list(pool.map(lambda g: nonspeech.predict(host_copy(g[1]), offset=g[0] / SAMPLE_RATE), group))
             items = [window_input(tr0, sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
             live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
+            tr0.started = tr0.started or bool(live)
             if lanes and len(live) >= len(lanes):
                 per = (len(live) + len(lanes) - 1) // len(lanes)
                 parts = [live[k * per:(k + 1) * per] for k in range(len(lanes))]
@@ -501,9 +503,13 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
 
     def finish(tr: _Track) -> WhisperResult:
         text = tokenizer.decode(tr.all_tokens[len(initial_prompt_tokens):])
-        result = WhisperResult(dict(text=text, segments=tr.all_segments, language=language), force_order=not word_timestamps)
-        if tr.nonspeech is not None and suppress_silence:
-            result.nonspeech_sections = tr.nonspeech.sections()
+        # the reference settles the language at the first window that is not skipped as silent (:527, detect_language());
+        # a recording without such a window yields language None
+        result = WhisperResult(dict(text=text, segments=tr.all_segments, language=language if tr.started else None,
+                                    time_scale=None), force_order=not word_timestamps)                    # :735-743
+        timings = tr.nonspeech.timings() if (tr.nonspeech is not None and suppress_silence) else None
+        if timings:
+            result.update_nonspeech_sections(*timings, overwrite=True)                            # :770-771
         if word_timestamps and regroup:
             from .regroup import regroup_default
             regroup_default(result, regroup)
@@ -519,10 +525,11 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
 
 class _Track:
     """State of one run of the reference's sequential window loop (seek, prompt history, segments, silence analysis)."""
-    __slots__ = ("loader", "nonspeech", "all_tokens", "all_segments", "prompt_reset_since", "seek", "offset")
+    __slots__ = ("loader", "nonspeech", "all_tokens", "all_segments", "prompt_reset_since", "seek", "offset", "started")
 
     def __init__(self, loader: AudioLoader, nonspeech, prompt_tokens: List[int], offset: int = 0):
         self.loader, self.nonspeech, self.all_tokens, self.offset = loader, nonspeech, prompt_tokens, offset
         self.all_segments: List[dict] = []
         self.prompt_reset_since = 0
         self.seek = 0
+        self.started = False

@@ -81,6 +81,7 @@ def test_transcribe_host_logic_matches_reference(models, monkeypatch, name):
     assert _snap(got) == _snap(want)
     assert len(want.segments) > 0 and len(_snap(want)) == len(want.segments)
     assert got.regroup_history == want.regroup_history
+    assert got.to_dict() == want.to_dict()              # the whole JSON form: ori_dict, ids, statistics, sections
     assert [(round(d["start"], 3), round(d["end"], 3)) for d in got.nonspeech_sections] == \
         [(round(d["start"], 3), round(d["end"], 3)) for d in want.nonspeech_sections]
 
@@ -160,7 +161,7 @@ def test_transcribe_edge_inputs_match_reference(models, monkeypatch, kind):
         want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **BASE)
         got = mine.transcribe(audio, language="en", **BASE)
     assert _snap(got) == _snap(want)
-    assert got.text == want.text
+    assert got.text == want.text and got.to_dict() == want.to_dict()
 
 
 def test_transcribe_audio_sources_agree(models, monkeypatch, tmp_path):
@@ -250,6 +251,8 @@ def test_head_selection_variants_match_reference(models, monkeypatch, name):
         for m in others:
             sw.modify_model(m)
         extra_ref, extra_mine = others, [CpuWhisper(m) for m in others]
+        for m in extra_mine:            # the reference encodes for the extra models inside disable_sdpa() (timing.py:58-60)
+            m.manual_attention_encoder = True
         if name.endswith("dynamic"):
             opts["dynamic_heads"] = "4,2"
     audio = G.synth_audio(41.0, seed=5)
@@ -259,6 +262,7 @@ def test_head_selection_variants_match_reference(models, monkeypatch, name):
         got = mine.transcribe(audio, language="en", extra_models=extra_mine, **opts)
         plain = mine.transcribe(audio, language="en", **BASE)
     assert _snap(got) == _snap(want) and len(want.segments) > 0
+    assert got.to_dict() == want.to_dict()
     assert _snap(got) != _snap(plain)                     # the variant really changes the word times
 
 
@@ -286,6 +290,7 @@ def test_transcribe_fuzz_regressions(models, monkeypatch, case):
         want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, **opts)
         got = mine.transcribe(audio, language="en", **opts)
     assert _snap(got) == _snap(want) and len(want.segments) > 0
+    assert got.to_dict() == want.to_dict()
 
 
 def test_transcribe_all_zero_audio_without_silence_suppression(models, monkeypatch):
