@@ -68,6 +68,7 @@ def test_transcribe_any_matches_reference(seed):
             assert _state(outs[0]) == _state(outs[1]), (name, kw)
             assert outs[0].regroup_history == outs[1].regroup_history
             assert outs[0].nonspeech_sections == outs[1].nonspeech_sections
+            assert outs[0].to_dict() == outs[1].to_dict()
             assert seen[ref_any] == seen[transcribe_any] == (torch.Tensor, name)
     # numpy in -> numpy out to the function; a result object is passed through; AudioLoader input warns and skips silence
     for fn, R, L in ((ref_any, RR.WhisperResult, None), (transcribe_any, WhisperResult, None)):
