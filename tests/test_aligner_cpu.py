@@ -272,6 +272,7 @@ def test_align_on_standin_matches_reference_align(monkeypatch, variant):
     snap = lambda r: [(w.word, w.start, w.end, round(float(w.probability), 9), list(w.tokens)) for w in r.all_words()]
     assert snap(got) == snap(want) and len(snap(want)) > 5
     assert [(s.start, s.end, s.text) for s in got.segments] == [(s.start, s.end, s.text) for s in want.segments]
+    assert got.to_dict() == want.to_dict()
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/stable_whisper"), reason="reference checkout not present")
@@ -306,6 +307,7 @@ def test_align_words_on_standin_matches_reference(monkeypatch, as_dicts, opts):
     snap = lambda r: [(w.word, w.start, w.end, round(float(w.probability), 9), list(w.tokens)) for w in r.all_words()]
     assert snap(got) == snap(want) and len(snap(want)) > 5
     assert [(s.start, s.end, s.text) for s in got.segments] == [(s.start, s.end, s.text) for s in want.segments]
+    assert got.to_dict() == want.to_dict()
     for fn, model, cls in ((ref.align_words, None, stable_whisper.WhisperResult), (A.align_words, mine, WhisperResult)):
         with pytest.raises(TypeError, match="unexpected keyword"):
             if model is None:
