@@ -193,3 +193,18 @@ def test_ctypes_table_matches_header_prototypes():
             assert res is ctypes.c_int, name
         checked += 1
     assert checked == len(_lib.SYMBOLS), (checked, len(_lib.SYMBOLS))
+
+
+def test_header_is_plain_c():
+    """include/swx.h is the drop-in boundary: it must parse as C (and C++) on its own, no torch / HIP types"""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "swx.h")
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    for lang, std in (("c", "-std=c11"), ("c++", "-std=c++17")):
+        r = subprocess.run(["gcc", "-fsyntax-only", "-x", lang, std, "-Wall", hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    text = open(hdr).read()
+    assert "torch" not in text.lower().replace("pytorch", "") and "hipStream_t" not in text.split("*/")[-1]
