@@ -11,6 +11,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+# tests named test_inner_* exercise device paths that have not run on hardware yet; they run in a child pytest process
+# (test_pending_device_paths_in_subprocess) so that a device fault there cannot take the validated tests down with it
+INNER = os.environ.get("SWX_INNER_TESTS") == "1"
 
 
 def _golden():
@@ -120,8 +123,8 @@ def test_refinement_func_matches_reference_seam_b3():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.xfail(strict=False, reason="span-parallel driver written after the round's GPU minutes ran out: first hardware run decides")
-def test_transcribe_spans_equals_sequential_per_span():
+@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
+def test_inner_transcribe_spans_equals_sequential_per_span():
     # transcribe_spans (the sequential algorithm on several spans in lockstep batches, spans.py) == model.transcribe on
     # each span separately: the property SURVEY.md 8e states for the span-sharded mode, through the C ABI, no oracle
     from stable_ts_amd.spans import plan_spans
@@ -150,9 +153,9 @@ def test_transcribe_spans_equals_sequential_per_span():
             assert abs(wa["start"] - wb["start"]) < 2e-3 and abs(wa["end"] - wb["end"]) < 2e-3
 
 
-@pytest.mark.xfail(strict=False, reason="head-selection variants written after the round's GPU minutes ran out: first hardware run decides")
+@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
 @pytest.mark.parametrize("name", ["tiny_en_dynamic_heads", "tiny_en_new_aligner"])
-def test_transcribe_variants_match_reference_glue(name):
+def test_inner_transcribe_variants_match_reference_glue(name):
     # dynamic heads / the 'new' aligner (timing.py:87-103, 115-163): the reference's transcribe on the oracle
     # (tests/golden/reference_variants.json) vs this package on the device, strict f32.  Same bar as the default path.
     with open(os.path.join(HERE, "golden", "reference_variants.json")) as f:
@@ -173,8 +176,8 @@ def test_transcribe_variants_match_reference_glue(name):
             assert abs(wa["probability"] - wb["probability"]) <= 1e-3 * max(wb["probability"], 1e-3) + 1e-9
 
 
-@pytest.mark.xfail(strict=False, reason="locate() on the device written after the round's GPU minutes ran out: first hardware run decides")
-def test_locate_matches_reference_glue():
+@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
+def test_inner_locate_matches_reference_glue():
     # the reference's locate (alignment.py:756-1116, modes 2 / 1 / 0) on the oracle model vs this package on the device
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
@@ -205,3 +208,16 @@ def test_locate_matches_reference_glue():
         text = kw.pop("text")
         got = mg.plain_locate(model.locate(audio, text, "en", verbose=None, **kw))
         close(got, want, str(kw))
+
+
+@pytest.mark.xfail(strict=False, reason="device paths written after the round's GPU minutes ran out: first hardware run decides")
+@pytest.mark.parametrize("inner", ["test_inner_transcribe_spans_equals_sequential_per_span",
+                                   "test_inner_transcribe_variants_match_reference_glue",
+                                   "test_inner_locate_matches_reference_glue"])
+def test_pending_device_paths_in_subprocess(inner):
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::{inner}", "-q", "-x", "-m", "gpu",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, SWX_INNER_TESTS="1"), cwd=os.path.dirname(HERE))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
