@@ -1,0 +1,77 @@
+"""The committed fixtures of the head-selection variants and of locate() (tests/golden/reference_variants.json: the
+reference's transcribe / locate run on the CPU oracle) against this package's HOST code on the oracle-backed stand-in.
+Runs without /root/reference: it ties the fixtures the pending GPU tests use to the host logic that produced CPU parity."""
+import contextlib
+import io
+import json
+import os
+import sys
+import warnings
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, HERE)
+
+
+@pytest.fixture(scope="module")
+def fixtures():
+    with open(os.path.join(HERE, "golden", "reference_variants.json")) as f:
+        return json.load(f)
+
+
+def _standin(case):
+    from oracle.whisper.model import build_model
+    from oracle_engine import CpuWhisper
+    return CpuWhisper(build_model(case["model"], seed=1234, std=0.02, embed_gain=case["gain"], ts_gain=case["ts_gain"]))
+
+
+@pytest.mark.parametrize("name", ["tiny_en_dynamic_heads", "tiny_en_new_aligner"])
+def test_variant_fixtures_match_host_code(fixtures, monkeypatch, name):
+    import make_golden as G
+    from oracle_engine import install
+    install(monkeypatch)
+    g = fixtures[name]
+    c = g["case"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = _standin(c).transcribe(G.synth_audio(c["seconds"], c["seed"]), language="en", regroup=False, word_timestamps=True, **c["opts"])
+    segs = res.to_dict()["segments"]
+    assert len(segs) == len(g["segments"]) > 0
+    for a, b in zip(segs, g["segments"]):
+        assert [(w["word"], w["start"], w["end"], w["tokens"]) for w in a["words"]] == \
+            [(w["word"], w["start"], w["end"], w["tokens"]) for w in b["words"]]
+        for wa, wb in zip(a["words"], b["words"]):
+            assert abs(wa["probability"] - wb["probability"]) <= 1e-6 * abs(wb["probability"]) + 1e-12
+
+
+def test_locate_fixtures_match_host_code(fixtures, monkeypatch):
+    import make_golden as G
+    import stable_ts_amd.locator as L
+    from oracle_engine import install
+    install(monkeypatch)
+    g = fixtures["locate_tiny_en"]
+    c = g["case"]
+    model = _standin(c)
+    audio = G.synth_audio(c["seconds"], c["seed"])
+    for kw, want in zip(g["calls"], g["results"]):
+        kw = dict(kw)
+        text = kw.pop("text")
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            got = G.plain_locate(L.locate(model, audio, text, "en", verbose=None, **kw))
+        assert len(got) == len(want) > 0
+
+        def strip(x):                       # probabilities to 1e-5 (incremental KV cache there, full re-computation here)
+            if isinstance(x, dict):
+                return {k: (round(v, 7) if k == "probability" else strip(v)) for k, v in x.items()}
+            if isinstance(x, list):
+                return [strip(v) for v in x]
+            return x
+        sg, sw_ = strip(got), strip(want)
+        if sg != sw_:
+            flat = lambda o: json.dumps(o, sort_keys=True)
+            # allow last-digit probability noise only
+            import re
+            assert re.sub(r'"probability": [0-9.e-]+', "", flat(sg)) == re.sub(r'"probability": [0-9.e-]+', "", flat(sw_))
