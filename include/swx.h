@@ -58,6 +58,12 @@ int swx_load_tensor(swx_model *m, const char *name, const float *d_src, int64_t 
 /* 1 if every slot has been loaded; swx_missing_tensor writes the index-th missing name into buf (returns 0 at the end) */
 int swx_weights_complete(const swx_model *m);
 int swx_missing_tensor(const swx_model *m, int index, char *buf, int buflen);
+/* the arena was filled from outside (rank 0's packed arena received over RCCL, parallel.py::broadcast_arena): mark every
+ * tensor as present.  swx_weights_finalize: load-time preparation that depends on the complete set of tensors (the
+ * LayerNorm-folded copies of the decoder projections the fused f16 decode step streams, csrc/swx_fold.hip); must be
+ * called once after the last swx_load_tensor / after swx_weights_mark_loaded, before swx_decode. */
+int swx_weights_mark_loaded(swx_model *m);
+int swx_weights_finalize(swx_model *m, void *stream);
 /* alignment heads (timing.py:105 reads model.alignment_heads.indices()): pairs (layer, head) */
 int swx_set_alignment_heads(swx_model *m, const int32_t *h_layer_head_pairs, int n_pairs);
 int swx_num_alignment_heads(const swx_model *m);
@@ -193,6 +199,13 @@ int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, cons
 int swx_test_gemm_splitk(const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
                          void *d_c, int64_t ldc, const float *d_ln_g, const float *d_ln_b, void *d_ln_out,
                          int M, int N, int K, int epilogue, void *stream);
+/* decode-step "dec" GEMM (csrc/swx_decstep.hip), f16: epilogue bits 1 = LayerNorm fold (gamma / beta given, A = raw rows, K = full
+ * row), 2 = GELU, 4 = residual update of d_x in place, 8 = QKV scatter (columns >= d go to the caches at pos0[m]), 16 = K-split
+ * allowed.  d_scratch: >= N*K*2 + 8N + slab bytes + 1 KiB. */
+int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float *d_gamma, const float *d_beta,
+                      const float *d_bias, void *d_c, int64_t ldc, void *d_x, void *d_kcache, void *d_vcache,
+                      const int32_t *d_pos0, int n_ctx, int d, int M, int N, int K, int epilogue, void *d_scratch,
+                      size_t scratch_bytes, void *stream);
 int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float *d_b, void *d_y, int rows, int d,
                        void *stream);
 /* vt_kp > 0: d_v is transposed per batch item, [H][64][vt_kp] (keys contiguous, zero padded) -- the cross-KV layout */

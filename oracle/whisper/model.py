@@ -260,7 +260,7 @@ def dims_for(name: str) -> ModelDimensions:
 
 
 def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02,
-                      embed_gain: float = 1.0, ts_gain: float = 1.0) -> Dict[str, Tensor]:
+                      embed_gain: float = 1.0, ts_gain: float = 1.0, ln_jitter: float = 0.0, xattn_gain: float = 1.0) -> Dict[str, Tensor]:
     """Deterministic random weights at the real architecture (no checkpoints exist offline).
 
     Linear / conv / embedding ~ N(0, std), biases ~ N(0, std), LN gamma=1 beta=0,
@@ -282,11 +282,23 @@ def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02
                 sd[k][dims.n_vocab - 1501:] *= ts_gain
         else:
             sd[k] = torch.randn(v.shape, generator=g) * std
+    if ln_jitter:
+        # non-trivial LayerNorm affine parameters (gamma = 1 + j*N(0,1), beta = j*N(0,1)) from a generator of their own, so
+        # that every other tensor is the same as without the jitter
+        g2 = torch.Generator().manual_seed(seed + 7919)
+        for k in sd:
+            if "_ln" in k or k.endswith("ln.weight") or k.endswith("ln.bias") or "ln_post" in k:
+                sd[k] = sd[k] + ln_jitter * torch.randn(sd[k].shape, generator=g2)
+    if xattn_gain != 1.0:   # sharper cross-attention (scores scaled by xattn_gain): word timing on peaky attention maps
+        for k in sd:
+            if ".cross_attn.query.weight" in k or ".cross_attn.key.weight" in k:
+                sd[k] = sd[k] * float(xattn_gain) ** 0.5
     return sd
 
 
-def build_model(name_or_dims, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0, ts_gain: float = 1.0) -> Whisper:
+def build_model(name_or_dims, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0, ts_gain: float = 1.0,
+                ln_jitter: float = 0.0, xattn_gain: float = 1.0) -> Whisper:
     dims = dims_for(name_or_dims) if isinstance(name_or_dims, str) else name_or_dims
     model = Whisper(dims)
-    model.load_state_dict(random_state_dict(dims, seed, std, embed_gain, ts_gain))
+    model.load_state_dict(random_state_dict(dims, seed, std, embed_gain, ts_gain, ln_jitter, xattn_gain))
     return model.eval()

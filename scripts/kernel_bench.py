@@ -19,16 +19,26 @@ EPI_BIAS, EPI_GELU, EPI_RES = 1, 2, 4
 
 
 def timed(fn, iters):
-    for _ in range(5):
-        fn()
+    """fn() or fn(i): i cycles so that a caller can rotate through operand copies (weights that must come from HBM: one copy
+    would sit in the 256 MB Infinity Cache after the first launch, which the decode step's 1.6 GB per step never does)"""
+    import inspect
+    takes_i = len(inspect.signature(fn).parameters) == 1
+    call = fn if takes_i else (lambda i: fn())
+    for i in range(5):
+        call(i)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
-    for _ in range(iters):
-        fn()
+    for i in range(iters):
+        call(i)
     b.record()
     torch.cuda.synchronize()
     return a.elapsed_time(b) * 1000.0 / iters      # us per launch
+
+
+def weight_copies(rnd, N, K, total_mb=600):
+    n = max(2, int(total_mb * 1e6 / (N * K * 2)) + 1)
+    return [rnd(N, K) for _ in range(n)]
 
 
 def main():
@@ -73,17 +83,41 @@ def main():
         us = timed(lambda: lib.swx_test_attention(1, p(q), H * 64, p(k), p(vt), H * 64, p(o), H * 64, B, H, nq, nk, 3, kp, st), args.iters)
         print(f"  {us:9.1f} us  {B * H * 64 * 2 * (2.0 * nk + 2.0 * nq) / us / 1e3:7.1f} GB/s algorithmic")
 
+    if args.only in ("", "dec"):
+        print(f"-- decode-step GEMMs, third generation (un-split dec kernels), M=100  SWX_DEC_POLICY={os.environ.get('SWX_DEC_POLICY')}")
+        M, d = 100, 1280
+        tot = 0.0
+        for name, N, K, epi in [("qkv (LN fold + scatter)", 3840, 1280, 1 | 8 | 32), ("attn-out (+x)", 1280, 1280, 4), ("cross-q (LN fold)", 1280, 1280, 1 | 32),
+                                ("cross-out (+x)", 1280, 1280, 4), ("mlp-1 (LN fold + GELU)", 5120, 1280, 1 | 2 | 32), ("mlp-2 (+x, K=4d)", 1280, 5120, 4 | 16)]:
+            a, ws = rnd(M, K), weight_copies(rnd, N, K)
+            c = torch.empty(M, N if not (epi & 8) else d, dtype=torch.half, device=dev)
+            x = rnd(M, N if not (epi & 8) else d)
+            c1, c2 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+            kc = torch.zeros(M, 448, d, dtype=torch.half, device=dev)
+            vc = torch.zeros(M, 448, d, dtype=torch.half, device=dev)
+            pos0 = torch.full((M,), 17, dtype=torch.int32, device=dev)
+            scratch = torch.empty(N * K * 2 + 8 * N + 16 * M * N * 4 + 8192, dtype=torch.uint8, device=dev)
+            ldc = d if (epi & 8) else N
+            fn = lambda i: lib.swx_test_dec_gemm(p(a), K, p(ws[i % len(ws)]), p(c1), p(c2), p(c2), p(c), ldc, p(x), p(kc), p(vc), p(pos0), 448, d,
+                                                 M, N, K, epi, p(scratch), scratch.numel(), st)
+            rc = fn(0)
+            assert rc == 0, rc
+            us = timed(fn, args.iters)
+            tot += us
+            print(f"  {name:26s} N={N:5d} K={K:5d}: {us:7.2f} us  {2.0 * (N * K + M * K + M * N) / us / 1e3:7.1f} GB/s algorithmic")
+        print(f"  sum of the six projections of one layer: {tot:.1f} us")
+
     if args.only in ("", "splitk"):
         print("-- decode-step GEMMs (split-K weight streaming + finish), M=100")
         M = 100
         for name, N, K, epi, ln in [("qkv", 3840, 1280, EPI_BIAS, False), ("attn-out + LN", 1280, 1280, EPI_BIAS | EPI_RES, True),
                                     ("cross-q", 1280, 1280, EPI_BIAS, False), ("mlp-1 (GELU)", 5120, 1280, EPI_BIAS | EPI_GELU, False),
                                     ("mlp-2 + LN", 1280, 5120, EPI_BIAS | EPI_RES, True)]:
-            a, w = rnd(M, K), rnd(N, K)
+            a, ws = rnd(M, K), weight_copies(rnd, N, K)
             bias, lg, lb = torch.zeros(N, device=dev), torch.ones(N, device=dev), torch.zeros(N, device=dev)
             c = torch.zeros(M, N, dtype=torch.half, device=dev)
             h = torch.empty(M, N, dtype=torch.half, device=dev) if ln else None
-            us = timed(lambda: lib.swx_test_gemm_splitk(p(a), K, p(w), p(bias), p(c) if epi & EPI_RES else None, p(c), N,
+            us = timed(lambda i: lib.swx_test_gemm_splitk(p(a), K, p(ws[i % len(ws)]), p(bias), p(c) if epi & EPI_RES else None, p(c), N,
                                                         p(lg) if ln else None, p(lb) if ln else None, p(h), M, N, K, epi, st), args.iters)
             print(f"  {name:14s} N={N:5d} K={K:5d}: {us:7.2f} us per GEMM+finish  {2.0 * (N * K + M * K + M * N) / us / 1e3:7.1f} GB/s algorithmic")
 

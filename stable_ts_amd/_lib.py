@@ -43,6 +43,8 @@ SYMBOLS = {
     "swx_load_tensor": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, c_void_p]),
     "swx_weights_complete": (c_int, [c_void_p]),
     "swx_missing_tensor": (c_int, [c_void_p, c_int, c_char_p, c_int]),
+    "swx_weights_mark_loaded": (c_int, [c_void_p]),
+    "swx_weights_finalize": (c_int, [c_void_p, c_void_p]),
     "swx_set_alignment_heads": (c_int, [c_void_p, POINTER(c_int32), c_int]),
     "swx_num_alignment_heads": (c_int, [c_void_p]),
     "swx_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
@@ -73,6 +75,9 @@ SYMBOLS = {
                               c_int, c_int, c_int, c_void_p]),
     "swx_test_gemm_splitk": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "swx_test_dec_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                  c_void_p]),
     "swx_test_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "swx_test_attention": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -502,6 +502,10 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
 // The dependent-load chain is 3 round trips instead of 5: {pos0} -> {ancestor ids, slabs} -> {K rows, V fragments} ->
 // math; the V fragments of the first 128 positions are requested together with the K rows (ancestor ids travel between
 // lanes by ds_bpermute).  Arithmetic order is the generic kernel's, so both paths agree bit for bit.
+// SLABS = true : q | k | v of the new token are finished here from the split-K partials (second-generation decode step)
+// SLABS = false: q is read from a.qkv (f16, row stride ldqkv) and the new token's K / V are ALREADY in the cache at position
+//                pos0[r] of row r (the QKV projection of the third-generation step scatters them in its epilogue)
+template <bool SLABS>
 __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
 {
     constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
@@ -513,13 +517,17 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     const int32_t *anc = a.anc ? a.anc + (size_t)r * a.n_ctx : nullptr;
     const f16 *kc = (const f16 *)a.kcache, *vc = (const f16 *)a.vcache;
     const int j0 = lane, j1 = lane + 64;
-    const bool has0 = j0 < pos, has1 = j1 < pos;           // strictly older positions live in the cache
+    // positions that live in the cache: strictly older ones, plus the new one itself when the projection already put it there
+    const bool has0 = SLABS ? j0 < pos : j0 <= pos, has1 = SLABS ? j1 < pos : j1 <= pos;
     // ancestor ids: clamped unconditional loads + select (a predicated load would cost its own round trip)
     const int32_t *ap = anc ? anc : a.pos0;
-    const int t0 = ap[(anc && has0) ? j0 : 0], t1 = ap[(anc && has1) ? j1 : 0];
-    const int pr0 = (anc && has0) ? t0 : r, pr1 = (anc && has1) ? t1 : r;
+    const bool old0 = j0 < pos, old1 = j1 < pos;           // the ancestor table covers the older positions; the new one is row r's own
+    const int t0 = ap[(anc && old0) ? j0 : 0], t1 = ap[(anc && old1) ? j1 : 0];
+    const int pr0 = (anc && old0) ? t0 : r, pr1 = (anc && old1) ? t1 : r;
     // ---- finish q | k | v of this head from the split-K partials
-    {
+    if constexpr (!SLABS) {
+        qs[lane] = (float)((const f16 *)a.qkv)[(size_t)r * a.ldqkv + h * DH + lane];
+    } else {
         const SlabRef sr = a.qkvs;
         const float *sp = sr.slabs + (size_t)r * sr.N + h * DH + lane;
         // all 3 x ks2 partial loads in flight before the first add (see attn_decode_cross_f16)
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
         const f16 *kr0 = kc + ((size_t)(has0 ? pr0 : r) * a.n_ctx + (has0 ? j0 : 0)) * d + h * DH;   // clamped, never predicated
 #pragma unroll
         for (int e = 0; e < 8; ++e) k0[e] = *(const f16x8 *)(kr0 + 8 * e);
-        if (pos > 64) {
+        if (SLABS ? pos > 64 : pos >= 64) {
             const f16 *kr1 = kc + ((size_t)(has1 ? pr1 : r) * a.n_ctx + (has1 ? j1 : 0)) * d + h * DH;
 #pragma unroll
             for (int e = 0; e < 8; ++e) k1[e] = *(const f16x8 *)(kr1 + 8 * e);
@@ -556,12 +564,12 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     f16x8 vpre[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-        if (i * 8 < pos) {                                  // uniform: some key of this group of 8 is in the cache
+        if (SLABS ? i * 8 < pos : i * 8 <= pos) {           // uniform: some key of this group of 8 is in the cache
             const int j = kg + 8 * i;
             const int src = j & 63;
             const int pa = __shfl(pr0, src, 64), pb = __shfl(pr1, src, 64);
-            const int prj = j < 64 ? pa : pb;
-            const bool ok = j < pos;
+            const int prj = j < 64 ? pa : pb;                       // (pr0 / pr1 are r for the new position)
+            const bool ok = SLABS ? j < pos : j <= pos;
             vpre[i] = *(const f16x8 *)(vc + ((size_t)(ok ? prj : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
         }
     }
@@ -591,8 +599,8 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     }
     for (int j = lane + 128; j <= pos; j += 64) {
         float acc;
-        if (j < pos) {
-            const int pr = anc ? anc[j] : r;
+        if (!SLABS || j < pos) {
+            const int pr = (anc && j < pos) ? anc[j] : r;
             const f16 *kr = kc + ((size_t)pr * a.n_ctx + j) * d + h * DH;
             acc = 0.f;
 #pragma unroll 2
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
         const int j = kg + 8 * i;
         if (i * 8 <= pos && j <= pos) {
             float vv[8];
-            if (j < pos) {
+            if (!SLABS || j < pos) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) vv[e] = (float)vpre[i][e];
             } else {
@@ -637,8 +645,8 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     }
     for (int j = kg + 8 * PF; j <= pos; j += 8) {
         float vv[8];
-        if (j < pos) {
-            const int pr = anc ? anc[j] : r;
+        if (!SLABS || j < pos) {
+            const int pr = (anc && j < pos) ? anc[j] : r;
             load8<f16>(vc + ((size_t)pr * a.n_ctx + j) * d + h * DH + dc, vv);
         } else {
 #pragma unroll
@@ -737,7 +745,13 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
     if (a.qkvs.slabs) {
         if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.qkvs.bias || a.qkvs.N != 3 * a.d || a.qkvs.ks2 < 1 ||
             a.qkvs.ks2 > SLAB_KMAX) return -5;
-        hipLaunchKernelGGL(self_attn_fused_f16, dim3(a.H, a.R), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(self_attn_fused_f16<true>, dim3(a.H, a.R), dim3(64), 0, s, a);
+        SWX_CHECK_LAUNCH();
+        return 0;
+    }
+    if (a.step_cached) {       // single-token step, q in a.qkv, the new K / V already in the cache
+        if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.skip_append) return -5;
+        hipLaunchKernelGGL(self_attn_fused_f16<false>, dim3(a.H, a.R), dim3(64), 0, s, a);
         SWX_CHECK_LAUNCH();
         return 0;
     }

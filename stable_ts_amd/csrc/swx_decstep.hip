@@ -1,0 +1,345 @@
+// swx_decstep.hip -- the weight-streaming GEMM of the fused f16 decoder step, third generation ("dec" kernels).
+//
+// One decoder step multiplies M <= ~128 live sequences (windows x beams) with every decoder weight once: HBM-bound
+// weight streaming (1.60 GB fp16 per step for large-v3), reached from stable_whisper/decode.py:40
+// (`inference.logits` -> upstream TextDecoder.forward with the KV-cache hooks).
+//
+// What round 1's profile said about the split-K generation (swx_gemm.hip::gemm_f16_pg + splitk_finish_f16): 8.3 us per
+// launch for 3-13 MB of weights (0.13 of HBM peak), as much HBM traffic for the f32 partial slabs as for the weights
+// (2.05x the algorithmic bytes), and a finish launch per projection (another 8 us) only to reduce the slabs and apply
+// the next LayerNorm.  This generation removes the slabs and the finish launches:
+//   * split M, not K.  A workgroup owns 64 output columns (16 per wave) x MT*16 rows x the WHOLE reduction (or a
+//     >= 640-deep slice of it for the one projection with K = 4d), so it finishes its outputs itself: bias / GELU /
+//     residual add / K,V-cache scatter happen in the epilogue and the compute dtype is stored directly.  The row groups of
+//     one column panel run on the SAME XCD (block id -> XCD is id % 8 in hardware; the mapping below is built on it for
+//     speed only), so the panel's weights leave HBM once and the other row groups hit them in that XCD's L2.
+//   * LayerNorm folded into the consumer:  LN(x) W^T + b  =  rstd * (x (W.gamma)^T - mean * c1) + c2  with
+//     c1[n] = sum_k (W.gamma)[n][k],  c2[n] = b[n] + sum_k beta[k] W[n][k]  prepared once at load time
+//     (swx_weights_finalize).  The GEMM runs on the RAW residual stream; a workgroup holds complete rows of it
+//     (K = d, un-split), computes mean / rstd of its rows from its own LDS tile and applies them in the epilogue.  No
+//     LayerNorm launch, no normalised copy of the activations in HBM.
+//   * one-shot operand staging.  The activation tile [MT*16][kslice] goes global -> LDS by LDS-DMA (`global_load_lds`,
+//     16 B per lane, no VGPRs) in ONE batch issued at kernel entry together with every weight fragment of the wave
+//     (<= 40 x 1 KB in flight per wave): one memory round trip per launch instead of one per 64-deep chunk.  The LDS
+//     image is XOR-swizzled on the SOURCE address (the DMA destination is lane-linear) so that the 16 rows of an MFMA
+//     operand fragment fall on 16 different 16-byte bank columns.
+//   * the MFMA operands are swapped (weights = A operand, activations = B operand): a lane's 4 accumulator registers are
+//     4 CONSECUTIVE output columns of one row, so every store of the epilogue is 8 (f16) or 16 (f32) contiguous bytes.
+#include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include "swx_common.h"
+#include "swx_kernels.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int DEC_MAXMT = 3;
+
+template <int MT, int NKS>          // NKS = K-slice depth / 32, fixed at compile time: every loop below unrolls without branches
+__global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [MT*16][kslice] f16 | float2 stat[MT*16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    // ---- block id -> (column panel, K slice, row group): all row groups of one (panel, slice) unit share an XCD
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int unit = (slot / g.n_rg) * 8 + xcd, rg = slot % g.n_rg;
+    const int panels = (g.N + 63) >> 6;
+    if (unit >= panels * g.ks2) return;
+    const int panel = unit / g.ks2, ks_id = unit - panel * g.ks2;
+    constexpr int kslice = NKS * 32;             // MFMA k-steps of 32
+    constexpr int SPR = kslice >> 3;             // 16-byte slots per LDS row (a multiple of 16)
+    constexpr int RS = kslice * 2;               // LDS row stride in bytes
+    const int k0 = ks_id * kslice;
+    const int r0 = rg * (MT * 16);
+
+    // ---- weights of this wave's 16 columns: every fragment of the slice in flight at once (HBM, or L2 behind a sibling)
+    const int ncol = panel * 64 + wave * 16 + li;
+    const f16 *wp = g.W + (size_t)(ncol < g.N ? ncol : g.N - 1) * g.ldw + k0 + lg * 8;
+    f16x8 wf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wf[ks] = *(const f16x8 *)(wp + ks * 32);
+
+    // ---- activation tile -> LDS by LDS-DMA; instruction q writes LDS bytes [q*1024, q*1024 + 1024)
+    {
+        constexpr int n_instr = (MT * 16 * SPR) >> 6;      // = MT * NKS, a multiple of 4
+#pragma unroll
+        for (int j = 0; j < n_instr / 4; ++j) {
+            const int q = j * 4 + wave;
+            const int p = q * 64 + lane;                    // 16-byte slot index of this lane's destination
+            const int row = p / SPR, ps = p - row * SPR;
+            const int kslot = ps ^ (row & 15);              // logical slot that must land there (swizzle on the source)
+            const int gr = r0 + row < g.M ? r0 + row : g.M - 1;
+            const f16 *src = g.A + (size_t)gr * g.lda + k0 + kslot * 8;
+            __builtin_amdgcn_global_load_lds(src, (lds_void *)(smem + q * 1024), 16, 0, 0);
+        }
+    }
+    __syncthreads();          // drains the DMA (and the weight loads): one round trip per launch
+
+    // ---- LayerNorm statistics of the tile's rows (complete rows: K == kslice == d), 16 lanes per row
+    float2 *stat = (float2 *)(smem + (size_t)MT * 16 * RS);
+    if (g.epi & DEC_LN) {
+        const f16x2 one2 = {(f16)1.f, (f16)1.f};
+        for (int rb = wave * 4 + lg; rb < MT * 16; rb += 16) {
+            const unsigned char *rp = smem + (size_t)rb * RS + li * 16;
+            f16x8 v[SPR / 16];                      // the row's share of this lane: every read in flight before the first add
+#pragma unroll
+            for (int i = 0; i < SPR / 16; ++i) v[i] = *(const f16x8 *)(rp + i * 256);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < SPR / 16; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f16x2 pr = {v[i][2 * e], v[i][2 * e + 1]};
+                    s1 = __builtin_amdgcn_fdot2(pr, one2, s1, false);
+                    s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
+                }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (li == 0) {
+                const float inv = 1.0f / (float)kslice;
+                const float mean = s1 * inv;
+                float var = s2 * inv - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                stat[rb] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+            }
+        }
+    }
+
+    // ---- MFMA: D[i = column][j = row] += W-fragment . A-fragment^T ; the activation fragments of the next PF k-steps are
+    //      requested from LDS before the current step's MFMAs (the compiler does not hoist them by itself: measured in the
+    //      ISA as read -> wait -> mfma per step, i.e. one exposed LDS latency per k-step)
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned char *abase = smem + (size_t)li * RS;
+    constexpr int PF = 4;
+    f16x8 af[PF][MT];
+    auto lds_frag = [&](int ks, int t) {
+        const int phys = (ks * 4 + lg) ^ li;
+        return *(const f16x8 *)(abase + (size_t)t * 16 * RS + phys * 16);
+    };
+#pragma unroll
+    for (int ks = 0; ks < PF; ++ks)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) af[ks][t] = lds_frag(ks, t);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[ks % PF][t], acc[t], 0, 0, 0);
+            if (ks + PF < NKS) af[ks % PF][t] = lds_frag(ks + PF, t);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // keeps the prefetch PF steps ahead (the scheduler sinks it back otherwise)
+    }
+    if (g.epi & DEC_LN) __syncthreads();          // stat[] visible to every wave
+
+    // ---- epilogue: lane holds columns n .. n+3 of row m for every tile
+    const int n = panel * 64 + wave * 16 + lg * 4;
+    if (n >= g.N) return;                          // N % 4 == 0 is checked by the launcher
+    if (g.epi & DEC_SLAB) {
+        float *out = g.slabs + (size_t)ks_id * g.slab_stride;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = r0 + t * 16 + li;
+            if (m < g.M) *(f32x4 *)(out + (size_t)m * g.N + n) = acc[t];
+        }
+        return;
+    }
+    const f32x4 c2 = *(const f32x4 *)(g.c2 + n);
+    f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (g.epi & DEC_LN) c1 = *(const f32x4 *)(g.c1 + n);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int m = r0 + t * 16 + li;
+        if (m >= g.M) continue;
+        f32x4 v = acc[t];
+        if (g.epi & DEC_LN) {
+            const float2 st = stat[t * 16 + li];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = st.y * (v[e] - st.x * c1[e]) + c2[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += c2[e];
+        }
+        if (g.epi & DEC_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        f16 *dst;
+        if (g.epi & DEC_RES) {
+            dst = g.X + (size_t)m * g.ldx + n;
+            const f16x4 xv = *(const f16x4 *)dst;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)xv[e];
+        } else if ((g.epi & DEC_QKV) && n >= g.d) {
+            const int pos = g.pos0[m];
+            f16 *cache = n < 2 * g.d ? g.kcache : g.vcache;
+            dst = cache + ((size_t)m * g.n_ctx + pos) * g.d + (n < 2 * g.d ? n - g.d : n - 2 * g.d);
+        } else {
+            dst = g.C + (size_t)m * g.ldc + n;
+        }
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+        *(f16x4 *)dst = o;
+    }
+}
+
+// x[m][n] = f16(x + bias[n] + sum_k slab[k][m][n]) : the reduction of the one projection that stays K-split (K = 4d)
+template <int KS>
+__global__ __launch_bounds__(256) void dec_slab_finish(const float *__restrict__ slabs, int64_t stride, int ks2, const float *__restrict__ bias,
+                                                       f16 *__restrict__ X, int64_t ldx, int M, int N)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N >> 2;
+    if (idx >= M * n4) return;
+    const int m = idx / n4, n = (idx - m * n4) * 4;
+    const float *sp = slabs + (size_t)m * N + n;
+    f32x4 part[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) part[k] = *(const f32x4 *)(sp + (size_t)(k < ks2 ? k : ks2 - 1) * stride);   // all in flight
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k) if (k < ks2) a += part[k];
+    a += *(const f32x4 *)(bias + n);
+    f16 *xp = X + (size_t)m * ldx + n;
+    const f16x4 xv = *(const f16x4 *)xp;
+    f16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] + (float)xv[e]);
+    *(f16x4 *)xp = o;
+}
+
+// load time: Wf[n][k] = f16(W[n][k] * gamma[k]);  c1[n] = sum_k Wf[n][k];  c2[n] = bias[n] + sum_k beta[k] * W[n][k]
+__global__ __launch_bounds__(256) void fold_ln_kernel(const f16 *__restrict__ W, const float *__restrict__ gamma,
+                                                      const float *__restrict__ beta, const float *__restrict__ bias,
+                                                      f16 *__restrict__ Wf, float *__restrict__ c1, float *__restrict__ c2, int K)
+{
+    __shared__ float sh[2][4];
+    const int n = blockIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = (float)W[(size_t)n * K + k];
+        const f16 wf = (f16)(w * gamma[k]);
+        Wf[(size_t)n * K + k] = wf;
+        s1 += (float)wf;
+        s2 += beta[k] * w;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c1[n] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        c2[n] = (bias ? bias[n] : 0.f) + ((sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]));
+    }
+}
+
+// SWX_DEC_POLICY="NxK=MT:ks2,NxK=MT:ks2,..." pins the tiling of given shapes (experiments)
+bool dec_policy(int N, int K, int *mt, int *ks2)
+{
+    static const char *env = getenv("SWX_DEC_POLICY");
+    const char *e = env;
+    while (e && *e) {
+        int n = 0, k = 0, a = 0, c = 0, used = 0;
+        if (sscanf(e, "%dx%d=%d:%d%n", &n, &k, &a, &c, &used) == 4 && used > 0) {
+            if (n == N && k == K) { *mt = a; *ks2 = c; return true; }
+            e += used;
+        } else break;
+        if (*e == ',') ++e;
+    }
+    return false;
+}
+
+}  // namespace
+
+int swx_dec_plan(int M, int N, int K, int epi, int *mt_out, int *ks2_out)
+{
+    if (M <= 0 || N <= 0 || N % 64 != 0 || K % 128 != 0) return -4;
+    // K slice: un-split when it fits one tile row (<= 1280 deep), else the fewest slices of <= 1280 that are a multiple of 128
+    int ks2 = 1;
+    auto depth_ok = [](int ks) { return ks == 384 || ks == 512 || ks == 640 || ks == 768 || ks == 1024 || ks == 1280; };
+    while (K % ks2 != 0 || !depth_ok(K / ks2)) { if (++ks2 > 64) return -4; }
+    if ((epi & DEC_LN) && ks2 != 1) return -4;       // the statistics need complete rows
+    if (ks2 > 1 && !(epi & DEC_SLAB)) return -4;
+    const int kslice = K / ks2;
+    const int panels = N / 64;
+    // rows per workgroup: the smallest MT whose grid fits one round of 256 workgroups, within 120 KB of LDS
+    int mt = 1;
+    while (mt < DEC_MAXMT && (int64_t)(mt + 1) * 16 * kslice * 2 <= 122880 && panels * ks2 * cdiv(M, mt * 16) > 256) ++mt;
+    int pm = 0, pk = 0;
+    if (dec_policy(N, K, &pm, &pk) && pm >= 1 && pm <= DEC_MAXMT && pk >= 1 && K % pk == 0 && depth_ok(K / pk) &&
+        (int64_t)pm * 16 * (K / pk) * 2 <= 122880 && (pk == 1 || (epi & DEC_SLAB))) { mt = pm; ks2 = pk; }
+    *mt_out = mt; *ks2_out = ks2;
+    return 0;
+}
+
+size_t swx_dec_slab_floats(int M, int N, int K)
+{
+    int mt, ks2;
+    if (swx_dec_plan(M, N, K, DEC_SLAB, &mt, &ks2) < 0) return 0;
+    return ks2 > 1 ? (size_t)ks2 * M * N : 0;
+}
+
+int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
+{
+    if (g.M <= 0 || g.N <= 0) return 0;
+    if (g.lda % 8 != 0 || g.ldw % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return -4;
+    int mt = 1, ks2 = 1;
+    { const int rc = swx_dec_plan(g.M, g.N, g.K, g.epi, &mt, &ks2); if (rc < 0) return rc; }
+    if (ks2 > 1 && !g.slabs) return -4;
+    if (ks2 == 1 && (g.epi & DEC_SLAB)) g.epi &= ~DEC_SLAB;      // un-split after all: the kernel finishes the output itself
+    g.ks2 = ks2; g.kslice = g.K / ks2; g.n_rg = cdiv(g.M, mt * 16);
+    g.slab_stride = (int64_t)g.M * g.N;
+    const int nks = g.kslice / 32;
+    const int units = (g.N / 64) * ks2;
+    const int grid = cdiv(units, 8) * g.n_rg * 8;
+    const size_t lds = (size_t)mt * 16 * g.kslice * 2 + (size_t)mt * 16 * sizeof(float2);
+    SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
+#define SWX_DEC(MT_, NK_) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { \
+            hipError_t e_ = hipFuncSetAttribute((const void *)gemm_dec_f16<MT_, NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            if (e_ != hipSuccess) return -100 - (int)e_; \
+            attr_done = true; \
+        } \
+        hipLaunchKernelGGL((gemm_dec_f16<MT_, NK_>), dim3(grid), dim3(256), lds, s, g); } while (0)
+#define SWX_DEC_MT(NK_) do { if (mt == 1) SWX_DEC(1, NK_); else if (mt == 2) SWX_DEC(2, NK_); else SWX_DEC(3, NK_); } while (0)
+    switch (nks) {          // K-slice depths of the Whisper sizes: d = 384 / 512 / 768 / 1024 / 1280 and the halves of 4d that fit
+        case 12: SWX_DEC_MT(12); break;
+        case 16: SWX_DEC_MT(16); break;
+        case 20: SWX_DEC_MT(20); break;
+        case 24: SWX_DEC_MT(24); break;
+        case 32: SWX_DEC_MT(32); break;
+        case 40: SWX_DEC_MT(40); break;
+        default: return -4;
+    }
+#undef SWX_DEC_MT
+#undef SWX_DEC
+    SWX_CHECK_LAUNCH();
+    if (ks2 > 1) {
+        // the one K-split projection: x += bias + sum of slabs
+        if (!(g.epi & DEC_RES) || !g.X) return -4;
+        SwxProfScope prof2(PC_NORM, (double)ks2 * g.M * g.N * 4 + 4.0 * g.M * g.N, s);
+        const int blocks = cdiv((int64_t)g.M * (g.N / 4), 256);
+        if (ks2 <= 4) hipLaunchKernelGGL(dec_slab_finish<4>, dim3(blocks), dim3(256), 0, s, g.slabs, g.slab_stride, ks2, g.c2, g.X, g.ldx, g.M, g.N);
+        else if (ks2 <= 8) hipLaunchKernelGGL(dec_slab_finish<8>, dim3(blocks), dim3(256), 0, s, g.slabs, g.slab_stride, ks2, g.c2, g.X, g.ldx, g.M, g.N);
+        else if (ks2 <= 16) hipLaunchKernelGGL(dec_slab_finish<16>, dim3(blocks), dim3(256), 0, s, g.slabs, g.slab_stride, ks2, g.c2, g.X, g.ldx, g.M, g.N);
+        else return -4;
+        SWX_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+int swx_fold_ln(const void *W, const float *gamma, const float *beta, const float *bias, void *Wf, float *c1, float *c2,
+                int N, int K, hipStream_t s)
+{
+    if (N <= 0 || K <= 0) return 0;
+    hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, (const f16 *)W, gamma, beta, bias, (f16 *)Wf, c1, c2, K);
+    SWX_CHECK_LAUNCH();
+    return 0;
+}

@@ -35,8 +35,10 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_FUSE_SELF 16       // self-attention finishes q|k|v from the split-K slabs, appends K/V and attends in one launch
 #define SWX_FLAG_FUSE_CROSS_Q 64    // cross-attention finishes q from the split-K slabs (no finish launch for the query projection)
 #define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
+#define SWX_FLAG_DEC_V3 512        // decode step on the un-split "dec" GEMMs (swx_decstep.hip) when the batch has enough rows
+#define SWX_FLAG_DEC_V3_FORCE 1024 // ... for every row count (tests)
 #define SWX_FLAG_GLDS_GEMM 256     // tiled f16 GEMM (encoder, cross-KV, scoring): direct-to-LDS operand staging (global_load_lds)
-#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q)
+#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q | SWX_FLAG_DEC_V3)
 int swx_flags();
 
 // split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:
@@ -60,6 +62,33 @@ int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ld
 int swx_pg_splits(int N, int K);     // the ks2 swx_gemm_pg will use for this shape (0 = shape not supported)
 int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
                 hipStream_t s);
+
+// ---- decode-step GEMM, third generation (swx_decstep.hip): M split over workgroups, K whole -> the kernel finishes its own
+//      outputs (no f32 slabs, no finish launch), LayerNorm folded into the consumer (statistics from the staged tile)
+#define DEC_LN 1        // out = rstd[m] * (acc - mean[m] * c1[n]) + c2[n]   (A = raw residual stream, W = gamma-folded weights)
+#define DEC_GELU 2
+#define DEC_RES 4       // X[m][n] = f16(X + c2[n] + acc)   (in place)
+#define DEC_QKV 8       // columns [0,d) -> C, [d,2d) -> kcache[m][pos0[m]], [2d,3d) -> vcache[m][pos0[m]]
+#define DEC_SLAB 16     // K-split allowed: f32 partials to slabs + dec_slab_finish (needs DEC_RES)
+struct DecGemmArgs {
+    const _Float16 *A; int64_t lda;      // [M][K]
+    const _Float16 *W; int64_t ldw;      // [N][K]
+    int M, N, K;
+    int epi;
+    const float *c2;                     // [N] bias (or folded bias with DEC_LN)
+    const float *c1;                     // [N] column sums of the folded weights (DEC_LN)
+    _Float16 *C; int64_t ldc;
+    _Float16 *X; int64_t ldx;
+    float *slabs;                        // swx_dec_slab_floats(M, N, K) floats when the shape runs K-split
+    _Float16 *kcache, *vcache; const int32_t *pos0; int n_ctx, d;
+    int ks2, kslice, n_rg; int64_t slab_stride;   // filled by the launcher
+};
+int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation
+size_t swx_dec_slab_floats(int M, int N, int K);
+int swx_gemm_dec(DecGemmArgs g, hipStream_t s);
+// load-time LayerNorm fold: Wf = f16(W * gamma), c1[n] = sum_k Wf[n][k], c2[n] = bias[n] + sum_k beta[k] W[n][k]
+int swx_fold_ln(const void *W, const float *gamma, const float *beta, const float *bias, void *Wf, float *c1, float *c2,
+                int N, int K, hipStream_t s);
 
 // ---- in-library kernel timing (HIP events on the launch stream), used by bench.py for the roofline object
 enum SwxProfClass { PC_GEMM_TILED = 0, PC_GEMM_SKINNY = 1, PC_ATTN_FLASH = 2, PC_ATTN_ROWWISE = 3, PC_SELF_ATTN = 4,
@@ -111,6 +140,8 @@ struct SelfAttnArgs {
     void *o; int64_t ldo;            // [R*n_new][d]
     int R, n_new, H, n_ctx, d;
     int skip_append;                 // K/V of the new token were already scattered into the cache (split-K finish kernel)
+    int step_cached;                 // n_new == 1, f16: q at a.qkv (row stride ldqkv), the new K/V already appended -> the
+                                     // latency-optimised single-token kernel (third-generation decode step)
     SlabRef qkvs;                    // qkvs.slabs != null (n_new == 1, f16): q|k|v of the new token come from the split-K slabs;
                                      // the kernel finishes them, appends k/v to the cache and attends in ONE launch
 };

@@ -28,6 +28,8 @@ struct LayerW {
     size_t ln1_g, ln1_b, wqkv, bqkv, wo, bo;
     size_t lnx_g, lnx_b, wcq, bcq, wckv, bckv, wco, bco;   // decoder only
     size_t ln2_g, ln2_b, w1, b1, w2, b2;
+    // decoder, f16: LayerNorm-folded copies for the third-generation decode step (swx_decstep.hip): W.gamma, c1, c2
+    size_t wqkv_f, qkv_c1, qkv_c2, wcq_f, cq_c1, cq_c2, w1_f, w1_c1, w1_c2;
 };
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -46,6 +48,8 @@ struct swx_model {
     size_t o_hann, o_twiddle, o_filters, o_heads, o_zeros;
     size_t arena_bytes = 0;
     unsigned char *arena = nullptr;
+    bool has_fold = false;          // the layout holds the folded copies (f16, d % 128 == 0)
+    bool folded = false;            // ... and swx_weights_finalize has filled them
     // alignment heads
     std::vector<std::vector<int>> heads_by_layer;   // per decoder layer
     std::vector<int> head_slot0;                    // first capture slot of each layer
@@ -143,6 +147,17 @@ void build_layout(swx_model *m)
     m->o_tok_emb = mat("decoder.token_embedding.weight", D.n_vocab, dt);
     m->o_dec_pos = add_slot(m, cur, "decoder.positional_embedding", SK_VEC, 1, (int64_t)D.n_text_ctx * dt, 0, (size_t)D.n_text_ctx * dt * 4);
     for (int l = 0; l < D.n_text_layer; ++l) m->dec.push_back(block("decoder.blocks." + std::to_string(l) + ".", dt, true));
+    {
+        int mt = 0, ks = 0;
+        m->has_fold = m->dtype == SWX_F16 && swx_dec_plan(64, 3 * dt, dt, DEC_LN, &mt, &ks) == 0 &&
+                      swx_dec_plan(64, dt, 4 * dt, DEC_RES | DEC_SLAB, &mt, &ks) == 0;
+        if (m->has_fold)
+            for (auto &w : m->dec) {
+                w.wqkv_f = reserve((size_t)3 * dt * dt * e); w.qkv_c1 = reserve((size_t)3 * dt * 4); w.qkv_c2 = reserve((size_t)3 * dt * 4);
+                w.wcq_f = reserve((size_t)dt * dt * e); w.cq_c1 = reserve((size_t)dt * 4); w.cq_c2 = reserve((size_t)dt * 4);
+                w.w1_f = reserve((size_t)4 * dt * dt * e); w.w1_c1 = reserve((size_t)4 * dt * 4); w.w1_c2 = reserve((size_t)4 * dt * 4);
+            }
+    }
     m->o_ln_g = vec("decoder.ln.weight", dt);
     m->o_ln_b = vec("decoder.ln.bias", dt);
     // constants
@@ -239,6 +254,8 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
         size_t mx = 0;
         const int shapes[4][2] = {{3 * dt, dt}, {dt, dt}, {4 * dt, dt}, {dt, 4 * dt}};
         for (auto &sh : shapes) { const size_t f = swx_skinny_slab_floats(128, sh[0], sh[1]); if (f > mx) mx = f; }
+        const size_t f3 = swx_dec_slab_floats(Mmax > 128 ? Mmax : 128, dt, 4 * dt);     // the K = 4d projection of the "dec" step
+        if (f3 > mx) mx = f3;
         L.slabs = take(mx * 4 + 256);
     }
     // the alignment-head list lives with the workspace, not with the weights: views that share one weight arena
@@ -379,8 +396,75 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
     return 1;   // h holds the final LayerNorm of x
 }
 
+// One decoder step (n_new == 1), third generation: un-split "dec" GEMMs (swx_decstep.hip) that finish their own outputs.
+// 8 launches per layer (QKV+scatter, self-attention, out-proj+residual, cross-q, cross-attention, out-proj+residual, MLP-in+GELU,
+// MLP-out [+ its slab reduction]) instead of 12; no LayerNorm launch, no f32 slabs except for the K = 4d projection.
+// Leaves the RAW residual stream in `x` (returns 0: the caller applies the final LayerNorm).
+int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
+{
+    const swx_dims &D = m->dims;
+    const int d = D.n_text_state, H = D.n_text_head;
+    const size_t e = m->esz;
+    const int rows = f.W * f.rpw;
+    f16 *x = m->Wp<f16>(m->L.x), *q = m->Wp<f16>(m->L.qkv), *att = m->Wp<f16>(m->L.att), *u = m->Wp<f16>(m->L.u);
+    float *slabs = m->Wp<float>(m->L.slabs);
+    SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, rows, 1, m->arena + m->o_tok_emb,
+                      m->A<float>(m->o_dec_pos), d, x, s));
+    const int64_t chunk = xkv_chunk_elems(D);
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const LayerW &w = m->dec[l];
+        f16 *kc = (f16 *)(f.kcache + (size_t)l * f.layer_stride), *vc = (f16 *)(f.vcache + (size_t)l * f.layer_stride);
+        DecGemmArgs g{};
+        g.M = rows;
+        // q | k | v = LN1(x) Wqkv^T + b : q -> the q buffer, k / v -> the cache at each row's position
+        g.A = x; g.lda = d; g.W = m->A<f16>(w.wqkv_f); g.ldw = d; g.N = 3 * d; g.K = d; g.epi = DEC_LN | DEC_QKV;
+        g.c1 = m->A<float>(w.qkv_c1); g.c2 = m->A<float>(w.qkv_c2); g.C = q; g.ldc = d;
+        g.kcache = kc; g.vcache = vc; g.pos0 = f.pos0; g.n_ctx = D.n_text_ctx; g.d = d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        SelfAttnArgs sa{};
+        sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
+        sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1; sa.step_cached = 1;
+        SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
+        // x += att Wo^T + bo
+        g = DecGemmArgs{};
+        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        // cross-attention query = LNx(x) Wcq^T + b
+        g = DecGemmArgs{};
+        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
+        g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
+        AttnArgs ca{};
+        ca.q = q; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
+        ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
+        ca.B = f.W; ca.H = H; ca.nq = f.rpw; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw;
+        SWX_TRY(swx_attention(m->dtype, ca, 0, s));
+        g = DecGemmArgs{};
+        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.c2 = m->A<float>(w.bco); g.X = x; g.ldx = d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        // MLP
+        g = DecGemmArgs{};
+        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.w1_f); g.ldw = d; g.N = 4 * d; g.K = d; g.epi = DEC_LN | DEC_GELU;
+        g.c1 = m->A<float>(w.w1_c1); g.c2 = m->A<float>(w.w1_c2); g.C = u; g.ldc = 4 * d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        g = DecGemmArgs{};
+        g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
+        g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
+        SWX_TRY(swx_gemm_dec(g, s));
+    }
+    return 0;
+}
+
 int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
+    if (m->dtype == SWX_F16 && m->folded && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.rpw <= 16 && m->dims.n_audio_ctx >= 128 &&
+        !(g_debug_flags & SWX_FLAG_NO_FAST_STEP) &&
+        ((g_debug_flags & SWX_FLAG_DEC_V3_FORCE) || ((g_debug_flags & SWX_FLAG_DEC_V3) && f.W * f.rpw >= 48)) &&
+        (size_t)f.W * f.rpw <= (size_t)m->L.rows_big)
+        return decoder_step_v3(m, f, s);
     if (!(g_debug_flags & SWX_FLAG_NO_FAST_STEP) && m->dtype == SWX_F16 && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.W * f.rpw <= 128 &&
         m->dims.n_text_state % 128 == 0 && swx_skinny_slab_floats(f.W * f.rpw, 3 * m->dims.n_text_state, m->dims.n_text_state) > 0)
         return decoder_step_fast(m, f, s);
@@ -582,6 +666,7 @@ int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes)
     e = hipMemcpy(m->arena + m->o_twiddle, tw.data(), sizeof(double2) * SWX_N_FFT, hipMemcpyHostToDevice);
     if (e != hipSuccess) return -100 - (int)e;
     for (auto &kv : m->slots) kv.second.loaded = false;
+    m->folded = false;
     return upload_heads(m);
 }
 
@@ -593,6 +678,7 @@ int swx_share_weights(swx_model *m, const swx_model *owner)
     if (m->dtype != owner->dtype || m->arena_bytes != owner->arena_bytes || memcmp(&m->dims, &owner->dims, sizeof(swx_dims)) != 0)
         return -1;
     m->arena = owner->arena;
+    m->folded = owner->folded && m->has_fold;
     for (auto &kv : m->slots) {
         auto it = owner->slots.find(kv.first);
         kv.second.loaded = it != owner->slots.end() && it->second.loaded;
@@ -619,6 +705,7 @@ int swx_load_tensor(swx_model *m, const char *name, const float *d_src, int64_t 
         if (e != hipSuccess) return -100 - (int)e;
     }
     sl.loaded = true;
+    m->folded = false;        // the folded copies are stale until the next swx_weights_finalize
     return 0;
 }
 
@@ -627,6 +714,33 @@ int swx_weights_complete(const swx_model *m)
     if (!m) return 0;
     for (auto &kv : m->slots) if (!kv.second.loaded) return 0;
     return 1;
+}
+
+int swx_weights_mark_loaded(swx_model *m)
+{
+    // the arena was filled from outside (a peer's packed arena received over RCCL): every slot counts as present
+    if (!m || !m->arena) return -9;
+    for (auto &kv : m->slots) kv.second.loaded = true;
+    return 0;
+}
+
+int swx_weights_finalize(swx_model *m, void *stream)
+{
+    if (!m || !m->arena) return -9;
+    if (!m->has_fold) return 0;
+    for (auto &kv : m->slots) if (!kv.second.loaded) return -9;
+    hipStream_t s = S(stream);
+    const int d = m->dims.n_text_state;
+    for (auto &w : m->dec) {
+        SWX_TRY(swx_fold_ln(m->arena + w.wqkv, m->A<float>(w.ln1_g), m->A<float>(w.ln1_b), m->A<float>(w.bqkv), m->arena + w.wqkv_f,
+                            m->A<float>(w.qkv_c1), m->A<float>(w.qkv_c2), 3 * d, d, s));
+        SWX_TRY(swx_fold_ln(m->arena + w.wcq, m->A<float>(w.lnx_g), m->A<float>(w.lnx_b), m->A<float>(w.bcq), m->arena + w.wcq_f,
+                            m->A<float>(w.cq_c1), m->A<float>(w.cq_c2), d, d, s));
+        SWX_TRY(swx_fold_ln(m->arena + w.w1, m->A<float>(w.ln2_g), m->A<float>(w.ln2_b), m->A<float>(w.b1), m->arena + w.w1_f,
+                            m->A<float>(w.w1_c1), m->A<float>(w.w1_c2), 4 * d, d, s));
+    }
+    m->folded = true;
+    return 0;
 }
 
 int swx_missing_tensor(const swx_model *m, int index, char *buf, int buflen)
@@ -1091,6 +1205,35 @@ int swx_test_gemm_splitk(const void *d_a, int64_t lda, const void *d_w, const fl
     f.bias = d_bias; f.epi = epilogue & (EPI_BIAS | EPI_GELU | EPI_RES); f.R = d_res; f.ldr = ldc; f.C = d_c; f.ldc = ldc;
     f.ln_g = d_ln_g; f.ln_b = d_ln_b; f.ln_out = d_ln_out; f.ld_ln = N;
     return swx_gemm_skinny_splitk(d_a, lda, d_w, K, M, N, K, slabs, f, S(stream));
+}
+
+int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float *d_gamma, const float *d_beta, const float *d_bias,
+                      void *d_c, int64_t ldc, void *d_x, void *d_kcache, void *d_vcache, const int32_t *d_pos0, int n_ctx, int d,
+                      int M, int N, int K, int epilogue, void *d_scratch, size_t scratch_bytes, void *stream)
+{
+    // d_scratch: N*K halfs (folded weights) + 2N floats (c1, c2) + the slab floats of the shape, 256-byte aligned pieces
+    hipStream_t s = S(stream);
+    unsigned char *p = (unsigned char *)d_scratch;
+    const size_t need = align_up((size_t)N * K * 2) + 2 * align_up((size_t)N * 4) + align_up(swx_dec_slab_floats(M, N, K) * 4 + 256);
+    if (scratch_bytes < need) return -8;
+    f16 *wf = (f16 *)p; p += align_up((size_t)N * K * 2);
+    float *c1 = (float *)p; p += align_up((size_t)N * 4);
+    float *c2 = (float *)p; p += align_up((size_t)N * 4);
+    float *slabs = (float *)p;
+    DecGemmArgs g{};
+    g.A = (const f16 *)d_a; g.lda = lda; g.M = M; g.N = N; g.K = K; g.epi = epilogue; g.ldw = K;
+    g.C = (f16 *)d_c; g.ldc = ldc; g.X = (f16 *)d_x; g.ldx = ldc; g.slabs = slabs;
+    g.kcache = (f16 *)d_kcache; g.vcache = (f16 *)d_vcache; g.pos0 = d_pos0; g.n_ctx = n_ctx; g.d = d;
+    g.epi = epilogue & 31;
+    if ((epilogue & DEC_LN) && (epilogue & 32)) {     // bit 5: d_w is already folded, d_gamma / d_beta are c1 / c2 (timing runs)
+        g.W = (const f16 *)d_w; g.c1 = d_gamma; g.c2 = d_beta;
+    } else if (epilogue & DEC_LN) {
+        SWX_TRY(swx_fold_ln(d_w, d_gamma, d_beta, d_bias, wf, c1, c2, N, K, s));
+        g.W = wf; g.c1 = c1; g.c2 = c2;
+    } else {
+        g.W = (const f16 *)d_w; g.c2 = d_bias;
+    }
+    return swx_gemm_dec(g, s);
 }
 
 int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float *d_b, void *d_y, int rows, int d, void *stream)

@@ -120,6 +120,13 @@ class Engine:
         self._load_one("const.hann", hann_window())
         self._load_one("const.mel_filters", torch.from_numpy(slaney_mel_filterbank(self.dims.n_mels)))
 
+    def mark_weights_loaded(self):
+        """The arena was filled from outside (RCCL broadcast of rank 0's packed arena, parallel.broadcast_arena): take
+        every tensor as present and run the load-time preparation that ``load_state_dict`` ends with."""
+        check(self.lib.swx_weights_mark_loaded(self.h), "swx_weights_mark_loaded")
+        check(self.lib.swx_weights_finalize(self.h, self.stream), "swx_weights_finalize")
+        torch.cuda.current_stream(self.device).synchronize()
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         """`sd` uses the upstream checkpoint keys (encoder.blocks.N.attn.query.weight, ...)."""
         for k, v in sd.items():
@@ -139,6 +146,10 @@ class Engine:
                 missing.append(buf.value.decode())
                 i += 1
             raise _lib.SwxError(f"missing tensors in state dict: {missing} ...")
+        if self.lib.swx_weights_complete(self.h):
+            # load-time preparation that needs every tensor (LayerNorm-folded copies for the fused decode step)
+            check(self.lib.swx_weights_finalize(self.h, self.stream), "swx_weights_finalize")
+            torch.cuda.current_stream(self.device).synchronize()
 
     def set_alignment_heads(self, pairs: Sequence[Tuple[int, int]]):
         pairs = [tuple(int(v) for v in p) for p in pairs]

@@ -48,7 +48,7 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> tor
 
 
 def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0,
-                      ts_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+                      ts_gain: float = 1.0, ln_jitter: float = 0.0, xattn_gain: float = 1.0) -> Dict[str, torch.Tensor]:
     """Seeded random weights under the upstream checkpoint keys (no checkpoint exists offline).  Same generator order
     as the test oracle so that both sides see identical weights for a given seed."""
     g = torch.Generator().manual_seed(seed)
@@ -99,6 +99,15 @@ def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02
     for i in range(dims.n_text_layer):
         block(f"decoder.blocks.{i}", dt, True)
     ln("decoder.ln", dt)
+    if ln_jitter:   # non-trivial LayerNorm affine parameters from a generator of their own (the other tensors stay the same)
+        g2 = torch.Generator().manual_seed(seed + 7919)
+        for k in sd:
+            if "_ln" in k or k.endswith("ln.weight") or k.endswith("ln.bias") or "ln_post" in k:
+                sd[k] = sd[k] + ln_jitter * torch.randn(sd[k].shape, generator=g2)
+    if xattn_gain != 1.0:   # sharper cross-attention (scores scaled by xattn_gain): word timing on peaky attention maps
+        for k in sd:
+            if ".cross_attn.query.weight" in k or ".cross_attn.key.weight" in k:
+                sd[k] = sd[k] * float(xattn_gain) ** 0.5
     return sd
 
 
@@ -129,6 +138,17 @@ class Whisper:
         self.alignment_heads = SparseHeads(alignment_heads)
         self.dq = False
         self._bind_api()
+
+    @classmethod
+    def from_engine(cls, engine: Engine) -> "Whisper":
+        """A model object around an engine that already exists (weights loaded, heads set)."""
+        self = object.__new__(cls)
+        self.dims = engine.dims
+        self.engine = engine
+        self.alignment_heads = SparseHeads(getattr(engine, "alignment_heads", None) or [])
+        self.dq = False
+        self._bind_api()
+        return self
 
     # -- reference-visible attributes
     @property

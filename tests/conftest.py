@@ -26,9 +26,8 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    # first-ever hardware runs of new device code (non-strict xfail, own subprocess) go last: whatever they do to the
-    # GPU, the validated parity tests have already run
-    pending = [it for it in items if it.get_closest_marker("xfail") is not None and "gpu" in it.keywords]
+    # checks that run in a subprocess of their own (hw_checks/, inner pytest runs) go last
+    pending = [it for it in items if "gpu" in it.keywords and "in_subprocess" in it.name]
     if pending:
         items[:] = [it for it in items if it not in pending] + pending
     import torch

@@ -1,6 +1,6 @@
 """Hardware check of swx_test_gemm_splitk (the decode-step GEMM as the fused step launches it: split-K weight streaming
-+ finish kernel with bias / GELU / residual / fused LayerNorm) against a torch fp32 reference of the same op on the f16
-inputs.  Tolerance: the f16 rounding of the output (f32 accumulation inside).  Exit code 0 = all shapes agree.
++ finish kernel with bias / GELU / residual / fused LayerNorm) against a float64 reference computed on the CPU from the
+same f16 inputs.  Tolerance: the f16 rounding of the output (f32 accumulation inside).  Exit code 0 = all shapes agree.
 
     python tests/hw_checks/splitk_hook_check.py
 """
@@ -38,18 +38,18 @@ def main() -> int:
         rc = lib.swx_test_gemm_splitk(p(a), K, p(w), p(bias), p(c) if epi & EPI_RES else None, p(c), N,
                                       p(lg) if ln else None, p(lb) if ln else None, p(h), M, N, K, epi, st)
         torch.cuda.synchronize()
-        ref = a.float() @ w.float().t() + bias
+        ref = a.cpu().double() @ w.cpu().double().t() + bias.cpu().double()      # CPU, float64
         if epi & EPI_GELU:
             ref = torch.nn.functional.gelu(ref)
         if epi & EPI_RES:
-            ref = ref + res.float()
-        err = ((c.float() - ref).abs() / (ref.abs() + 1.0)).max().item()
+            ref = ref + res.cpu().double()
+        err = ((c.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max().item()
         ok = rc == 0 and err < 4e-3
         msg = f"M={M} N={N} K={K} epi={epi} ln={ln}: rc={rc} max rel err {err:.2e}"
         if ln and rc == 0:
-            x = c.float()                                    # the fused LayerNorm sees the stored (f16-rounded) row
-            ref_h = torch.nn.functional.layer_norm(x, (N,), lg, lb, 1e-5)
-            err_h = ((h.float() - ref_h).abs() / (ref_h.abs() + 1.0)).max().item()
+            x = c.cpu().double()                             # the fused LayerNorm sees the stored (f16-rounded) row
+            ref_h = torch.nn.functional.layer_norm(x, (N,), lg.cpu().double(), lb.cpu().double(), 1e-5)
+            err_h = ((h.cpu().double() - ref_h).abs() / (ref_h.abs() + 1.0)).max().item()
             ok = ok and err_h < 4e-3
             msg += f", LayerNorm {err_h:.2e}"
         print(("ok   " if ok else "FAIL ") + msg)
