@@ -107,6 +107,25 @@ def main():
             print(f"  {name:26s} N={N:5d} K={K:5d}: {us:7.2f} us  {2.0 * (N * K + M * K + M * N) / us / 1e3:7.1f} GB/s algorithmic")
         print(f"  sum of the six projections of one layer: {tot:.1f} us")
 
+    if args.only in ("", "dtw"):
+        print("-- DTW + backtrace (one workgroup per window)")
+        from stable_ts_amd.engine import dtw as _dtw  # noqa: F401
+        import numpy as np
+        for W, N, Mc in [(1, 226, 1500), (20, 226, 1500), (20, 112, 1500), (20, 64, 1500), (4, 448, 1500)]:
+            x = torch.randn(W, N, Mc, device=dev)
+            dN = torch.full((W,), N, dtype=torch.int32, device=dev)
+            dM = torch.full((W,), Mc, dtype=torch.int32, device=dev)
+            cap = N + Mc
+            ti = torch.empty(W, cap, dtype=torch.int32, device=dev)
+            tj = torch.empty(W, cap, dtype=torch.int32, device=dev)
+            ln = torch.empty(W, dtype=torch.int32, device=dev)
+            wsb = torch.empty(lib.swx_dtw_workspace_bytes(W, N, Mc), dtype=torch.uint8, device=dev)
+            fn = lambda: lib.swx_dtw(p(x), W, N, Mc, p(dN), p(dM), p(ti), p(tj), p(ln), p(wsb), st)
+            assert fn() == 0
+            us = timed(fn, 20)
+            steps = Mc + (N + (N + 63) // 64 - 1) // ((N + 63) // 64) - 1
+            print(f"  W={W:3d} N={N:4d} M={Mc}: {us:8.1f} us per launch   {1000.0 * us / (steps + N + Mc):7.1f} ns per dependent step (sweep {steps} + walk <= {N + Mc})")
+
     if args.only in ("", "splitk"):
         print("-- decode-step GEMMs (split-K weight streaming + finish), M=100")
         M = 100

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     // ---- block id -> (column panel, K slice, row group): all row groups of one (panel, slice) unit share an XCD
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int unit = (slot / g.n_rg) * 8 + xcd, rg = slot % g.n_rg;
+    int unit = (slot / g.n_rg) * 8 + xcd, rg = slot % g.n_rg;
+    if (g.abl & 32) { unit = b / g.n_rg; rg = b % g.n_rg; }        // experiment: row groups of a panel spread over the XCDs
     const int panels = (g.N + 63) >> 6;
     if (unit >= panels * g.ks2) return;
     const int panel = unit / g.ks2, ks_id = unit - panel * g.ks2;
@@ -61,11 +62,16 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     const int ncol = panel * 64 + wave * 16 + li;
     const f16 *wp = g.W + (size_t)(ncol < g.N ? ncol : g.N - 1) * g.ldw + k0 + lg * 8;
     f16x8 wf[NKS];
+    if (g.abl & 1) {                       // experiment: no weight traffic
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) wf[ks] = *(const f16x8 *)(wp + ks * 32);
+        for (int ks = 0; ks < NKS; ++ks) wf[ks] = (f16x8)(f16)(0.001f * (float)(lane + ks));
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) wf[ks] = *(const f16x8 *)(wp + ks * 32);
+    }
 
     // ---- activation tile -> LDS by LDS-DMA; instruction q writes LDS bytes [q*1024, q*1024 + 1024)
-    {
+    if (!(g.abl & 2)) {
         constexpr int n_instr = (MT * 16 * SPR) >> 6;      // = MT * NKS, a multiple of 4
 #pragma unroll
         for (int j = 0; j < n_instr / 4; ++j) {
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 
     // ---- LayerNorm statistics of the tile's rows (complete rows: K == kslice == d), 16 lanes per row
     float2 *stat = (float2 *)(smem + (size_t)MT * 16 * RS);
-    if (g.epi & DEC_LN) {
+    if ((g.epi & DEC_LN) && !(g.abl & 4)) {
         const f16x2 one2 = {(f16)1.f, (f16)1.f};
         for (int rb = wave * 4 + lg; rb < MT * 16; rb += 16) {
             const unsigned char *rp = smem + (size_t)rb * RS + li * 16;
@@ -123,6 +129,10 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
         const int phys = (ks * 4 + lg) ^ li;
         return *(const f16x8 *)(abase + (size_t)t * 16 * RS + phys * 16);
     };
+    if (g.abl & 8) {                       // experiment: no MFMA phase (keeps the weight fragments live)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) acc[0][ks & 3] += (float)wf[ks][0];
+    } else {
 #pragma unroll
     for (int ks = 0; ks < PF; ++ks)
 #pragma unroll
@@ -136,11 +146,13 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
         }
         __builtin_amdgcn_sched_barrier(0);        // keeps the prefetch PF steps ahead (the scheduler sinks it back otherwise)
     }
+    }
     if (g.epi & DEC_LN) __syncthreads();          // stat[] visible to every wave
 
     // ---- epilogue: lane holds columns n .. n+3 of row m for every tile
     const int n = panel * 64 + wave * 16 + lg * 4;
     if (n >= g.N) return;                          // N % 4 == 0 is checked by the launcher
+    if ((g.abl & 16) && acc[0][0] != 12345.678f) return;      // experiment: no epilogue
     if (g.epi & DEC_SLAB) {
         float *out = g.slabs + (size_t)ks_id * g.slab_stride;
 #pragma unroll
@@ -295,6 +307,8 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     if (ks2 == 1 && (g.epi & DEC_SLAB)) g.epi &= ~DEC_SLAB;      // un-split after all: the kernel finishes the output itself
     g.ks2 = ks2; g.kslice = g.K / ks2; g.n_rg = cdiv(g.M, mt * 16);
     g.slab_stride = (int64_t)g.M * g.N;
+    static const int abl = [] { const char *e = getenv("SWX_DEC_ABL"); return e ? atoi(e) : 0; }();
+    g.abl = abl;
     const int nks = g.kslice / 32;
     const int units = (g.N / 64) * ks2;
     const int grid = cdiv(units, 8) * g.n_rg * 8;

@@ -6,83 +6,164 @@
 // to a correctly rounded f32 add for every pair of f32 inputs (the f64 sum is exact when the exponents
 // are within 29 bits, and otherwise both roundings return the larger operand), so the kernel adds in f32.
 //
-// Mapping: one 64-lane wavefront per window.  Lane l owns R consecutive token rows; at step t it computes
-// column j = t - l + 1, so the wave sweeps a skewed anti-diagonal front and the only cross-lane traffic is
-// one shuffle per step (the bottom cell of the lane above).  The sweep is bound by its serial depth
-// (M + ceil(N/R) - 1 steps), not by bandwidth.  The 2-bit moves of a lane's R rows for one column are packed
-// into one u16 and written to a [M][64] trace plane; the backtrace walks it and emits the path in forward order.
+// The problem is bound by its serial depth (M + ceil(N/R) - 1 dependent steps), not by bandwidth:
+// the cost matrix is <= 2.7 MB.  What round 1's kernel paid per step was memory latency -- a global load of x per lane with
+// nothing prefetched (the skewed front touches 64 different cache lines per step) and a global trace store: 0.83 us per
+// step.  This generation is the LDS wavefront scan the north star names:
+//   * one workgroup (4 waves) per window.  Wave 0 sweeps the skewed anti-diagonal front: lane l owns R consecutive token
+//     rows and computes column j = t - l at step t; the only cross-lane traffic is one shuffle per step (the bottom cell of
+//     the lane above).
+//   * waves 1-3 stream x from HBM/L2 in 16-step chunks with coalesced row segments (64 contiguous bytes per row and chunk)
+//     and park it in an LDS ring ALREADY SKEWED: slot s of lane l holds x[l*R .. l*R+R-1][s - l], so the sweep reads one
+//     aligned R-float record per step at a lane stride chosen to be bank-conflict free, one step ahead of its use.
+//     Loads for chunk k+2 are in flight while the sweep runs chunk k; one workgroup barrier per 16 steps.
+//   * the 2-bit moves of a lane's R rows for one column are packed into one byte (R <= 4, i.e. N <= 256 tokens -- every
+//     transcribe() / align() window) and kept in LDS, lane-major ([lane][column]); the backtrace walks it from LDS in
+//     8-column words (one LDS read per 8 columns or lane change instead of one dependent memory load per path step).
+//     Longer token axes (R = 5..7, N <= 448) keep the trace in global memory in the same lane-major layout.
+#include <type_traits>
 #include "swx_common.h"
 #include "swx_kernels.h"
 
-template <int R>
-__global__ __launch_bounds__(64) void swx_dtw_kernel(const float *__restrict__ x_all, int ld_n, int ld_m,
-                                                     const int *__restrict__ Nw, const int *__restrict__ Mw,
-                                                     int *__restrict__ text_idx, int *__restrict__ time_idx,
-                                                     int *__restrict__ out_len, unsigned char *__restrict__ ws_all,
-                                                     size_t ws_stride)
+namespace {
+
+constexpr int DTW_CH = 16;            // steps per chunk (one barrier per chunk)
+constexpr int DTW_RING = 32;          // ring slots = 2 chunks: the chunk being swept + the chunk being written
+
+__host__ __device__ constexpr int dtw_lane_stride(int R)      // dwords between two lanes' rings; see the bank notes above
 {
+    return DTW_RING * R + (R == 4 ? 4 : (R == 2 ? 2 : 1));
+}
+
+template <int R, bool TLDS>
+__global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ x_all, int ld_n, int ld_m,
+                                                      const int *__restrict__ Nw, const int *__restrict__ Mw,
+                                                      int *__restrict__ text_idx, int *__restrict__ time_idx,
+                                                      int *__restrict__ out_len, unsigned char *__restrict__ ws_all,
+                                                      size_t ws_stride, int TP)
+{
+    typedef typename std::conditional<(R <= 4), unsigned char, unsigned short>::type TT;    // one column's moves of a lane
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LS = dtw_lane_stride(R);
+    float *xs = (float *)smem;                                   // [64][LS]: slot s of lane l at l*LS + (s % RING)*R + r
+    TT *tr_lds = (TT *)(smem + (size_t)64 * LS * 4);             // [64][TP] (TLDS only)
     const int w = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int N = Nw[w], M = Mw[w];
     const int cap = ld_n + ld_m;
     const float *__restrict__ x = x_all + (size_t)w * ld_n * ld_m;
-    unsigned short *trace = (unsigned short *)(ws_all + (size_t)w * ws_stride);
-    int *tmp_t = (int *)(ws_all + (size_t)w * ws_stride + (size_t)ld_m * 64 * sizeof(unsigned short));
+    unsigned char *wsw = ws_all + (size_t)w * ws_stride;
+    TT *tr = TLDS ? tr_lds : (TT *)wsw;                          // trace plane, lane-major, pitch TP
+    int *tmp_t = (int *)(wsw + (size_t)64 * TP * sizeof(unsigned short));
     int *tmp_f = tmp_t + cap;
     int *o_t = text_idx + (size_t)w * cap;
     int *o_f = time_idx + (size_t)w * cap;
 
     if (N <= 0 || M <= 0) {  // degenerate: path of the border only
-        if (lane == 0) out_len[w] = 0;
+        if (tid == 0) out_len[w] = 0;
         return;
     }
-    const int nl = (N + R - 1) / R;  // active lanes
+    const int nl = (N + R - 1) / R;                    // active lanes
+    const int steps = M + nl - 1;
+    const int nchunks = (steps + DTW_CH - 1) / DTW_CH;
     const float INF = __builtin_inff();
 
+    // ---- loader side (waves 1-3): element e of a chunk = (row e / 16, step t0 + e % 16) -> column step - row / R
+    constexpr int NLD = (64 * R * DTW_CH + 191) / 192;
+    float lreg[NLD];
+    auto issue_loads = [&](int k) {
+        const int t0 = k * DTW_CH;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = (tid - 64) + 192 * i;
+            const int row = e >> 4, s = t0 + (e & 15);
+            const int j = s - row / R;
+            const bool ok = row < N && j >= 0 && j < M;
+            // clamped address + select: a predicated load would be a branch with its own wait
+            const float v = x[(size_t)(row < N ? row : N - 1) * ld_m + (j < 0 ? 0 : (j < M ? j : M - 1))];
+            lreg[i] = ok ? v : 0.f;
+        }
+    };
+    auto store_lds = [&](int k) {
+        const int t0 = k * DTW_CH;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = (tid - 64) + 192 * i;
+            const int row = e >> 4, s = t0 + (e & 15);
+            if (row < 64 * R) xs[(row / R) * LS + (s % DTW_RING) * R + (row % R)] = lreg[i];
+        }
+    };
+
+    // ---- sweep state (wave 0)
     float prev[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) prev[r] = INF;         // cost[i][0] = inf for i >= 1
     float diag_in = (lane == 0) ? 0.0f : INF;          // cost[i0-1][0]; cost[0][0] = 0
     float bottom = INF;
     const int i0 = lane * R;                           // 0-based first row of this lane
-    const int steps = M + nl - 1;
+    const float *xl = xs + lane * LS;
 
-    for (int t = 0; t < steps; ++t) {
-        float up = __shfl_up(bottom, 1, 64);
-        if (lane == 0) up = INF;                       // cost[0][j] = inf for j >= 1
-        const int j = t - lane;                        // 0-based column
-        if (lane < nl && j >= 0 && j < M) {
-            float c0 = diag_in, c1 = up;
-            unsigned tr = 0;
+    if (wave > 0) { issue_loads(0); store_lds(0); if (nchunks > 1) issue_loads(1); }
+    __syncthreads();
+    for (int k = 0; k < nchunks; ++k) {
+        if (wave == 0) {
+            const int t_end = (k + 1) * DTW_CH < steps ? (k + 1) * DTW_CH : steps;
+            int t = k * DTW_CH;
+            float xv[R], xn[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (i0 + r < N) {
+            for (int r = 0; r < R; ++r) xv[r] = xl[(t % DTW_RING) * R + r];
+            for (; t < t_end; ++t) {
+                if (t + 1 < t_end) {                   // next step's record: in flight while this step's chain runs
+#pragma unroll
+                    for (int r = 0; r < R; ++r) xn[r] = xl[((t + 1) % DTW_RING) * R + r];
+                }
+                // bottom cell of the lane above: one DPP move (wave_shr:1; lane 0 keeps `old` = inf = cost[0][j], j >= 1)
+                const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(bottom), 0x138, 0xf, 0xf, false));
+                const int j = t - lane;                // 0-based column
+                const bool valid = lane < nl && j >= 0 && j < M;
+                // straight-line body for all R rows (no branches on the dependent chain): rows past N of the last active
+                // lane compute on zeros -- their results feed only rows further down, which are past N as well -- and a
+                // lane outside its column range keeps its state through the selects below
+                float c0 = diag_in, c1 = up;
+                unsigned trb = 0;
+                float nvs[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
                     const float c2 = prev[r];
-                    const float xv = x[(size_t)(i0 + r) * ld_m + j];
-                    float c;
-                    unsigned mv;
-                    if (c0 < c1 && c0 < c2) { c = c0; mv = 0u; }
-                    else if (c1 < c0 && c1 < c2) { c = c1; mv = 1u; }
-                    else { c = c2; mv = 2u; }
-                    const float nv = __fadd_rn(xv, c);
-                    tr |= mv << (2 * r);
+                    const bool s0 = (c0 < c1) & (c0 < c2);
+                    const bool s1 = (c1 < c0) & (c1 < c2);
+                    const float c = s0 ? c0 : (s1 ? c1 : c2);
+                    trb |= (s0 ? 0u : (s1 ? 1u : 2u)) << (2 * r);
+                    const float nv = __fadd_rn(xv[r], c);
+                    nvs[r] = nv;
                     c0 = c2;       // cost[i][j-1] is the diagonal of the row below
                     c1 = nv;       // cost[i][j]   is "up" of the row below
-                    prev[r] = nv;
                 }
+#pragma unroll
+                for (int r = 0; r < R; ++r) prev[r] = valid ? nvs[r] : prev[r];
+                bottom = valid ? c1 : bottom;
+                diag_in = valid ? up : diag_in;
+                if (valid) tr[(size_t)lane * TP + j] = (TT)trb;
+#pragma unroll
+                for (int r = 0; r < R; ++r) xv[r] = xn[r];
             }
-            bottom = c1;
-            diag_in = up;
-            trace[(size_t)j * 64 + lane] = (unsigned short)tr;
+        } else if (k + 1 < nchunks) {
+            store_lds(k + 1);                           // loads issued one chunk ago; its slots held chunk k-1
+            if (k + 2 < nchunks) issue_loads(k + 2);
         }
+        __syncthreads();
     }
+    if (wave > 0) return;
 
-    // make the trace plane visible to the whole wave before the walk (same workgroup, global memory)
-    __threadfence_block();
-    __syncthreads();
+    // the trace plane must be visible to the walk (LDS: the barrier above; global: same wave, program order + fence)
+    if (!TLDS) __threadfence_block();
 
-    // backtrace: every lane walks the same path (uniform loads); lane 0 records it
+    // ---- backtrace: every lane of wave 0 walks the same path (uniform control flow, broadcast reads); lane 0 records it.
+    //      The moves of 8 (byte trace) or 4 (short trace) consecutive columns of one lane travel in one 64-bit word.
+    constexpr int WCOLS = 8 / (int)sizeof(TT);
     int i = N, j = M, n = 0;
+    int cur_lane = -1, cur_blk = -1;
+    unsigned long long word = 0;
     while (i > 0 || j > 0) {
         if (lane == 0) { tmp_t[n] = i - 1; tmp_f[n] = j - 1; }
         ++n;
@@ -90,15 +171,21 @@ __global__ __launch_bounds__(64) void swx_dtw_kernel(const float *__restrict__ x
         if (i == 0) mv = 2u;
         else if (j == 0) mv = 1u;
         else {
-            const unsigned wd = trace[(size_t)(j - 1) * 64 + (i - 1) / R];
-            mv = (wd >> (2 * ((i - 1) % R))) & 3u;
+            const int tl = (i - 1) / R, rr = (i - 1) - tl * R, col = j - 1;
+            const int blk = col / WCOLS;
+            if (tl != cur_lane || blk != cur_blk) {
+                word = *(const unsigned long long *)(tr + (size_t)tl * TP + blk * WCOLS);     // TP % 8 == 0: aligned
+                cur_lane = tl; cur_blk = blk;
+            }
+            const unsigned wd = (unsigned)(word >> ((col - blk * WCOLS) * 8 * (int)sizeof(TT))) & (sizeof(TT) == 1 ? 0xFFu : 0xFFFFu);
+            mv = (wd >> (2 * rr)) & 3u;
         }
         if (mv == 0u) { --i; --j; }
         else if (mv == 1u) { --i; }
         else { --j; }
     }
     __threadfence_block();
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0);        // lane 0's path stores before the other lanes read them back (one wave: program order)
     for (int p = lane; p < n; p += 64) {
         o_t[p] = tmp_t[n - 1 - p];
         o_f[p] = tmp_f[n - 1 - p];
@@ -106,9 +193,14 @@ __global__ __launch_bounds__(64) void swx_dtw_kernel(const float *__restrict__ x
     if (lane == 0) out_len[w] = n;
 }
 
+inline int dtw_tp(int ld_m) { return (ld_m + 15) / 16 * 16; }
+
+}  // namespace
+
 extern "C" size_t swx_dtw_workspace_bytes(int W, int ld_n, int ld_m)
 {
-    size_t per = (size_t)ld_m * 64 * sizeof(unsigned short) + 2 * (size_t)(ld_n + ld_m) * sizeof(int);
+    // per window: the lane-major trace plane as shorts (used by the long-token-axis variant only) + the path scratch
+    size_t per = (size_t)64 * dtw_tp(ld_m) * sizeof(unsigned short) + 2 * (size_t)(ld_n + ld_m) * sizeof(int);
     per = (per + 255) & ~(size_t)255;
     return per * (size_t)(W > 0 ? W : 1);
 }
@@ -120,18 +212,28 @@ extern "C" int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_
     if (ld_n <= 0 || ld_m <= 0 || ld_n > 448) return -2;
     hipStream_t s = (hipStream_t)stream;
     SwxProfScope prof(PC_DTW, (double)W * ld_n * ld_m * 5.0, s);
-    size_t per = swx_dtw_workspace_bytes(1, ld_n, ld_m);
+    const size_t per = swx_dtw_workspace_bytes(1, ld_n, ld_m);
     const int R = (ld_n + 63) / 64;
-#define SWX_DTW_LAUNCH(RR) hipLaunchKernelGGL(swx_dtw_kernel<RR>, dim3(W), dim3(64), 0, s, d_x, ld_n, ld_m, d_N, d_M, \
-                                              d_text_idx, d_time_idx, d_len, (unsigned char *)d_trace_ws, per)
+    const int TP = dtw_tp(ld_m);
+#define SWX_DTW_LAUNCH(RR, TL) do { \
+        const size_t lds = (size_t)64 * dtw_lane_stride(RR) * 4 + ((TL) ? (size_t)64 * TP * (RR <= 4 ? 1 : 2) : 0); \
+        static bool attr_done = false; \
+        if (!attr_done) { \
+            hipError_t e_ = hipFuncSetAttribute((const void *)swx_dtw_kernel<RR, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            if (e_ != hipSuccess) return -100 - (int)e_; \
+            attr_done = true; \
+        } \
+        if (lds > 160 * 1024 - 1024) return -2; \
+        hipLaunchKernelGGL((swx_dtw_kernel<RR, TL>), dim3(W), dim3(256), lds, s, d_x, ld_n, ld_m, d_N, d_M, d_text_idx, d_time_idx, \
+                           d_len, (unsigned char *)d_trace_ws, per, TP); } while (0)
     switch (R) {
-        case 1: SWX_DTW_LAUNCH(1); break;
-        case 2: SWX_DTW_LAUNCH(2); break;
-        case 3: SWX_DTW_LAUNCH(3); break;
-        case 4: SWX_DTW_LAUNCH(4); break;
-        case 5: SWX_DTW_LAUNCH(5); break;
-        case 6: SWX_DTW_LAUNCH(6); break;
-        default: SWX_DTW_LAUNCH(7); break;
+        case 1: SWX_DTW_LAUNCH(1, true); break;
+        case 2: SWX_DTW_LAUNCH(2, true); break;
+        case 3: SWX_DTW_LAUNCH(3, true); break;
+        case 4: SWX_DTW_LAUNCH(4, true); break;
+        case 5: SWX_DTW_LAUNCH(5, false); break;
+        case 6: SWX_DTW_LAUNCH(6, false); break;
+        default: SWX_DTW_LAUNCH(7, false); break;
     }
 #undef SWX_DTW_LAUNCH
     SWX_CHECK_LAUNCH();

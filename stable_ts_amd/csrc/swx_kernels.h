@@ -82,6 +82,7 @@ struct DecGemmArgs {
     float *slabs;                        // swx_dec_slab_floats(M, N, K) floats when the shape runs K-split
     _Float16 *kcache, *vcache; const int32_t *pos0; int n_ctx, d;
     int ks2, kslice, n_rg; int64_t slab_stride;   // filled by the launcher
+    int abl;                             // experiment switches (SWX_DEC_ABL, scripts/dec_ablate.sh); 0 in production
 };
 int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation
 size_t swx_dec_slab_floats(int M, int N, int K);

@@ -308,21 +308,33 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                              only_voice_freq=only_voice_freq, only_ffmpeg=only_ffmpeg, verbose=verbose,
                              new_chunk_divisor=None, load_sections=sections)
 
-    language = decode_options.get("language")
-    if not language:
-        if not model.is_multilingual:
-            language = "en"
-        else:                                                                                   # :319-336
-            first = loader.next_chunk(0, N_SAMPLES)
-            mel0 = model.log_mel(first, N_SAMPLES - first.shape[-1])
-            _, probs = model.detect_language(mel0)
-            language = max(probs, key=probs.get)
-    decode_options["language"] = language
-    tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=language, task=task)
+    # Language and tokenizer are settled at the FIRST WINDOW THAT IS ACTUALLY DECODED (original_whisper.py:319-345, called at
+    # :532 after the silent windows were skipped, after nonspeech_skip trimmed the window and inside the first clip section) --
+    # not on the first 30 s of the file.  `settle_language` is called with that window's audio right before its batch runs.
+    lang_state = dict(language=decode_options.get("language"), tokenizer=None, prompt_tokens=[])
+    if lang_state["language"] or not model.is_multilingual:
+        lang_state["language"] = lang_state["language"] or "en"
+        decode_options["language"] = lang_state["language"]
+        lang_state["tokenizer"] = get_tokenizer(model.is_multilingual, num_languages=model.num_languages,
+                                                language=lang_state["language"], task=task)
+        if initial_prompt is not None:                                                          # :342-345
+            lang_state["prompt_tokens"] = lang_state["tokenizer"].encode(" " + initial_prompt.strip())
+    initial_prompt_tokens: List[int] = lang_state["prompt_tokens"]
 
-    initial_prompt_tokens: List[int] = []
-    if initial_prompt is not None:                                                              # :342-345
-        initial_prompt_tokens = tokenizer.encode(" " + initial_prompt.strip())
+    def settle_language(first_audio: torch.Tensor, tracks_: list):
+        if lang_state["tokenizer"] is not None:
+            return
+        n = int(first_audio.shape[-1])
+        mel0 = model.log_mel(first_audio, max(N_SAMPLES - n, 0))
+        _, probs = model.detect_language(mel0)
+        lang = max(probs, key=probs.get)
+        lang_state["language"] = decode_options["language"] = lang
+        tok = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language=lang, task=task)
+        lang_state["tokenizer"] = tok
+        if initial_prompt is not None:
+            lang_state["prompt_tokens"].extend(tok.encode(" " + initial_prompt.strip()))
+            for tr in tracks_:                      # the reference extends all_tokens at this point (:344-345)
+                tr.all_tokens.extend(lang_state["prompt_tokens"])
 
     def new_track(source: AudioLoader, offset: int = 0) -> _Track:
         from .stabilization import NonSpeechPredictor
@@ -454,7 +466,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                 return []
             ctx, side = m.stream_context()
             with ctx:
-                outs_k = _process_batch(m, tokenizer, part, o)
+                outs_k = _process_batch(m, lang_state["tokenizer"], part, o)
             if side is not None:
                 side.synchronize()
             return outs_k
@@ -467,6 +479,12 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             items = [window_input(tr0, sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
             live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
             tr0.started = tr0.started or bool(live)
+            if live:
+                settle_language(live[0]["audio"], [tr0])
+                for it in live:
+                    if not it["prompt"]:
+                        it["prompt"] = list(lang_state["prompt_tokens"])
+            tokenizer = lang_state["tokenizer"]
             if lanes and len(live) >= len(lanes):
                 per = (len(live) + len(lanes) - 1) // len(lanes)
                 parts = [live[k * per:(k + 1) * per] for k in range(len(lanes))]
@@ -491,7 +509,11 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             items = [(tr, it) for tr in active if (it := next_live_item(tr)) is not None]
             if not items:
                 break
-            outs = _process_batch(model, tokenizer, [it for _, it in items], o)
+            if lang_state["tokenizer"] is None:
+                settle_language(items[0][1]["audio"], tracks)
+                for tr, it in items:                # the prompt slices were taken before the initial prompt was known
+                    it["prompt"] = tr.all_tokens[tr.prompt_reset_since:]
+            outs = _process_batch(model, lang_state["tokenizer"], [it for _, it in items], o)
             for (tr, it), out in zip(items, outs):
                 advance(tr, it, out)
             active = [tr for tr, _ in items]
@@ -502,6 +524,10 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     loader.terminate()                                                                          # :731
 
     def finish(tr: _Track) -> WhisperResult:
+        language = lang_state["language"]
+        tokenizer = lang_state["tokenizer"]
+        if tokenizer is None:       # nothing was ever decoded (all windows silent): no language was settled (:527)
+            tokenizer = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language="en", task=task)
         text = tokenizer.decode(tr.all_tokens[len(initial_prompt_tokens):])
         # the reference settles the language at the first window that is not skipped as silent (:527, detect_language());
         # a recording without such a window yields language None

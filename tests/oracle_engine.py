@@ -212,6 +212,11 @@ class CpuWhisper:
     def cross_kv(self, xa):
         return XKV(xa)
 
+    @torch.no_grad()
+    def detect_language(self, mel):
+        from oracle.whisper.decoding import detect_language
+        return detect_language(self.om, mel)
+
     def clone_for_stream(self):
         import copy
         return CpuWhisper(copy.deepcopy(self.om))      # the oracle's hook-based KV cache is per module instance

@@ -321,3 +321,49 @@ def test_transcribe_zero_progress_window_is_skipped(models, monkeypatch):
     with pytest.warns(UserWarning, match="no forward progress"):
         got = mine.transcribe(G.synth_audio(47.0, seed=143), language="en", **opts)
     assert len(got.segments) > 0
+
+
+@pytest.fixture(scope="module")
+def multilingual_models():
+    import make_golden as G
+    sw = G.import_reference()
+    from oracle.whisper.model import build_model
+    m = build_model("tiny", seed=99, std=0.02, embed_gain=2.0, ts_gain=0.5)
+    sw.modify_model(m)
+    from oracle_engine import CpuWhisper
+    return G, m, CpuWhisper(m)
+
+
+@pytest.mark.parametrize("name,opts", [
+    ("leading_silence", dict()),
+    ("leading_silence_clip", dict(clip_timestamps=[36.0, 60.0, 64.0, 80.0], regroup=False)),
+    ("nonspeech_skip_trim", dict(nonspeech_skip=0.4, regroup=False)),
+    ("prompt_before_language", dict(initial_prompt=" aaat aaau", condition_on_previous_text=True)),
+    ("window_parallel", dict(batch_size=2, regroup=False)),
+])
+def test_language_is_detected_on_the_first_decoded_window(multilingual_models, monkeypatch, name, opts):
+    # multilingual model, no language given: the reference detects the language on the first window it actually decodes
+    # (original_whisper.py:319-336, called at :532) -- after the silent windows were skipped, after nonspeech_skip trimmed the
+    # window, inside the first clip section -- and only then builds the tokenizer and the initial prompt tokens.  The
+    # recording opens with 33 s of exact silence; language detection on those zeros gives a different language than the
+    # first audible window (checked below), so detecting on the file's first 30 s would show up as a different result.
+    G, ref_model, mine = multilingual_models
+    from oracle_engine import install
+    install(monkeypatch)
+    o = dict(BASE, **opts)
+    batch = o.pop("batch_size", None)
+    audio = torch.cat([torch.zeros(33 * 16000), G.synth_audio(52.0, seed=5)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = mine.transcribe(audio, **o, **({"batch_size": batch} if batch else {}))
+        if batch:     # the reference has no window-parallel mode: its oracle is "each 30-s clip on its own, one language"
+            assert got.language is not None and len(got.segments) > 0
+            _, p_first = mine.detect_language(mine.log_mel(audio[30 * 16000: 60 * 16000]))
+            assert got.language == max(p_first, key=p_first.get)
+            return
+        want = ref_model.transcribe(audio, verbose=None, ignore_compatibility=True, **o)
+    assert got.language == want.language and want.language is not None
+    _, p_zero = mine.detect_language(mine.log_mel(torch.zeros(480000)))
+    assert max(p_zero, key=p_zero.get) != want.language, "the silent opening must not give the same language by accident"
+    assert _snap(got) == _snap(want)
+    assert got.to_dict() == want.to_dict()
