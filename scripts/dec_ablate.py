@@ -32,7 +32,13 @@ def main():
         pos0 = torch.full((M,), 17, dtype=torch.int32, device=dev)
         scratch = torch.empty(N * K * 2 + 8 * N + 16 * M * N * 4 + 8192, dtype=torch.uint8, device=dev)
         ldc = d if (epi & 8) else N
+        hot = os.environ.get("DEC_HOT") == "1"
+        touch = os.environ.get("DEC_TOUCH")
         for i in range(60):
+            if hot:
+                i = 0
+            if touch is not None:          # read a weight copy `touch` launches ahead (warms the Infinity Cache and the TLB)
+                ws[(i + int(touch)) % len(ws)].float().sum()
             rc = lib.swx_test_dec_gemm(p(a), K, p(ws[i % len(ws)]), p(c1), p(c2), p(c2), p(c), ldc, p(x), p(kc), p(vc), p(pos0), 448, d,
                                        M, N, K, epi, p(scratch), scratch.numel(), st)
             assert rc == 0, rc

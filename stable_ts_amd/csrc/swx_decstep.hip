@@ -38,9 +38,14 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DEC_MAXMT = 3;
 
-template <int MT, int NKS>          // NKS = K-slice depth / 32, fixed at compile time: every loop below unrolls without branches
+// NKS = K-slice depth / 32 and the epilogue EPI are fixed at compile time: every loop below unrolls without branches, and no
+// load sits under a run-time condition (a conditional load compiles to a branch whose join waits vmcnt(0), which would drain
+// the weight stream before the barrier -- seen in the ISA of the run-time-epilogue version)
+template <int MT, int NKS, int EPI>
 __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 {
+    constexpr bool E_LN = (EPI & DEC_LN) != 0, E_GELU = (EPI & DEC_GELU) != 0, E_RES = (EPI & DEC_RES) != 0,
+                   E_QKV = (EPI & DEC_QKV) != 0, E_SLAB = (EPI & DEC_SLAB) != 0;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [MT*16][kslice] f16 | float2 stat[MT*16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -58,20 +63,12 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     const int k0 = ks_id * kslice;
     const int r0 = rg * (MT * 16);
 
-    // ---- weights of this wave's 16 columns: every fragment of the slice in flight at once (HBM, or L2 behind a sibling)
-    const int ncol = panel * 64 + wave * 16 + li;
-    const f16 *wp = g.W + (size_t)(ncol < g.N ? ncol : g.N - 1) * g.ldw + k0 + lg * 8;
-    f16x8 wf[NKS];
-    if (g.abl & 1) {                       // experiment: no weight traffic
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) wf[ks] = (f16x8)(f16)(0.001f * (float)(lane + ks));
-    } else {
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) wf[ks] = *(const f16x8 *)(wp + ks * 32);
-    }
-
+    // Issue order = arrival order (loads return in order): the activation tile first (L2-resident: the previous launch
+    // wrote it), then every weight fragment of the slice (HBM, ~4 us of latency for a cold 3-13 MB panel set -- measured:
+    // profiles/r02_dec_ablation.csv), then the epilogue's operands.  Only the DMA is waited for before the barrier; the
+    // LayerNorm statistics and the MFMA loop then run UNDER the weight latency, each k-step waiting for its own fragment.
     // ---- activation tile -> LDS by LDS-DMA; instruction q writes LDS bytes [q*1024, q*1024 + 1024)
-    if (!(g.abl & 2)) {
+    {
         constexpr int n_instr = (MT * 16 * SPR) >> 6;      // = MT * NKS, a multiple of 4
 #pragma unroll
         for (int j = 0; j < n_instr / 4; ++j) {
@@ -84,11 +81,42 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             __builtin_amdgcn_global_load_lds(src, (lds_void *)(smem + q * 1024), 16, 0, 0);
         }
     }
-    __syncthreads();          // drains the DMA (and the weight loads): one round trip per launch
+    // ---- weights of this wave's 16 columns: every fragment of the slice in flight at once (HBM, or L2 behind a sibling)
+    const int ncol = panel * 64 + wave * 16 + li;
+    const f16 *wp = g.W + (size_t)(ncol < g.N ? ncol : g.N - 1) * g.ldw + k0 + lg * 8;
+    // The loads are inline asm so that hipcc does not count them: with an LDS-DMA in flight it waits vmcnt(0) at the first
+    // use of any ordinary load result (cdna_hip_programming.md 5, trap (b)), i.e. the whole weight stream would have to land
+    // before the first MFMA.  Their completion is counted by hand below: k-step ks waits until at most (NKS - 1 - ks) weight
+    // loads + the epilogue loads issued after them are pending.  (Audit after any edit: no compiler v_mov / spill of wf[]
+    // between the load and its wait in the .s -- 5.7 item 1.)
+    f16x8 wf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(wf[ks]) : "v"(wp), "n"(ks * 64) : "memory");
+    // ---- epilogue operands (clamped addresses, never predicated): column constants and the residual rows
+    constexpr int N_EPI = (E_SLAB ? 0 : 1) + (E_LN ? 1 : 0) + ((E_RES && !E_SLAB) ? MT : 0);   // loads younger than the weights
+    const int n = panel * 64 + wave * 16 + lg * 4;
+    const int nc = n < g.N ? n : g.N - 4;
+    f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (!E_SLAB) c2 = *(const f32x4 *)(g.c2 + nc);
+    if constexpr (E_LN) c1 = *(const f32x4 *)(g.c1 + nc);
+    f16x4 xres[MT];
+    if constexpr (E_RES && !E_SLAB) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = r0 + t * 16 + li;
+            xres[t] = *(const f16x4 *)(g.X + (size_t)(m < g.M ? m : g.M - 1) * g.ldx + nc);
+        }
+    }
+    {
+        // the DMA instructions are the oldest: they have landed once at most (weights + epilogue loads) younger loads are pending
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS + N_EPI) : "memory");
+        __builtin_amdgcn_s_barrier();
+    }
 
     // ---- LayerNorm statistics of the tile's rows (complete rows: K == kslice == d), 16 lanes per row
     float2 *stat = (float2 *)(smem + (size_t)MT * 16 * RS);
-    if ((g.epi & DEC_LN) && !(g.abl & 4)) {
+    if constexpr (E_LN) {
         const f16x2 one2 = {(f16)1.f, (f16)1.f};
         for (int rb = wave * 4 + lg; rb < MT * 16; rb += 16) {
             const unsigned char *rp = smem + (size_t)rb * RS + li * 16;
@@ -111,7 +139,11 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
                 const float mean = s1 * inv;
                 float var = s2 * inv - mean * mean;
                 var = var > 0.f ? var : 0.f;
-                stat[rb] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+                // inline asm store: an LDS store the compiler can see is ordered behind the LDS-DMA it believes to be pending
+                // (it would wait vmcnt(0) here, i.e. for the whole weight stream)
+                const float2 sv = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+                const unsigned lds_addr = (unsigned)(uintptr_t)(lds_void *)(stat + rb);
+                asm volatile("ds_write_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" ::"v"(lds_addr), "v"(sv) : "memory");
             }
         }
     }
@@ -129,16 +161,14 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
         const int phys = (ks * 4 + lg) ^ li;
         return *(const f16x8 *)(abase + (size_t)t * 16 * RS + phys * 16);
     };
-    if (g.abl & 8) {                       // experiment: no MFMA phase (keeps the weight fragments live)
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) acc[0][ks & 3] += (float)wf[ks][0];
-    } else {
 #pragma unroll
     for (int ks = 0; ks < PF; ++ks)
 #pragma unroll
         for (int t = 0; t < MT; ++t) af[ks][t] = lds_frag(ks, t);
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
+        // this k-step's weight fragment has landed once no more than the younger loads are pending (counter is 6 bits wide)
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf[ks]) : "n"((NKS - 1 - ks) + N_EPI) : "memory");
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[ks % PF][t], acc[t], 0, 0, 0);
@@ -146,14 +176,11 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
         }
         __builtin_amdgcn_sched_barrier(0);        // keeps the prefetch PF steps ahead (the scheduler sinks it back otherwise)
     }
-    }
-    if (g.epi & DEC_LN) __syncthreads();          // stat[] visible to every wave
+    if constexpr (E_LN) __syncthreads();          // stat[] visible to every wave
 
     // ---- epilogue: lane holds columns n .. n+3 of row m for every tile
-    const int n = panel * 64 + wave * 16 + lg * 4;
     if (n >= g.N) return;                          // N % 4 == 0 is checked by the launcher
-    if ((g.abl & 16) && acc[0][0] != 12345.678f) return;      // experiment: no epilogue
-    if (g.epi & DEC_SLAB) {
+    if constexpr (E_SLAB) {
         float *out = g.slabs + (size_t)ks_id * g.slab_stride;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -162,15 +189,12 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
         }
         return;
     }
-    const f32x4 c2 = *(const f32x4 *)(g.c2 + n);
-    f32x4 c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (g.epi & DEC_LN) c1 = *(const f32x4 *)(g.c1 + n);
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
         const int m = r0 + t * 16 + li;
         if (m >= g.M) continue;
         f32x4 v = acc[t];
-        if (g.epi & DEC_LN) {
+        if constexpr (E_LN) {
             const float2 st = stat[t * 16 + li];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = st.y * (v[e] - st.x * c1[e]) + c2[e];
@@ -178,17 +202,16 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += c2[e];
         }
-        if (g.epi & DEC_GELU) {
+        if constexpr (E_GELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
         }
         f16 *dst;
-        if (g.epi & DEC_RES) {
+        if constexpr (E_RES) {
             dst = g.X + (size_t)m * g.ldx + n;
-            const f16x4 xv = *(const f16x4 *)dst;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)xv[e];
-        } else if ((g.epi & DEC_QKV) && n >= g.d) {
+            for (int e = 0; e < 4; ++e) v[e] += (float)xres[t][e];
+        } else if (E_QKV && n >= g.d) {
             const int pos = g.pos0[m];
             f16 *cache = n < 2 * g.d ? g.kcache : g.vcache;
             dst = cache + ((size_t)m * g.n_ctx + pos) * g.d + (n < 2 * g.d ? n - g.d : n - 2 * g.d);
@@ -314,24 +337,30 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     const int grid = cdiv(units, 8) * g.n_rg * 8;
     const size_t lds = (size_t)mt * 16 * g.kslice * 2 + (size_t)mt * 16 * sizeof(float2);
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
-#define SWX_DEC(MT_, NK_) do { \
+    // the epilogues the decoder step uses (compile-time): QKV, out-projections, cross-q, MLP-in, MLP-out (split / un-split)
+    const int epi = g.epi & (DEC_LN | DEC_GELU | DEC_RES | DEC_QKV | DEC_SLAB);
+#define SWX_DEC(MT_, NK_, EP_) do { \
         static bool attr_done = false; \
         if (!attr_done) { \
-            hipError_t e_ = hipFuncSetAttribute((const void *)gemm_dec_f16<MT_, NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            hipError_t e_ = hipFuncSetAttribute((const void *)gemm_dec_f16<MT_, NK_, EP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
             if (e_ != hipSuccess) return -100 - (int)e_; \
             attr_done = true; \
         } \
-        hipLaunchKernelGGL((gemm_dec_f16<MT_, NK_>), dim3(grid), dim3(256), lds, s, g); } while (0)
-#define SWX_DEC_MT(NK_) do { if (mt == 1) SWX_DEC(1, NK_); else if (mt == 2) SWX_DEC(2, NK_); else SWX_DEC(3, NK_); } while (0)
-    switch (nks) {          // K-slice depths of the Whisper sizes: d = 384 / 512 / 768 / 1024 / 1280 and the halves of 4d that fit
-        case 12: SWX_DEC_MT(12); break;
-        case 16: SWX_DEC_MT(16); break;
-        case 20: SWX_DEC_MT(20); break;
-        case 24: SWX_DEC_MT(24); break;
-        case 32: SWX_DEC_MT(32); break;
-        case 40: SWX_DEC_MT(40); break;
+        hipLaunchKernelGGL((gemm_dec_f16<MT_, NK_, EP_>), dim3(grid), dim3(256), lds, s, g); } while (0)
+#define SWX_DEC_MT(NK_, EP_) do { if (mt == 1) SWX_DEC(1, NK_, EP_); else if (mt == 2) SWX_DEC(2, NK_, EP_); else SWX_DEC(3, NK_, EP_); } while (0)
+#define SWX_DEC_NK(EP_) do { switch (nks) { \
+        case 12: SWX_DEC_MT(12, EP_); break; case 16: SWX_DEC_MT(16, EP_); break; case 20: SWX_DEC_MT(20, EP_); break; \
+        case 24: SWX_DEC_MT(24, EP_); break; case 32: SWX_DEC_MT(32, EP_); break; case 40: SWX_DEC_MT(40, EP_); break; \
+        default: return -4; } } while (0)
+    switch (epi) {          // K-slice depths: d = 384 / 512 / 768 / 1024 / 1280 of the Whisper sizes and the pieces of 4d that fit
+        case DEC_LN | DEC_QKV: SWX_DEC_NK(DEC_LN | DEC_QKV); break;
+        case DEC_RES: SWX_DEC_NK(DEC_RES); break;
+        case DEC_LN: SWX_DEC_NK(DEC_LN); break;
+        case DEC_LN | DEC_GELU: SWX_DEC_NK(DEC_LN | DEC_GELU); break;
+        case DEC_RES | DEC_SLAB: SWX_DEC_NK(DEC_RES | DEC_SLAB); break;
         default: return -4;
     }
+#undef SWX_DEC_NK
 #undef SWX_DEC_MT
 #undef SWX_DEC
     SWX_CHECK_LAUNCH();

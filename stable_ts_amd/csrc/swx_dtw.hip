@@ -22,29 +22,29 @@
 //     8-column words (one LDS read per 8 columns or lane change instead of one dependent memory load per path step).
 //     Longer token axes (R = 5..7, N <= 448) keep the trace in global memory in the same lane-major layout.
 #include <type_traits>
+#include <cstdlib>
 #include "swx_common.h"
 #include "swx_kernels.h"
 
 namespace {
 
-constexpr int DTW_CH = 16;            // steps per chunk (one barrier per chunk)
-constexpr int DTW_RING = 32;          // ring slots = 2 chunks: the chunk being swept + the chunk being written
-
-__host__ __device__ constexpr int dtw_lane_stride(int R)      // dwords between two lanes' rings; see the bank notes above
+// DTW_CH steps per chunk (one barrier per chunk); ring slots = 2 chunks: the chunk being swept + the chunk being written
+__host__ __device__ constexpr int dtw_lane_stride(int R, int RING)      // dwords between two lanes' rings; see the bank notes above
 {
-    return DTW_RING * R + (R == 4 ? 4 : (R == 2 ? 2 : 1));
+    return RING * R + (R == 4 ? 4 : (R == 2 ? 2 : 1));
 }
 
-template <int R, bool TLDS>
+template <int R, bool TLDS, int DTW_CH>
 __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ x_all, int ld_n, int ld_m,
                                                       const int *__restrict__ Nw, const int *__restrict__ Mw,
                                                       int *__restrict__ text_idx, int *__restrict__ time_idx,
                                                       int *__restrict__ out_len, unsigned char *__restrict__ ws_all,
-                                                      size_t ws_stride, int TP)
+                                                      size_t ws_stride, int TP, int abl)
 {
+    constexpr int DTW_RING = 2 * DTW_CH;
     typedef typename std::conditional<(R <= 4), unsigned char, unsigned short>::type TT;    // one column's moves of a lane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LS = dtw_lane_stride(R);
+    constexpr int LS = dtw_lane_stride(R, DTW_RING);
     float *xs = (float *)smem;                                   // [64][LS]: slot s of lane l at l*LS + (s % RING)*R + r
     TT *tr_lds = (TT *)(smem + (size_t)64 * LS * 4);             // [64][TP] (TLDS only)
     const int w = blockIdx.x;
@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = (tid - 64) + 192 * i;
-            const int row = e >> 4, s = t0 + (e & 15);
+            const int row = e / DTW_CH, s = t0 + (e % DTW_CH);
             const int j = s - row / R;
             const bool ok = row < N && j >= 0 && j < M;
             // clamped address + select: a predicated load would be a branch with its own wait
-            const float v = x[(size_t)(row < N ? row : N - 1) * ld_m + (j < 0 ? 0 : (j < M ? j : M - 1))];
+            const float v = (abl & 2) ? 0.5f : x[(size_t)(row < N ? row : N - 1) * ld_m + (j < 0 ? 0 : (j < M ? j : M - 1))];
             lreg[i] = ok ? v : 0.f;
         }
     };
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = (tid - 64) + 192 * i;
-            const int row = e >> 4, s = t0 + (e & 15);
+            const int row = e / DTW_CH, s = t0 + (e % DTW_CH);
             if (row < 64 * R) xs[(row / R) * LS + (s % DTW_RING) * R + (row % R)] = lreg[i];
         }
     };
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
     if (wave > 0) { issue_loads(0); store_lds(0); if (nchunks > 1) issue_loads(1); }
     __syncthreads();
     for (int k = 0; k < nchunks; ++k) {
-        if (wave == 0) {
+        if (wave == 0 && !(abl & 4)) {
             const int t_end = (k + 1) * DTW_CH < steps ? (k + 1) * DTW_CH : steps;
             int t = k * DTW_CH;
             float xv[R], xn[R];
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
         __syncthreads();
     }
     if (wave > 0) return;
+    if (abl & 1) { if (lane == 0) out_len[w] = 0; return; }      // experiment: no backtrace
 
     // the trace plane must be visible to the walk (LDS: the barrier above; global: same wave, program order + fence)
     if (!TLDS) __threadfence_block();
@@ -215,17 +216,20 @@ extern "C" int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_
     const size_t per = swx_dtw_workspace_bytes(1, ld_n, ld_m);
     const int R = (ld_n + 63) / 64;
     const int TP = dtw_tp(ld_m);
-#define SWX_DTW_LAUNCH(RR, TL) do { \
-        const size_t lds = (size_t)64 * dtw_lane_stride(RR) * 4 + ((TL) ? (size_t)64 * TP * (RR <= 4 ? 1 : 2) : 0); \
+    static const int abl = [] { const char *e = getenv("SWX_DTW_ABL"); return e ? atoi(e) : 0; }();
+    static const int ch = [] { const char *e = getenv("SWX_DTW_CH"); return e ? atoi(e) : 16; }();
+#define SWX_DTW_LAUNCH2(RR, TL, CH_) do { \
+        const size_t lds = (size_t)64 * dtw_lane_stride(RR, 2 * CH_) * 4 + ((TL) ? (size_t)64 * TP * (RR <= 4 ? 1 : 2) : 0); \
         static bool attr_done = false; \
         if (!attr_done) { \
-            hipError_t e_ = hipFuncSetAttribute((const void *)swx_dtw_kernel<RR, TL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            hipError_t e_ = hipFuncSetAttribute((const void *)swx_dtw_kernel<RR, TL, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
             if (e_ != hipSuccess) return -100 - (int)e_; \
             attr_done = true; \
         } \
         if (lds > 160 * 1024 - 1024) return -2; \
-        hipLaunchKernelGGL((swx_dtw_kernel<RR, TL>), dim3(W), dim3(256), lds, s, d_x, ld_n, ld_m, d_N, d_M, d_text_idx, d_time_idx, \
-                           d_len, (unsigned char *)d_trace_ws, per, TP); } while (0)
+        hipLaunchKernelGGL((swx_dtw_kernel<RR, TL, CH_>), dim3(W), dim3(256), lds, s, d_x, ld_n, ld_m, d_N, d_M, d_text_idx, d_time_idx, \
+                           d_len, (unsigned char *)d_trace_ws, per, TP, abl); } while (0)
+#define SWX_DTW_LAUNCH(RR, TL) do { if (ch == 32 && RR <= 4) SWX_DTW_LAUNCH2(RR, TL, 32); else SWX_DTW_LAUNCH2(RR, TL, 16); } while (0)
     switch (R) {
         case 1: SWX_DTW_LAUNCH(1, true); break;
         case 2: SWX_DTW_LAUNCH(2, true); break;
@@ -236,6 +240,7 @@ extern "C" int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_
         default: SWX_DTW_LAUNCH(7, false); break;
     }
 #undef SWX_DTW_LAUNCH
+#undef SWX_DTW_LAUNCH2
     SWX_CHECK_LAUNCH();
     return 0;
 }
