@@ -20,8 +20,8 @@ def main():
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     rnd = lambda *s: (torch.randn(*s, device=dev) * 0.05).half()
     M, d = int(os.environ.get("DEC_M", "100")), 1280
-    for name, N, K, epi in [("qkv", 3840, 1280, 1 | 8 | 32), ("attn-out", 1280, 1280, 4), ("cross-q", 1280, 1280, 1 | 32),
-                            ("mlp-1", 5120, 1280, 1 | 2 | 32), ("mlp-2", 1280, 5120, 4 | 16)]:
+    for name, N, K, epi in [("qkv", 3840, 1280, 1 | 8 | 32), ("attn-out", 1280, 1280, 4 | 32), ("cross-q", 1280, 1280, 1 | 32),
+                            ("mlp-1", 5120, 1280, 1 | 2 | 32), ("mlp-2", 1280, 5120, 4 | 16 | 32)]:
         ws = [rnd(N, K) for _ in range(max(2, int(400e6 / (N * K * 2)) + 1))]
         a = rnd(M, K)
         c = torch.empty(M, N if not (epi & 8) else d, dtype=torch.half, device=dev)

@@ -87,8 +87,8 @@ def main():
         print(f"-- decode-step GEMMs, third generation (un-split dec kernels), M=100  SWX_DEC_POLICY={os.environ.get('SWX_DEC_POLICY')}")
         M, d = 100, 1280
         tot = 0.0
-        for name, N, K, epi in [("qkv (LN fold + scatter)", 3840, 1280, 1 | 8 | 32), ("attn-out (+x)", 1280, 1280, 4), ("cross-q (LN fold)", 1280, 1280, 1 | 32),
-                                ("cross-out (+x)", 1280, 1280, 4), ("mlp-1 (LN fold + GELU)", 5120, 1280, 1 | 2 | 32), ("mlp-2 (+x, K=4d)", 1280, 5120, 4 | 16)]:
+        for name, N, K, epi in [("qkv (LN fold + scatter)", 3840, 1280, 1 | 8 | 32), ("attn-out (+x)", 1280, 1280, 4 | 32), ("cross-q (LN fold)", 1280, 1280, 1 | 32),
+                                ("cross-out (+x)", 1280, 1280, 4 | 32), ("mlp-1 (LN fold + GELU)", 5120, 1280, 1 | 2 | 32), ("mlp-2 (+x, K=4d)", 1280, 5120, 4 | 16 | 32)]:
             a, ws = rnd(M, K), weight_copies(rnd, N, K)
             c = torch.empty(M, N if not (epi & 8) else d, dtype=torch.half, device=dev)
             x = rnd(M, N if not (epi & 8) else d)

@@ -81,18 +81,21 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             __builtin_amdgcn_global_load_lds(src, (lds_void *)(smem + q * 1024), 16, 0, 0);
         }
     }
-    // ---- weights of this wave's 16 columns: every fragment of the slice in flight at once (HBM, or L2 behind a sibling)
-    const int ncol = panel * 64 + wave * 16 + li;
-    const f16 *wp = g.W + (size_t)(ncol < g.N ? ncol : g.N - 1) * g.ldw + k0 + lg * 8;
+    // ---- weights of this wave's 16 columns: every fragment of the slice in flight at once (HBM, or L2 behind a sibling).
+    //      The weights are stored PRE-PACKED in MFMA-fragment order (swx_fold_ln at load time): the 1 KB block of
+    //      (16-column group, k-step) holds lane l's 16 bytes at l*16, so a wave instruction reads 8 full 128-byte lines.
+    //      (Row-major [N][K] weights make every instruction touch 16 separate 64-byte row pieces: the per-CU address /
+    //      L1 path, not HBM, bounded the first version of this kernel -- hot or cold weights cost the same ~4 us.)
+    const f16 *wp = g.W + ((size_t)(panel * 4 + wave) * (g.K >> 5) + (size_t)ks_id * NKS) * 512 + lane * 8;
     // The loads are inline asm so that hipcc does not count them: with an LDS-DMA in flight it waits vmcnt(0) at the first
     // use of any ordinary load result (cdna_hip_programming.md 5, trap (b)), i.e. the whole weight stream would have to land
     // before the first MFMA.  Their completion is counted by hand below: k-step ks waits until at most (NKS - 1 - ks) weight
-    // loads + the epilogue loads issued after them are pending.  (Audit after any edit: no compiler v_mov / spill of wf[]
-    // between the load and its wait in the .s -- 5.7 item 1.)
+    // loads + the epilogue loads issued after them are pending.  (Audited by tests/test_kernel_isa_cpu.py: no compiler
+    // v_mov / spill of wf[] between a load and its wait -- 5.7 item 1.)
     f16x8 wf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(wf[ks]) : "v"(wp), "n"(ks * 64) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(wf[ks]) : "v"(wp + (ks >> 2) * 2048), "n"((ks & 3) * 1024) : "memory");
     // ---- epilogue operands (clamped addresses, never predicated): column constants and the residual rows
     constexpr int N_EPI = (E_SLAB ? 0 : 1) + (E_LN ? 1 : 0) + ((E_RES && !E_SLAB) ? MT : 0);   // loads younger than the weights
     const int n = panel * 64 + wave * 16 + lg * 4;
@@ -250,21 +253,26 @@ __global__ __launch_bounds__(256) void dec_slab_finish(const float *__restrict__
     *(f16x4 *)xp = o;
 }
 
-// load time: Wf[n][k] = f16(W[n][k] * gamma[k]);  c1[n] = sum_k Wf[n][k];  c2[n] = bias[n] + sum_k beta[k] * W[n][k]
-__global__ __launch_bounds__(256) void fold_ln_kernel(const f16 *__restrict__ W, const float *__restrict__ gamma,
-                                                      const float *__restrict__ beta, const float *__restrict__ bias,
-                                                      f16 *__restrict__ Wf, float *__restrict__ c1, float *__restrict__ c2, int K)
+// load time: Wp = pack(f16(W[n][k] * gamma[k]));  c1[n] = sum_k Wf[n][k];  c2[n] = bias[n] + sum_k beta[k] * W[n][k]
+// (gamma == null: plain re-pack, c1 / c2 untouched).  Packed layout: [N/16][K/32][64 lanes][8 halfs] with
+// lane = ((k % 32) / 8) * 16 + n % 16 -- the operand fragment order of v_mfma_f32_16x16x32_f16.
+__global__ __launch_bounds__(256) void fold_pack_kernel(const f16 *__restrict__ W, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, const float *__restrict__ bias,
+                                                        f16 *__restrict__ Wp, float *__restrict__ c1, float *__restrict__ c2, int K)
 {
     __shared__ float sh[2][4];
     const int n = blockIdx.x;
     float s1 = 0.f, s2 = 0.f;
+    const size_t grp = (size_t)(n >> 4) * (K >> 5);
     for (int k = threadIdx.x; k < K; k += 256) {
         const float w = (float)W[(size_t)n * K + k];
-        const f16 wf = (f16)(w * gamma[k]);
-        Wf[(size_t)n * K + k] = wf;
+        const f16 wf = gamma ? (f16)(w * gamma[k]) : (f16)w;
+        const int ks = k >> 5, lane = ((k & 31) >> 3) * 16 + (n & 15);
+        Wp[((grp + ks) * 64 + lane) * 8 + (k & 7)] = wf;
         s1 += (float)wf;
-        s2 += beta[k] * w;
+        if (beta) s2 += beta[k] * w;
     }
+    if (!gamma) return;
     s1 = wave_sum(s1); s2 = wave_sum(s2);
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
     __syncthreads();
@@ -323,7 +331,7 @@ size_t swx_dec_slab_floats(int M, int N, int K)
 int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
 {
     if (g.M <= 0 || g.N <= 0) return 0;
-    if (g.lda % 8 != 0 || g.ldw % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return -4;
+    if (g.lda % 8 != 0 || ((uintptr_t)g.A & 15) || ((uintptr_t)g.W & 15)) return -4;      // g.W: packed (swx_fold_ln)
     int mt = 1, ks2 = 1;
     { const int rc = swx_dec_plan(g.M, g.N, g.K, g.epi, &mt, &ks2); if (rc < 0) return rc; }
     if (ks2 > 1 && !g.slabs) return -4;
@@ -336,6 +344,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     const int units = (g.N / 64) * ks2;
     const int grid = cdiv(units, 8) * g.n_rg * 8;
     const size_t lds = (size_t)mt * 16 * g.kslice * 2 + (size_t)mt * 16 * sizeof(float2);
+    {   // (profiler scopes must not nest: each one closes the most recent record)
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
     // the epilogues the decoder step uses (compile-time): QKV, out-projections, cross-q, MLP-in, MLP-out (split / un-split)
     const int epi = g.epi & (DEC_LN | DEC_GELU | DEC_RES | DEC_QKV | DEC_SLAB);
@@ -363,6 +372,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
 #undef SWX_DEC_NK
 #undef SWX_DEC_MT
 #undef SWX_DEC
+    }
     SWX_CHECK_LAUNCH();
     if (ks2 > 1) {
         // the one K-split projection: x += bias + sum of slabs
@@ -382,7 +392,8 @@ int swx_fold_ln(const void *W, const float *gamma, const float *beta, const floa
                 int N, int K, hipStream_t s)
 {
     if (N <= 0 || K <= 0) return 0;
-    hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, (const f16 *)W, gamma, beta, bias, (f16 *)Wf, c1, c2, K);
+    if (N % 16 != 0 || K % 32 != 0) return -4;
+    hipLaunchKernelGGL(fold_pack_kernel, dim3(N), dim3(256), 0, s, (const f16 *)W, gamma, beta, bias, (f16 *)Wf, c1, c2, K);
     SWX_CHECK_LAUNCH();
     return 0;
 }

@@ -54,8 +54,6 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
     const float *__restrict__ x = x_all + (size_t)w * ld_n * ld_m;
     unsigned char *wsw = ws_all + (size_t)w * ws_stride;
     TT *tr = TLDS ? tr_lds : (TT *)wsw;                          // trace plane, lane-major, pitch TP
-    int *tmp_t = (int *)(wsw + (size_t)64 * TP * sizeof(unsigned short));
-    int *tmp_f = tmp_t + cap;
     int *o_t = text_idx + (size_t)w * cap;
     int *o_f = time_idx + (size_t)w * cap;
 
@@ -162,11 +160,14 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
     // ---- backtrace: every lane of wave 0 walks the same path (uniform control flow, broadcast reads); lane 0 records it.
     //      The moves of 8 (byte trace) or 4 (short trace) consecutive columns of one lane travel in one 64-bit word.
     constexpr int WCOLS = 8 / (int)sizeof(TT);
+    //      The path is collected in LDS (the x ring is free once the sweep is over; N + M <= 1948 packed entries fit the
+    //      smallest ring) and written out in forward order by all lanes at the end.
+    unsigned *path = (unsigned *)smem;
     int i = N, j = M, n = 0;
     int cur_lane = -1, cur_blk = -1;
     unsigned long long word = 0;
     while (i > 0 || j > 0) {
-        if (lane == 0) { tmp_t[n] = i - 1; tmp_f[n] = j - 1; }
+        if (lane == 0) path[n] = (unsigned)(i - 1) | ((unsigned)(j - 1) << 16);       // (-1 wraps to 0xFFFF: decoded below)
         ++n;
         unsigned mv;
         if (i == 0) mv = 2u;
@@ -181,15 +182,18 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
             const unsigned wd = (unsigned)(word >> ((col - blk * WCOLS) * 8 * (int)sizeof(TT))) & (sizeof(TT) == 1 ? 0xFFu : 0xFFFFu);
             mv = (wd >> (2 * rr)) & 3u;
         }
+        // the walk is wave-uniform: telling the compiler so keeps (i, j) and the loop's branches on the scalar unit
+        mv = (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
         if (mv == 0u) { --i; --j; }
         else if (mv == 1u) { --i; }
         else { --j; }
     }
-    __threadfence_block();
-    __builtin_amdgcn_s_waitcnt(0);        // lane 0's path stores before the other lanes read them back (one wave: program order)
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): lane 0's LDS stores before the other lanes read them (one wave)
     for (int p = lane; p < n; p += 64) {
-        o_t[p] = tmp_t[n - 1 - p];
-        o_f[p] = tmp_f[n - 1 - p];
+        const unsigned e = path[n - 1 - p];
+        const int a = (int)(e & 0xFFFFu), b = (int)(e >> 16);
+        o_t[p] = a == 0xFFFF ? -1 : a;
+        o_f[p] = b == 0xFFFF ? -1 : b;
     }
     if (lane == 0) out_len[w] = n;
 }

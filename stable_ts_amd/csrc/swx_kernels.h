@@ -72,7 +72,7 @@ int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, i
 #define DEC_SLAB 16     // K-split allowed: f32 partials to slabs + dec_slab_finish (needs DEC_RES)
 struct DecGemmArgs {
     const _Float16 *A; int64_t lda;      // [M][K]
-    const _Float16 *W; int64_t ldw;      // [N][K]
+    const _Float16 *W; int64_t ldw;      // PACKED weights (swx_fold_ln: [N/16][K/32][64][8], MFMA fragment order); ldw unused
     int M, N, K;
     int epi;
     const float *c2;                     // [N] bias (or folded bias with DEC_LN)
@@ -87,7 +87,8 @@ struct DecGemmArgs {
 int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation
 size_t swx_dec_slab_floats(int M, int N, int K);
 int swx_gemm_dec(DecGemmArgs g, hipStream_t s);
-// load-time LayerNorm fold: Wf = f16(W * gamma), c1[n] = sum_k Wf[n][k], c2[n] = bias[n] + sum_k beta[k] W[n][k]
+// load-time LayerNorm fold + re-pack into MFMA fragment order: Wf = pack(f16(W * gamma)), c1[n] = sum_k Wf[n][k],
+// c2[n] = bias[n] + sum_k beta[k] W[n][k];  gamma == null: plain re-pack of W (c1 / c2 untouched)
 int swx_fold_ln(const void *W, const float *gamma, const float *beta, const float *bias, void *Wf, float *c1, float *c2,
                 int N, int K, hipStream_t s);
 

@@ -29,7 +29,8 @@ struct LayerW {
     size_t lnx_g, lnx_b, wcq, bcq, wckv, bckv, wco, bco;   // decoder only
     size_t ln2_g, ln2_b, w1, b1, w2, b2;
     // decoder, f16: LayerNorm-folded copies for the third-generation decode step (swx_decstep.hip): W.gamma, c1, c2
-    size_t wqkv_f, qkv_c1, qkv_c2, wcq_f, cq_c1, cq_c2, w1_f, w1_c1, w1_c2;
+    size_t wqkv_f, qkv_c1, qkv_c2, wcq_f, cq_c1, cq_c2, w1_f, w1_c1, w1_c2;     // folded + packed in MFMA fragment order
+    size_t wo_p, wco_p, w2_p;                                                   // packed copies of the other three
 };
 
 size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -156,6 +157,7 @@ void build_layout(swx_model *m)
                 w.wqkv_f = reserve((size_t)3 * dt * dt * e); w.qkv_c1 = reserve((size_t)3 * dt * 4); w.qkv_c2 = reserve((size_t)3 * dt * 4);
                 w.wcq_f = reserve((size_t)dt * dt * e); w.cq_c1 = reserve((size_t)dt * 4); w.cq_c2 = reserve((size_t)dt * 4);
                 w.w1_f = reserve((size_t)4 * dt * dt * e); w.w1_c1 = reserve((size_t)4 * dt * 4); w.w1_c2 = reserve((size_t)4 * dt * 4);
+                w.wo_p = reserve((size_t)dt * dt * e); w.wco_p = reserve((size_t)dt * dt * e); w.w2_p = reserve((size_t)4 * dt * dt * e);
             }
     }
     m->o_ln_g = vec("decoder.ln.weight", dt);
@@ -427,7 +429,7 @@ int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
         SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
         // x += att Wo^T + bo
         g = DecGemmArgs{};
-        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
         SWX_TRY(swx_gemm_dec(g, s));
         // cross-attention query = LNx(x) Wcq^T + b
@@ -442,7 +444,7 @@ int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
         ca.B = f.W; ca.H = H; ca.nq = f.rpw; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw;
         SWX_TRY(swx_attention(m->dtype, ca, 0, s));
         g = DecGemmArgs{};
-        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bco); g.X = x; g.ldx = d;
         SWX_TRY(swx_gemm_dec(g, s));
         // MLP
@@ -451,7 +453,7 @@ int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
         g.c1 = m->A<float>(w.w1_c1); g.c2 = m->A<float>(w.w1_c2); g.C = u; g.ldc = 4 * d;
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
-        g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
+        g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
         g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
         SWX_TRY(swx_gemm_dec(g, s));
     }
@@ -608,6 +610,7 @@ int swx_prof_collect(double *out, int n_classes)
     }
     g_prof.clear();
     g_pool_next = 0;
+    (void)hipGetLastError();      // a failed elapsed-time query must not surface later as somebody else's launch error
     return PC_COUNT;
 }
 
@@ -738,6 +741,9 @@ int swx_weights_finalize(swx_model *m, void *stream)
                             m->A<float>(w.cq_c1), m->A<float>(w.cq_c2), d, d, s));
         SWX_TRY(swx_fold_ln(m->arena + w.w1, m->A<float>(w.ln2_g), m->A<float>(w.ln2_b), m->A<float>(w.b1), m->arena + w.w1_f,
                             m->A<float>(w.w1_c1), m->A<float>(w.w1_c2), 4 * d, d, s));
+        SWX_TRY(swx_fold_ln(m->arena + w.wo, nullptr, nullptr, nullptr, m->arena + w.wo_p, nullptr, nullptr, d, d, s));
+        SWX_TRY(swx_fold_ln(m->arena + w.wco, nullptr, nullptr, nullptr, m->arena + w.wco_p, nullptr, nullptr, d, d, s));
+        SWX_TRY(swx_fold_ln(m->arena + w.w2, nullptr, nullptr, nullptr, m->arena + w.w2_p, nullptr, nullptr, d, 4 * d, s));
     }
     m->folded = true;
     return 0;
@@ -1230,8 +1236,11 @@ int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float
     } else if (epilogue & DEC_LN) {
         SWX_TRY(swx_fold_ln(d_w, d_gamma, d_beta, d_bias, wf, c1, c2, N, K, s));
         g.W = wf; g.c1 = c1; g.c2 = c2;
-    } else {
+    } else if (epilogue & 32) {                       // timing runs: d_w is taken as packed already
         g.W = (const f16 *)d_w; g.c2 = d_bias;
+    } else {
+        SWX_TRY(swx_fold_ln(d_w, nullptr, nullptr, nullptr, wf, nullptr, nullptr, N, K, s));      // re-pack only
+        g.W = wf; g.c2 = d_bias;
     }
     return swx_gemm_dec(g, s);
 }

@@ -1,0 +1,99 @@
+"""ISA-level audit of the decode-step "dec" GEMM (csrc/swx_decstep.hip), run on the cross-compiled gfx950 assembly (no GPU).
+
+The kernel hides its weight loads from hipcc in inline asm and counts their completion by hand (so that the MFMA loop can
+start while the weight stream is still landing; with an LDS-DMA in flight hipcc would otherwise wait vmcnt(0) at the first
+use of any load result).  What hipcc does NOT do for an asm statement (cdna_hip_programming.md 5.7) is checked here after
+every build instead of by eye:
+  1. no compiler-generated instruction reads or writes a register that an asm load targets before that register's own
+     counted wait (a v_mov / spill of a not-yet-landed register would silently compute on garbage);
+  2. between the first barrier (activation tile landed) and the last MFMA there is no `s_waitcnt vmcnt(0)`: the weight stream
+     is consumed fragment by fragment, not drained;
+  3. no scratch (spill) traffic in any instantiation.
+"""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+@pytest.fixture(scope="module")
+def asm_text():
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not present")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(ROOT, "stable_ts_amd", "csrc", "swx_decstep.hip")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", src, "-o", os.path.join(td, "dec.s")], cwd=td)
+        return open(os.path.join(td, "dec.s")).read()
+
+
+def _kernels(text):
+    out, cur, name = {}, None, None
+    for ln in text.split("\n"):
+        m = re.match(r"^(_ZN\S*gemm_dec_f16\S*):", ln)
+        if m:
+            name, cur = m.group(1), []
+            continue
+        if cur is not None:
+            cur.append(ln)
+            if "s_endpgm" in ln:
+                out[name] = cur
+                cur = None
+    return out
+
+
+def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
+    kernels = _kernels(asm_text)
+    assert len(kernels) >= 60, len(kernels)          # 6 depths x 3 row-tile counts x 5 epilogues, minus nothing
+    for name, lines in kernels.items():
+        pending, in_asm, nload, first_barrier, last_mfma, drains = {}, False, 0, None, None, []
+        for i, ln in enumerate(lines):
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if t.startswith("s_barrier") and first_barrier is None:
+                first_barrier = i
+            if t.startswith("v_mfma"):
+                last_mfma = i
+            if "scratch_" in t:
+                pytest.fail(f"{name}: scratch traffic: {t}")
+            if in_asm and t.startswith("global_load_dwordx4"):
+                for r in _regs(t.split()[1].rstrip(",")):
+                    pending[r] = nload
+                nload += 1
+                continue
+            if in_asm and t.startswith("s_waitcnt vmcnt") and pending:
+                oldest = min(pending.values())       # the waits are issued in load order, one fragment per wait
+                for r in [r for r, k in pending.items() if k == oldest]:
+                    del pending[r]
+                continue
+            if not in_asm and t.startswith("s_waitcnt") and "vmcnt(0)" in t:
+                drains.append(i)
+            if not in_asm and pending and t and not t.startswith((";", ".")):
+                used = set()
+                for tk in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+                    used |= _regs(tk)
+                hit = used & set(pending)
+                assert not hit, f"{name}: line {i}: `{t}` touches asm-loaded registers {sorted(hit)[:4]} before their wait"
+        assert nload in (12, 16, 20, 24, 32, 40), (name, nload)
+        assert not pending, (name, len(pending))
+        assert first_barrier is not None and last_mfma is not None and first_barrier < last_mfma, name
+        early = [d for d in drains if d < last_mfma]
+        assert not early, f"{name}: s_waitcnt vmcnt(0) before the last MFMA (lines {early[:3]}): the weight stream is drained"
