@@ -119,6 +119,13 @@ typedef struct swx_decode_cfg {
     int32_t min_tokens;           /* >0: EOT is suppressed until this many tokens were sampled (synthetic-weights
                                      benchmarking only; 0 = reference behaviour) */
     uint64_t seed;                /* sampling RNG seed (temperature > 0) */
+    const int32_t *window_uid;    /* HOST array [W] or NULL: a stable identity of every window (e.g. its seek position).
+                                     Sampling contract (temperature > 0): the draw of a sequence is a counter-based hash of
+                                     (seed, window uid, slot within the window's group, step, token id) -- Gumbel-max over the
+                                     filtered logits / T, i.e. a Categorical(logits / T) sample like upstream's GreedyDecoder,
+                                     but NOT torch's Philox stream: a T > 0 retry is reproducible for a given (seed, uid)
+                                     whatever the batch it is decoded in, and is not token-identical with the reference's.
+                                     NULL: the window's index in this job is its uid. */
 } swx_decode_cfg;
 
 /* runs the whole loop; outputs (device):

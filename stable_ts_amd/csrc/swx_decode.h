@@ -24,6 +24,7 @@ struct DecodeBufs {
     float *logits;             // [M][V] f32
     const int32_t *suppress;   // [n_suppress]
     const uint8_t *ts_mask;    // [W][1501] or null
+    const int32_t *win_uid;    // [W] stable window identities for the sampling RNG, or null (= window index)
 };
 
 int swx_decode_init(const DecodeBufs &b, const int32_t *init_tokens, hipStream_t s);

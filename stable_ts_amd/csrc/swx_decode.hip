@@ -160,7 +160,7 @@ __global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int 
 
     // ---- SuppressBlank / SuppressTokens / min_tokens
     if (c.suppress_blank && nsamp == 0 && tid == 0) { if (c.blank_token >= 0) lg[c.blank_token] = NEG_INF; lg[c.eot] = NEG_INF; }
-    for (int i = tid; i < c.n_suppress; i += SEL_T) lg[b.suppress[i]] = NEG_INF;
+    for (int i = tid; i < c.n_suppress; i += SEL_T) { const int t = b.suppress[i]; if ((unsigned)t < (unsigned)V) lg[t] = NEG_INF; }   // ids are range-checked on the host too
     if (c.min_tokens > 0 && nsamp < c.min_tokens && tid == 0) lg[c.eot] = NEG_INF;
     __syncthreads();
 
@@ -231,8 +231,11 @@ __global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int 
             for (int i = tid; i < V; i += SEL_T) { ArgMax x; x.v = lg[i]; x.i = i; best = argmax_combine(best, x); }
         } else {
             const float invT = 1.0f / c.temperature;
+            // keyed on the window's stable identity, not on its row in this batch (fallback retries are decoded in
+            // whatever batch the pending windows form)
+            const unsigned row_uid = b.win_uid ? (unsigned)b.win_uid[r / b.G] * 0x9E3779B1u + (unsigned)(r % b.G) : (unsigned)r;
             for (int i = tid; i < V; i += SEL_T) {
-                ArgMax x; x.v = lg[i] * invT + gumbel(c.seed, (unsigned)r, (unsigned)step, (unsigned)i); x.i = i;
+                ArgMax x; x.v = lg[i] * invT + gumbel(c.seed, row_uid, (unsigned)step, (unsigned)i); x.i = i;
                 best = argmax_combine(best, x);
             }
         }

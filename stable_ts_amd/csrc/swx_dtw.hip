@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
     unsigned *path = (unsigned *)smem;
     int i = N, j = M, n = 0;
     int cur_lane = -1, cur_blk = -1;
-    unsigned long long word = 0;
+    unsigned w_lo = 0, w_hi = 0;          // the current 64-bit trace word, held in SCALAR registers
     while (i > 0 || j > 0) {
         if (lane == 0) path[n] = (unsigned)(i - 1) | ((unsigned)(j - 1) << 16);       // (-1 wraps to 0xFFFF: decoded below)
         ++n;
@@ -176,14 +176,17 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
             const int tl = (i - 1) / R, rr = (i - 1) - tl * R, col = j - 1;
             const int blk = col / WCOLS;
             if (tl != cur_lane || blk != cur_blk) {
-                word = *(const unsigned long long *)(tr + (size_t)tl * TP + blk * WCOLS);     // TP % 8 == 0: aligned
+                const unsigned long long word = *(const unsigned long long *)(tr + (size_t)tl * TP + blk * WCOLS);     // TP % 8 == 0
+                // the walk is wave-uniform: handing the word to the scalar unit keeps (i, j), the move extraction and every
+                // branch of the loop off the vector pipe (one VALU -> SALU transfer per 8 columns instead of one per step)
+                w_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)word);
+                w_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(word >> 32));
                 cur_lane = tl; cur_blk = blk;
             }
-            const unsigned wd = (unsigned)(word >> ((col - blk * WCOLS) * 8 * (int)sizeof(TT))) & (sizeof(TT) == 1 ? 0xFFu : 0xFFFFu);
+            const int sh = (col - blk * WCOLS) * 8 * (int)sizeof(TT);
+            const unsigned wd = (sh < 32 ? (w_lo >> sh) : (w_hi >> (sh - 32))) & (sizeof(TT) == 1 ? 0xFFu : 0xFFFFu);
             mv = (wd >> (2 * rr)) & 3u;
         }
-        // the walk is wave-uniform: telling the compiler so keeps (i, j) and the loop's branches on the scalar unit
-        mv = (unsigned)__builtin_amdgcn_readfirstlane((int)mv);
         if (mv == 0u) { --i; --j; }
         else if (mv == 1u) { --i; }
         else { --j; }

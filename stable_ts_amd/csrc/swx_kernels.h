@@ -38,7 +38,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_DEC_V3 512        // decode step on the un-split "dec" GEMMs (swx_decstep.hip) when the batch has enough rows
 #define SWX_FLAG_DEC_V3_FORCE 1024 // ... for every row count (tests)
 #define SWX_FLAG_GLDS_GEMM 256     // tiled f16 GEMM (encoder, cross-KV, scoring): direct-to-LDS operand staging (global_load_lds)
-#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q | SWX_FLAG_DEC_V3)
+#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q | SWX_FLAG_DEC_V3 | SWX_FLAG_GLDS_GEMM)
 int swx_flags();
 
 // split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:

@@ -64,7 +64,7 @@ struct swx_model {
         size_t melT, h1, x, h, qkv, att, u, gmax, small_i32, zeros_i32;
         size_t tokens0, tokens1, anc0, anc1, pos0, sum_lp, sum_lp_next, row_done, win_done, win_done_prev, n_done;
         size_t fin_tokens, fin_score, fin_len, fin_count, cand_lp, cand_tok, logits, hid2;
-        size_t kcache, vcache, sk, sv, cap, mean, sd, suppress, slabs, heads;
+        size_t kcache, vcache, sk, sv, cap, mean, sd, suppress, slabs, heads, win_uid;
         size_t total;
         int64_t rows_big, logits_rows;
     } L;
@@ -263,6 +263,7 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
     // the alignment-head list lives with the workspace, not with the weights: views that share one weight arena
     // (swx_bind_weights on the same buffer) may be configured with different heads
     L.heads = take(sizeof(int32_t) * (size_t)D.n_text_layer * D.n_text_head);
+    L.win_uid = take((size_t)Bmax * 4 + 256);
     L.total = cur;
 }
 
@@ -977,6 +978,17 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
         if (er != hipSuccess) return -100 - (int)er;
     }
     b.suppress = sup;
+    // every token id the filters write at must be a vocabulary id (upstream raises IndexError; here: size out of range)
+    for (int t : {cfg->eot, cfg->sot, cfg->timestamp_begin}) if (t < 0 || t >= D.n_vocab) return -2;
+    for (int t : {cfg->no_timestamps, cfg->no_speech, cfg->blank_token}) if (t < -1 || t >= D.n_vocab) return -2;
+    b.win_uid = nullptr;
+    if (cfg->window_uid) {
+        int32_t *d_uid = m->Wp<int32_t>(m->L.win_uid);
+        hipError_t eu = hipMemcpyAsync(d_uid, cfg->window_uid, (size_t)W * 4, hipMemcpyHostToDevice, s);
+        if (eu == hipSuccess) eu = hipStreamSynchronize(s);        // the caller's array may be freed when this call returns
+        if (eu != hipSuccess) return -100 - (int)eu;
+        b.win_uid = d_uid;
+    }
     hipError_t er = hipMemsetAsync(b.win_done_prev, 0, (size_t)W * 4, s);
     if (er != hipSuccess) return -100 - (int)er;
 

@@ -218,18 +218,26 @@ class Engine:
                max_initial_timestamp_index: Optional[int] = None, eot: int = 0, sot: int = 0, no_timestamps: int = -1,
                timestamp_begin: int = 0, no_speech: int = -1, blank_token: int = -1,
                suppress_tokens: Sequence[int] = (), ts_mask: Optional[torch.Tensor] = None, min_tokens: int = 0,
-               seed: int = 0):
+               seed: int = 0, window_uid: Optional[Sequence[int]] = None):
         W = len(init_tokens)
         n_init = len(init_tokens[0])
         assert all(len(t) == n_init for t in init_tokens), "all windows of a job share the initial length"
         self.reserve(max(W, self.max_windows), max(W * n_group, self.max_rows))
+        bad = [t for t in suppress_tokens if not 0 <= int(t) < self.dims.n_vocab]
+        if bad:       # upstream's SuppressTokens indexes the logits with them: IndexError
+            raise IndexError(f"suppress_tokens ids out of range for a vocabulary of {self.dims.n_vocab}: {bad[:8]}")
+        uid = None
+        if window_uid is not None:
+            assert len(window_uid) == W
+            uid = _i32arr([int(u) & 0x7FFFFFFF for u in window_uid])
         cfg = swx_decode_cfg(
             n_windows=W, n_group=n_group, beam=int(beam), temperature=float(temperature),
             patience=float(patience or 0.0), sample_len=int(sample_len), sample_begin=n_init, sot_index=int(sot_index),
             suppress_blank=int(suppress_blank), apply_timestamp_rules=int(apply_timestamp_rules),
             max_initial_timestamp_index=-1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index),
             eot=eot, sot=sot, no_timestamps=no_timestamps, timestamp_begin=timestamp_begin, no_speech=no_speech,
-            blank_token=blank_token, n_suppress=len(suppress_tokens), min_tokens=int(min_tokens), seed=int(seed))
+            blank_token=blank_token, n_suppress=len(suppress_tokens), min_tokens=int(min_tokens), seed=int(seed),
+            window_uid=uid)
         g_out = self.lib.swx_decode_gout(ctypes.byref(cfg))
         TS = self.dims.n_text_ctx + 1
         d_init = torch.tensor(np.asarray(init_tokens, dtype=np.int32), device=self.device)

@@ -294,10 +294,11 @@ class Whisper:
         return torch.cuda.stream(s), s
 
     def _bind_api(self):
-        from .transcribe import transcribe_stable
+        from .transcribe import transcribe_minimal, transcribe_stable
         from .alignment import align, align_words, refine
         self.transcribe = types.MethodType(transcribe_stable, self)
         self.transcribe_stable = self.transcribe
+        self.transcribe_minimal = types.MethodType(transcribe_minimal, self)
         self.align = types.MethodType(align, self)
         self.align_words = types.MethodType(align_words, self)
         self.refine = types.MethodType(refine, self)
@@ -308,7 +309,9 @@ class Whisper:
 
 
 def _read_checkpoint(path: str):
-    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    # weights_only: a checkpoint is data (upstream's are {"dims": dict, "model_state_dict": tensors}); a pickle that needs
+    # arbitrary classes to load is refused rather than executed
+    ckpt = torch.load(path, map_location="cpu", weights_only=True)
     dims = ckpt["dims"]
     dims = ModelDimensions(**dims) if isinstance(dims, dict) else ModelDimensions(**dims.__dict__)
     return dims, ckpt["model_state_dict"]

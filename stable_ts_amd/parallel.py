@@ -70,16 +70,35 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+_QUEUE_SERIAL = [0]
+
+
+def _span_queue(n_items: int, step: int):
+    """Yields the first index of every chunk of `step` items this rank pulls from a shared queue: an atomic fetch-add on a
+    counter in the default process group's store (TCPStore).  Every call of transcribe_sharded uses a fresh key (all ranks
+    call it the same number of times)."""
+    from torch.distributed.distributed_c10d import _get_default_store
+    store = _get_default_store()
+    _QUEUE_SERIAL[0] += 1
+    key = f"swx_span_queue_{_QUEUE_SERIAL[0]}"
+    while True:
+        first = store.add(key, step) - step
+        if first >= n_items:
+            return
+        yield first
+
+
 def transcribe_sharded(model, audio: torch.Tensor, *, batch_size: int = 8, mode: str = "windows", spans_per_rank: int = 4,
-                       **kw):
+                       work_queue: bool = True, lockstep: int = 2, **kw):
     """Transcription of ONE long recording over all ranks; the segments are gathered on rank 0 (returns a WhisperResult
     there, None elsewhere).
 
     ``mode="windows"``: rank r takes the contiguous block of 30-s windows `shard_windows(...)` and runs
     `model.transcribe(block, batch_size=...)` (fixed stride, no prompt carry-over).
     ``mode="spans"``: the recording is cut at quiet places into ``world * spans_per_rank`` spans (every rank computes the
-    same plan from the same audio), rank r takes a contiguous run of them and advances them in lockstep with the
-    reference's sequential algorithm per span (spans.py) -- equal to the reference run once per span."""
+    same plan from the same audio); the ranks pull them ``lockstep`` at a time from a shared work queue (``work_queue=False``:
+    static contiguous runs) and advance each group in lockstep with the reference's sequential algorithm per span
+    (spans.py) -- equal to the reference run once per span, whichever rank ran it."""
     from .audio import N_SAMPLES, SAMPLE_RATE
     from .result import WhisperResult
     rank = dist.get_rank() if dist.is_initialized() else 0
@@ -88,26 +107,64 @@ def transcribe_sharded(model, audio: torch.Tensor, *, batch_size: int = 8, mode:
         from .spans import merge_span_results, plan_spans, transcribe_spans
         plan = plan_spans(audio.detach().float().cpu(), world * spans_per_rank, q_levels=kw.get("q_levels", 20),
                           k_size=kw.get("k_size", 5))
-        mine = [plan[i] for i in shard_windows(len(plan), rank, world)]
         parts = []
-        if mine:
-            res = transcribe_spans(model, audio, spans=mine, **kw)
-            parts = [(0, res.to_dict())]
+        if work_queue and world > 1:
+            # over-decomposed work queue (speech density varies, a static split leaves ranks idle): the spans
+            # are handed out `lockstep` at a time through an atomic counter in the process group's key-value store -- no
+            # collective on the data path; every rank keeps pulling until the plan is exhausted
+            for first in _span_queue(len(plan), lockstep):
+                mine = plan[first:first + lockstep]
+                res = transcribe_spans(model, audio, spans=mine, **kw)
+                parts.append((int(mine[0][0]), res.to_dict()))          # keyed by the group's start: the queue hands spans out in any order
+        else:
+            mine = [plan[i] for i in shard_windows(len(plan), rank, world)]
+            if mine:
+                res = transcribe_spans(model, audio, spans=mine, **kw)
+                parts = [(int(mine[0][0]), res.to_dict())]
         gathered = gather_results(parts)
         if gathered is None:
             return None
-        return merge_span_results([(o, WhisperResult(d, check_sorted=False)) for o, d in gathered], kw.get("language"))
+        # the per-group results are already in recording time: order them by their start, no further shift
+        gathered.sort(key=lambda p: p[0])
+        return merge_span_results([(0, WhisperResult(d, check_sorted=False)) for _, d in gathered], kw.get("language"))
     if mode != "windows":
         raise ValueError(f"unknown mode {mode!r}")
+    kw = dict(kw)
+    regroup = kw.pop("regroup", True)
+    if not kw.get("language") and getattr(model, "is_multilingual", False):
+        # ONE language for the whole recording: every rank detects it on the same audio -- the first window that is not
+        # exact silence (what the single-GPU run settles on, original_whisper.py:319-336 / :532) -- so all ranks decode with
+        # the same tokenizer without a collective
+        first = None
+        for k in range(0, int(audio.shape[-1]), N_SAMPLES):
+            w = audio[k:k + N_SAMPLES]
+            if w.numel() and bool((w != 0).any()):
+                first = w
+                break
+        if first is not None:
+            _, probs = model.detect_language(model.log_mel(first, N_SAMPLES - int(first.shape[-1])))
+            kw["language"] = max(probs, key=probs.get)
     n_win = (int(audio.shape[-1]) + N_SAMPLES - 1) // N_SAMPLES
     mine = shard_windows(n_win, rank, world)
-    segs = []
+    rec = dict(segments=[], nonspeech=[], language=kw.get("language"))
     if len(mine):
         span = audio[mine.start * N_SAMPLES: mine.stop * N_SAMPLES]
-        res = model.transcribe(span, batch_size=batch_size, **kw)
-        res.offset_time(mine.start * N_SAMPLES / SAMPLE_RATE)
-        segs = [s.to_dict() for s in res.segments]
-    allsegs = gather_results(segs)
-    if allsegs is None:
+        off = mine.start * N_SAMPLES / SAMPLE_RATE
+        # per rank WITHOUT regrouping: segments may merge / split across shard boundaries, so that runs once on the whole result
+        res = model.transcribe(span, batch_size=batch_size, regroup=False, **kw)
+        res.offset_time(off)
+        rec["segments"] = [s.to_dict() for s in res.segments]
+        rec["nonspeech"] = [(d["start"] + off, d["end"] + off) for d in res.nonspeech_sections]
+        rec["language"] = res.language or rec["language"]
+    parts = gather_results([rec])
+    if parts is None:
         return None
-    return WhisperResult(dict(segments=allsegs, language=kw.get("language")), check_sorted=False)
+    language = next((p["language"] for p in parts if p["language"]), None)
+    out = WhisperResult(dict(segments=[s for p in parts for s in p["segments"]], language=language), check_sorted=False)
+    sections = [ns for p in parts for ns in p["nonspeech"]]
+    if sections:
+        out.nonspeech_sections = [dict(start=a, end=b) for a, b in sections]
+    if regroup and kw.get("word_timestamps", True):
+        from .regroup import regroup_default
+        regroup_default(out, regroup)
+    return out

@@ -67,7 +67,8 @@ def _xkv_select(model, xkv, idx: Sequence[int]):
 
 
 def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float], prompts, ts_masks,
-                          compression_ratio_threshold, logprob_threshold, no_speech_threshold) -> List[DecodingResult]:
+                          compression_ratio_threshold, logprob_threshold, no_speech_threshold,
+                          uids: Optional[Sequence[int]] = None) -> List[DecodingResult]:
     """original_whisper.py:349-393, for W windows: every window walks the temperature ladder independently; the ones that
     still need a fallback are re-decoded together at the next temperature."""
     W = xkv.n_windows
@@ -92,7 +93,9 @@ def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float],
             masks = None
             if ts_masks is not None:
                 masks = torch.stack([ts_masks[pending[k]] for k in ks])
+            # sampling draws are keyed on the window's identity (its seek position), not on its row in this batch
             out = model.engine.decode(sub_k, [list(plans[k].initial_tokens) for k in ks], ts_mask=masks,
+                                      window_uid=None if uids is None else [uids[pending[k]] for k in ks],
                                       **plans[ks[0]].engine_kwargs())
             for k, r in zip(ks, plans[ks[0]].results(out, [None] * len(ks), [options.language or "en"] * len(ks))):
                 outs[k] = r
@@ -173,7 +176,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
         ts_masks = [torch.zeros(1501, dtype=torch.bool) if m is None else m for m in ts_masks]
     results = _decode_with_fallback(model, xkv, o["decode_options"], o["temperatures"], [b["prompt"] for b in batch],
                                     ts_masks, o["compression_ratio_threshold"], o["logprob_threshold"],
-                                    o["no_speech_threshold"])
+                                    o["no_speech_threshold"], uids=[int(b["seek_sample"]) // 160 for b in batch])
     time_precision = (N_FRAMES // model.dims.n_audio_ctx) * HOP_LENGTH / SAMPLE_RATE
     punct = o["prepend_punctuations"] + o["append_punctuations"]
     outs = []
@@ -433,6 +436,14 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             adv = n_seg
         tr.seek += int(adv) if adv is not None else n_seg
 
+    # Ctrl-C ends the run with what has been transcribed so far (original_whisper.py:712-723): the result's
+    # ``unfinished_start`` is the time up to which it is complete (-1 = finished)
+    interrupted: List[float] = []
+
+    def _interrupted_time(tr: _Track, seek_sample: int) -> float:
+        t = tr.all_segments[-1]["end"] if tr.all_segments else -1.0
+        return max(t, seek_sample / SAMPLE_RATE)
+
     if batch_size:
         # ---- window-parallel driver: fixed stride, no prompt carry-over
         # the loader hands out the windows in order (a streamed source only moves forward); chunks are short-lived
@@ -472,31 +483,34 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             return outs_k
 
         done = 0
-        for group in batches():
-            preds = [None] * len(group)
-            if pool is not None and len(group) > 1:
-                preds = list(pool.map(lambda g: nonspeech.predict(host_copy(g[1]), offset=g[0] / SAMPLE_RATE), group))
-            items = [window_input(tr0, sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
-            live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
-            tr0.started = tr0.started or bool(live)
-            if live:
-                settle_language(live[0]["audio"], [tr0])
-                for it in live:
-                    if not it["prompt"]:
-                        it["prompt"] = list(lang_state["prompt_tokens"])
-            tokenizer = lang_state["tokenizer"]
-            if lanes and len(live) >= len(lanes):
-                per = (len(live) + len(lanes) - 1) // len(lanes)
-                parts = [live[k * per:(k + 1) * per] for k in range(len(lanes))]
-                outs = [x for r in lane_pool.map(run_lane, lanes, parts) for x in r]
-            else:
-                outs = _process_batch(model, tokenizer, live, o) if live else []
-            for it, out in zip(live, outs):
-                commit(tr0, it, out)
-            done += len(items)
-            if progress_callback is not None:
-                total = loader.get_total_samples()
-                progress_callback(min(total, done * N_SAMPLES) / SAMPLE_RATE, total / SAMPLE_RATE)
+        try:
+            for group in batches():
+                preds = [None] * len(group)
+                if pool is not None and len(group) > 1:
+                    preds = list(pool.map(lambda g: nonspeech.predict(host_copy(g[1]), offset=g[0] / SAMPLE_RATE), group))
+                items = [window_input(tr0, sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
+                live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
+                tr0.started = tr0.started or bool(live)
+                if live:
+                    settle_language(live[0]["audio"], [tr0])
+                    for it in live:
+                        if not it["prompt"]:
+                            it["prompt"] = list(lang_state["prompt_tokens"])
+                tokenizer = lang_state["tokenizer"]
+                if lanes and len(live) >= len(lanes):
+                    per = (len(live) + len(lanes) - 1) // len(lanes)
+                    parts = [live[k * per:(k + 1) * per] for k in range(len(lanes))]
+                    outs = [x for r in lane_pool.map(run_lane, lanes, parts) for x in r]
+                else:
+                    outs = _process_batch(model, tokenizer, live, o) if live else []
+                for it, out in zip(live, outs):
+                    commit(tr0, it, out)
+                done += len(items)
+                if progress_callback is not None:
+                    total = loader.get_total_samples()
+                    progress_callback(min(total, done * N_SAMPLES) / SAMPLE_RATE, total / SAMPLE_RATE)
+        except KeyboardInterrupt:                                                               # :716-723
+            interrupted.append(_interrupted_time(tr0, done * N_SAMPLES))
         if lanes:
             lane_pool.shutdown()
         if pool is not None:
@@ -506,14 +520,18 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
         # of each per device batch -- every track still sees exactly the reference's sequence of windows and prompts
         active = list(tracks)
         while active:
-            items = [(tr, it) for tr in active if (it := next_live_item(tr)) is not None]
-            if not items:
+            try:
+                items = [(tr, it) for tr in active if (it := next_live_item(tr)) is not None]
+                if not items:
+                    break
+                if lang_state["tokenizer"] is None:
+                    settle_language(items[0][1]["audio"], tracks)
+                    for tr, it in items:                # the prompt slices were taken before the initial prompt was known
+                        it["prompt"] = tr.all_tokens[tr.prompt_reset_since:]
+                outs = _process_batch(model, lang_state["tokenizer"], [it for _, it in items], o)
+            except KeyboardInterrupt:                                                           # :716-723
+                interrupted.append(_interrupted_time(tracks[0], tracks[0].seek))
                 break
-            if lang_state["tokenizer"] is None:
-                settle_language(items[0][1]["audio"], tracks)
-                for tr, it in items:                # the prompt slices were taken before the initial prompt was known
-                    it["prompt"] = tr.all_tokens[tr.prompt_reset_since:]
-            outs = _process_batch(model, lang_state["tokenizer"], [it for _, it in items], o)
             for (tr, it), out in zip(items, outs):
                 advance(tr, it, out)
             active = [tr for tr, _ in items]
@@ -544,9 +562,49 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     if _span_bounds:
         return [(tr.offset, finish(tr)) for tr in tracks]
     result = finish(tr0)
+    if interrupted:
+        result.unfinished_start = interrupted[0]                                                # :776
     if len(result.text) == 0:
         warnings.warn(f"Failed to {task} audio. Result contains no text. ")
     return result
+
+
+def transcribe_minimal(model, audio, *, verbose: Optional[bool] = False, word_timestamps: bool = True,
+                       regroup: Union[bool, str] = True, suppress_silence: bool = True, suppress_word_ts: bool = True,
+                       use_word_position: bool = True, q_levels: int = 20, k_size: int = 5, denoiser: Optional[str] = None,
+                       denoiser_options: Optional[dict] = None, demucs: bool = False, demucs_options: Optional[dict] = None,
+                       vad: bool = False, vad_threshold: float = 0.35, vad_onnx: bool = False, min_word_dur: float = 0.1,
+                       nonspeech_error: float = 0.1, only_voice_freq: bool = False, only_ffmpeg: bool = False,
+                       **options) -> WhisperResult:
+    """``model.transcribe_minimal`` (original_whisper.py:784-928): the plain recogniser wrapped by ``transcribe_any``'s pre- and
+    post-processing (voice-frequency filter before, silence adjustment and regrouping after) instead of the stabilising
+    window loop.  The reference's inner recogniser is upstream ``whisper.transcribe``; here it is this package's window loop
+    with every stabilising option switched off (no silence analysis inside the loop, no timestamp-token suppression, no
+    regrouping) -- the same device hot path per window.  Options that ``transcribe_any`` understands go to it, the rest to
+    the recogniser, as in the reference (``isolate_useful_options``)."""
+    import inspect
+    from .audio_io import audioloader_not_supported
+    from .non_whisper import transcribe_any
+    audioloader_not_supported(audio)
+    any_keys = set(inspect.signature(transcribe_any).parameters)
+    extra = {k: options.pop(k) for k in list(options) if k in any_keys}
+    if not isinstance(audio, (str, bytes)):
+        extra.setdefault("input_sr", SAMPLE_RATE)
+    if denoiser or only_voice_freq:
+        extra.setdefault("audio_type", "torch")
+        extra.setdefault("model_sr", SAMPLE_RATE)
+
+    def recognise(audio, **kw):
+        return transcribe_stable(model, audio, verbose=verbose, word_timestamps=word_timestamps, regroup=False,
+                                 suppress_silence=False, suppress_ts_tokens=False, **kw)
+
+    return transcribe_any(inference_func=recognise, audio=audio, inference_kwargs=dict(options), verbose=verbose,
+                          regroup=regroup, suppress_silence=suppress_silence, suppress_word_ts=suppress_word_ts,
+                          q_levels=q_levels, k_size=k_size, denoiser=denoiser, denoiser_options=denoiser_options,
+                          demucs=demucs, demucs_options=demucs_options, vad=vad, vad_threshold=vad_threshold,
+                          vad_onnx=vad_onnx, min_word_dur=min_word_dur, nonspeech_error=nonspeech_error,
+                          use_word_position=use_word_position, only_voice_freq=only_voice_freq, only_ffmpeg=only_ffmpeg,
+                          force_order=True, **extra)
 
 
 class _Track:

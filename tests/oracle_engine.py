@@ -49,7 +49,7 @@ class OracleEngine:
     def decode(self, xkv, init_tokens, *, n_group=1, beam=False, temperature=0.0, patience=None, sample_len=224,
                sot_index=0, suppress_blank=True, apply_timestamp_rules=True, max_initial_timestamp_index=None, eot=0, sot=0,
                no_timestamps=-1, timestamp_begin=0, no_speech=-1, blank_token=-1, suppress_tokens=(), ts_mask=None,
-               min_tokens=0, seed=0):
+               min_tokens=0, seed=0, window_uid=None):
         self.n_decode_calls += 1
         W = xkv.n_windows
         TS = self.dims.n_text_ctx + 1
@@ -177,6 +177,8 @@ class CpuWhisper:
         self.device = torch.device("cpu")
         self.engine = OracleEngine(oracle_model)
         self.transcribe = types.MethodType(transcribe_stable, self)
+        from stable_ts_amd.transcribe import transcribe_minimal
+        self.transcribe_minimal = types.MethodType(transcribe_minimal, self)
 
     def log_mel_batch(self, audios, paddings=None):
         out = []

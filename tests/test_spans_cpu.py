@@ -123,7 +123,7 @@ def test_spans_explicit_plan_and_errors(models, monkeypatch):
         transcribe_spans(mine, torch.zeros(0), 2, language="en", **BASE)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, work_queue=True):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -140,7 +140,7 @@ def _worker(rank, world, port, q):
     kw = dict(language="en", sample_len=24, **{k: v for k, v in BASE.items() if k != "sample_len"})
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        res = par.transcribe_sharded(model, audio, mode="spans", spans_per_rank=2, **kw)
+        res = par.transcribe_sharded(model, audio, mode="spans", spans_per_rank=2, work_queue=work_queue, lockstep=1, **kw)
         out = None if res is None else _snap(res)
         single = None
         if rank == 0:                                                 # the same plan on one rank
@@ -150,13 +150,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_spans_over_two_gloo_ranks():
-    """parallel.transcribe_sharded(mode='spans'), world_size 2: each rank advances its two spans in lockstep, rank 0
-    gathers; equal to all four spans on one rank (and thereby to the reference per span, test above)."""
+@pytest.mark.parametrize("work_queue", [True, False])
+def test_sharded_spans_over_two_gloo_ranks(work_queue):
+    """parallel.transcribe_sharded(mode='spans'), world_size 2: the ranks pull spans from the shared work queue (or take
+    static runs), rank 0 gathers; equal to all four spans on one rank (and thereby to the reference per span, test above)
+    whichever rank ran which span."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 33500 + (os.getpid() % 2000) + (7 if work_queue else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, work_queue)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=900) for _ in range(2))

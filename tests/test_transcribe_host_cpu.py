@@ -367,3 +367,51 @@ def test_language_is_detected_on_the_first_decoded_window(multilingual_models, m
     assert max(p_zero, key=p_zero.get) != want.language, "the silent opening must not give the same language by accident"
     assert _snap(got) == _snap(want)
     assert got.to_dict() == want.to_dict()
+
+
+def test_keyboard_interrupt_returns_partial_result(models, monkeypatch):
+    # Ctrl-C in the middle of the run (original_whisper.py:712-723, 776): what was transcribed so far comes back, and
+    # ``unfinished_start`` = max(end of the last segment, the seek position) instead of -1
+    G, ref_model, mine = models
+    from oracle_engine import install
+    import stable_ts_amd.transcribe as T
+    install(monkeypatch)
+    audio = G.synth_audio(97.0, seed=67)
+    opts = dict(BASE, sample_len=60)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        full = mine.transcribe(audio, language="en", **opts)
+        assert full.unfinished_start == -1 or full.unfinished_start == -1.0
+        calls = {"n": 0}
+        real = T._process_batch
+
+        def flaky(*a, **k):
+            calls["n"] += 1
+            if calls["n"] == 3:
+                raise KeyboardInterrupt
+            return real(*a, **k)
+        monkeypatch.setattr(T, "_process_batch", flaky)
+        part = mine.transcribe(audio, language="en", **opts)
+    assert 0 < len(part.segments) < len(full.segments)
+    assert part.unfinished_start >= part.segments[-1].end - 1e-6 and part.unfinished_start > 0
+    assert part.to_dict()["unfinished"] == part.unfinished_start
+    n = len(part.segments)
+    assert [s.text for s in part.segments[: n - 1]] == [s.text for s in full.segments[: n - 1]]   # regrouping may touch the last
+
+
+def test_transcribe_minimal_post_processing(models, monkeypatch):
+    # model.transcribe_minimal = the plain recogniser + transcribe_any's silence adjustment and default regrouping
+    # (original_whisper.py:784-928); against this package's own pieces: same words as the un-stabilised loop, regrouped
+    G, ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    audio = G.synth_audio(41.0, seed=31)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = mine.transcribe_minimal(audio, language="en", **BASE)
+        plain = mine.transcribe(audio, language="en", regroup=False, suppress_silence=False, **BASE)
+    assert len(res.segments) > 0
+    assert "".join(w.word for w in res.all_words()) == "".join(w.word for w in plain.all_words())
+    assert res.regroup_history != ""
+    with pytest.raises(NotImplementedError):
+        mine.transcribe_minimal(audio, language="en", vad=True, **BASE)
