@@ -153,6 +153,194 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
     }
 }
 
+// ================================================================================================ flash f16, gen 2
+// Same mathematics and MFMA operand arrangement as attn_flash_f16 above (swapped QK^T, lane-local softmax statistics, P feeds
+// PV from registers); what changes is the data movement, which bounded the first kernel at 0.10 of the MFMA peak:
+//   * a wave owns 32 queries (two 16-query blocks): every K / V^T fragment read from LDS feeds two MFMAs, and a workgroup
+//     covers 128 queries per barrier instead of 64;
+//   * K / V^T tiles are double-buffered in LDS, the global loads of tile t+1 are issued into registers BEFORE the MFMAs of
+//     tile t and written to the other buffer after them: one barrier per tile, no exposed load latency;
+//   * with VT (V already transposed per head in HBM: cross-KV layout, and the encoder's V through swx_transpose_v) both
+//     tiles are written with 16-byte vector stores; the row-major-V form (scalar transposing stores) is kept for the callers
+//     that have no transposed copy.
+template <bool VT>
+__global__ __launch_bounds__(256) void attn_flash2_f16(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f16 Ks[2][FL_KT][FL_LD];   // [buf][key][d]
+    __shared__ __attribute__((aligned(16))) f16 Vt[2][DH][FL_LD];      // [buf][d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qn = lane & 15, g = lane >> 4;
+    const f16 *Q = (const f16 *)a.q;
+    const f16 *K = (const f16 *)a.k + (size_t)b * a.k_bs + h * DH;
+    const f16 *V = (const f16 *)a.v + (size_t)b * a.v_bs + (VT ? (size_t)h * DH * a.vt_kp : (size_t)h * DH);
+
+    f16x8 qf[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 16 + qn;
+        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qi < a.nq ? qi : a.nq - 1)) * a.ldq + h * DH + g * 8;   // clamped
+        qf[qb][0] = *(const f16x8 *)(qp);
+        qf[qb][1] = *(const f16x8 *)(qp + 32);
+    }
+    f32x4 o[2][4];
+    float m_run[2], l_run[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        m_run[qb] = -__builtin_inff(); l_run[qb] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[qb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // staging registers of one tile: chunk c = tid + 256 i  ->  K row c>>3, dims (c&7)*8 ; V^T row c>>3, keys (c&7)*8
+    f16x8 rk[2], rv[2];
+    auto load_tile = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, c8 = (c & 7) * 8;
+            const int kg = kt0 + r;
+            const int kgc = kg < a.nk ? kg : a.nk - 1;                      // clamped, never predicated
+            rk[i] = *(const f16x8 *)(K + (size_t)kgc * a.ldkv + c8);
+            if (kg >= a.nk) rk[i] = (f16x8)(f16)0;
+            if constexpr (VT) {
+                rv[i] = *(const f16x8 *)(V + (size_t)r * a.vt_kp + kt0 + c8);           // zero padded past nk in the source
+            } else {
+                rv[i] = *(const f16x8 *)(V + (size_t)kgc * a.ldkv + c8);
+                if (kg >= a.nk) rv[i] = (f16x8)(f16)0;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, c8 = (c & 7) * 8;
+            *(f16x8 *)&Ks[buf][r][c8] = rk[i];
+            if constexpr (VT) {
+                *(f16x8 *)&Vt[buf][r][c8] = rv[i];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Vt[buf][c8 + e][r] = rv[i][e];
+            }
+        }
+    };
+
+    const int ntile = (a.nk + FL_KT - 1) / FL_KT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1, kt0 = t * FL_KT;
+        if (t + 1 < ntile) load_tile(kt0 + FL_KT);
+        // K fragments of this tile, shared by the two query blocks
+        f16x8 kf[4][2];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) kf[tt][kk] = *(const f16x8 *)&Ks[cur][tt * 16 + qn][kk * 32 + g * 8];
+        f16x8 pb[2][2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x4 sc[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                sc[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tt][0], qf[qb][0], sc[tt], 0, 0, 0);
+                sc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tt][1], qf[qb][1], sc[tt], 0, 0, 0);
+            }
+            float tmax = -__builtin_inff();
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt0 + tt * 16 + g * 4 + r;
+                    const float v = (key < a.nk) ? sc[tt][r] * 0.125f : -__builtin_inff();
+                    sc[tt][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[qb], tmax);
+            const float alpha = __expf(m_run[qb] - m_new);      // m_run = -inf on the first tile -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(sc[tt][r] - m_new);
+                    sc[tt][r] = p;
+                    psum += p;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[qb] = l_run[qb] * alpha + psum;
+            m_run[qb] = m_new;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) { o[qb][tt][0] *= alpha; o[qb][tt][1] *= alpha; o[qb][tt][2] *= alpha; o[qb][tt][3] *= alpha; }
+            // P^T as the B operand: k-slot (g, j) of k-block c <-> key 32c + (j<4 ? g*4+j : 16 + g*4 + j-4)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pb[qb][c][r] = (f16)sc[2 * c][r]; pb[qb][c][4 + r] = (f16)sc[2 * c + 1][r]; }
+        }
+        // O^T += V^T . P^T : every V^T fragment feeds both query blocks
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f16x4 lo = *(const f16x4 *)&Vt[cur][tt * 16 + qn][32 * c + g * 4];
+                const f16x4 hi = *(const f16x4 *)&Vt[cur][tt * 16 + qn][32 * c + 16 + g * 4];
+                f16x8 va;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[e] = lo[e]; va[4 + e] = hi[e]; }
+                o[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[0][c], o[0][tt], 0, 0, 0);
+                o[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[1][c], o[1][tt], 0, 0, 0);
+            }
+        if (t + 1 < ntile) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qi = q0 + qb * 16 + qn;
+        if (qi < a.nq) {
+            const float inv = 1.0f / l_run[qb];
+            f16 *op = (f16 *)a.o + ((size_t)b * a.q_rows_per_batch + qi) * a.ldo + h * DH;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[qb][t][r] * inv);
+                *(f16x4 *)(op + t * 16 + g * 4) = ov;
+            }
+        }
+    }
+}
+
+// V [B][n][ldv] (head h at column h*64) -> V^T [B][H][64][kp] per head, keys contiguous, zero padded up to kp: LDS tile
+// transpose, 16-byte accesses on both sides.  One workgroup per (64-key tile, head, batch item).
+__global__ __launch_bounds__(256) void transpose_v_kernel(const f16 *__restrict__ V, int64_t ldv, int64_t v_bs, int n, f16 *__restrict__ VT,
+                                                          int kp, int64_t vt_bs)
+{
+    __shared__ __attribute__((aligned(16))) f16 T[DH][FL_LD];      // [d][key]
+    const int kt0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, key = c >> 3, c8 = (c & 7) * 8;
+        const int kg = kt0 + key;
+        f16x8 v = *(const f16x8 *)(V + (size_t)b * v_bs + (size_t)(kg < n ? kg : n - 1) * ldv + h * DH + c8);
+        if (kg >= n) v = (f16x8)(f16)0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) T[c8 + e][key] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i, dr = c >> 3, k8 = (c & 7) * 8;
+        if (kt0 + k8 < kp) *(f16x8 *)(VT + (size_t)b * vt_bs + ((size_t)h * DH + dr) * kp + kt0 + k8) = *(const f16x8 *)&T[dr][k8];
+    }
+}
+
 // ============================================================================================ decode cross
 // Decode-step cross-attention: <= 16 queries (the G beams of one window) against the window's 1500 encoder positions.
 // HBM-bound: the only traffic that matters is ONE pass over this (window, head)'s K [1500][64] and V^T [64][kp]
@@ -160,7 +348,10 @@ __global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
 //   S^T[16 keys][16 q] = K-frag . Q^T        (K rows gathered so that a lane ends up holding 8 CONSECUTIVE keys)
 //   O^T[64 d][16 q]   += V^T-frag . P^T      (V^T rows are key-contiguous: 16-byte loads again)
 // 4 waves split the keys (32-key blocks, round-robin) with a private online softmax each and merge through LDS once.
-template <bool QSLAB, bool PIPE>
+// PACKED: K and V^T come from the fragment-ordered copy (swx_xkv_pack): every MFMA operand fragment of a 32-key block is one
+// contiguous 1 KB piece, so a wave instruction reads 8 full 128-byte lines instead of 16 separate 64-byte row pieces (the
+// per-CU address path, not HBM, bounds the row-layout variant at ~4.2 TB/s: same finding as for the decode GEMM weights).
+template <bool QSLAB, bool PIPE, bool PACKED = false>
 __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 {
     __shared__ float sm_m[4][16], sm_l[4][16];
@@ -183,7 +374,18 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     // Key blocks are double-buffered in registers by hand: the K / V^T fragments of this wave's NEXT block are requested
     // before the current block's MFMAs and softmax, so 16 KB per wave stay in flight and the loop never drains to
     // vmcnt(0) (the plain loop compiled to load -> wait -> compute per block: two exposed round trips per 32 keys).
+    const int64_t per_head = swx_xkv_packed_elems_per_head(a.nk);
+    const f16 *Kpk = PACKED ? (const f16 *)a.kv_packed + (size_t)b * a.k_bs + (size_t)h * per_head + lane * 8 : nullptr;
+    const f16 *Vpk = PACKED ? Kpk + per_head / 2 : nullptr;
     auto load_blk = [&](int cb, f16x8 (&kf)[4], f16x8 (&vf)[4]) {
+        if constexpr (PACKED) {
+            const int blk = cb < nblk ? cb : nblk - 1;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) kf[f] = *(const f16x8 *)(Kpk + ((size_t)blk * 4 + f) * 512);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vf[t] = *(const f16x8 *)(Vpk + ((size_t)blk * 4 + t) * 512);
+            return;
+        }
         const int k0 = (cb < nblk ? cb : nblk - 1) << 5;    // tail prefetch re-reads the last block: loads are never predicated
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -699,7 +901,43 @@ __global__ __launch_bounds__(256) void qk_capture_kernel(const T *__restrict__ q
     }
 }
 
+// ================================================================================================ xkv pack
+// One workgroup per (32-key block, head, window): the block's K rows (32 x 64) and V^T columns (64 x 32) are copied into the
+// fragment order attn_decode_cross_f16 consumes (index maps: see load_blk / compute_blk there).
+__global__ __launch_bounds__(256) void xkv_pack_kernel(const f16 *__restrict__ K, const f16 *__restrict__ VT, f16 *__restrict__ P,
+                                                       int nk, int ldk, int vt_kp, int64_t bs)
+{
+    const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, frag = tid >> 6;           // 4 fragments x 64 lanes for K, then for V^T
+    const int qn = lane & 15, g = lane >> 4;
+    const int64_t per_head = swx_xkv_packed_elems_per_head(nk);
+    f16 *out = P + (size_t)b * bs + (size_t)h * per_head + ((size_t)blk * 4 + frag) * 512 + lane * 8;
+    {   // K fragment f = 2t + kk: lane (qn, g) holds dims 32 kk + 8 g .. + 8 of key 32 blk + (qn >> 2) * 8 + (qn & 3) + 4 t
+        const int t = frag >> 1, kk = frag & 1;
+        const int key = blk * 32 + (qn >> 2) * 8 + (qn & 3) + 4 * t;
+        f16x8 v = (f16x8)(f16)0;
+        if (key < nk) v = *(const f16x8 *)(K + (size_t)b * bs + (size_t)key * ldk + h * DH + kk * 32 + g * 8);
+        *(f16x8 *)out = v;
+    }
+    {   // V^T fragment t: lane (qn, g) holds keys 32 blk + 8 g .. + 8 of row d = 16 t + qn (zero padded past nk in the source)
+        const int t = frag;
+        const f16x8 v = *(const f16x8 *)(VT + (size_t)b * bs + ((size_t)h * DH + t * 16 + qn) * vt_kp + blk * 32 + g * 8);
+        *(f16x8 *)(out + per_head / 2) = v;
+    }
+}
+
 }  // namespace
+
+int swx_xkv_pack(const void *k, const void *vt, void *packed, int B, int H, int nk, int ldk, int vt_kp, int64_t batch_stride,
+                 hipStream_t s)
+{
+    if (B <= 0) return 0;
+    if (((nk + 31) / 32) * 32 > vt_kp) return -5;
+    hipLaunchKernelGGL(xkv_pack_kernel, dim3((nk + 31) / 32, H, B), dim3(256), 0, s, (const f16 *)k, (const f16 *)vt, (f16 *)packed,
+                       nk, ldk, vt_kp, batch_stride);
+    SWX_CHECK_LAUNCH();
+    return 0;
+}
 
 int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
 {
@@ -716,14 +954,22 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias || a.qs.ks2 < 1 || a.qs.ks2 > SLAB_KMAX)) return -5;
         dim3 gd(a.H, a.B);
 #define SWX_XA(QS_, PP_) hipLaunchKernelGGL((attn_decode_cross_f16<QS_, PP_>), gd, dim3(256), 0, s, a)
-        if (pipe) { if (qsl) SWX_XA(true, true); else SWX_XA(false, true); }
+        if (a.kv_packed && !qsl && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV))
+            hipLaunchKernelGGL((attn_decode_cross_f16<false, false, true>), gd, dim3(256), 0, s, a);
+        else if (pipe) { if (qsl) SWX_XA(true, true); else SWX_XA(false, true); }
         else { if (qsl) SWX_XA(true, false); else SWX_XA(false, false); }
 #undef SWX_XA
     } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
-        dim3 g(cdiv(a.nq, 64), a.H, a.B);
-        hipLaunchKernelGGL(attn_flash_f16, g, dim3(256), 0, s, a);
+        if (swx_flags() & SWX_FLAG_FLASH_V1) {
+            dim3 g(cdiv(a.nq, 64), a.H, a.B);
+            hipLaunchKernelGGL(attn_flash_f16, g, dim3(256), 0, s, a);
+        } else {
+            dim3 g(cdiv(a.nq, 128), a.H, a.B);
+            if (a.vt_kp) hipLaunchKernelGGL(attn_flash2_f16<true>, g, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(attn_flash2_f16<false>, g, dim3(256), 0, s, a);
+        }
     } else {
         // algorithmic bytes: K and V of every (window, head) once + q in + o out
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
@@ -733,6 +979,15 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         if (dtype == SWX_F16) hipLaunchKernelGGL(attn_dense_rowwise<f16>, g, dim3(256), smem, s, a);
         else hipLaunchKernelGGL(attn_dense_rowwise<float>, g, dim3(256), smem, s, a);
     }
+    SWX_CHECK_LAUNCH();
+    return 0;
+}
+
+int swx_transpose_v(const void *v, int64_t ldv, int64_t v_bs, int n, void *vt, int kp, int64_t vt_bs, int B, int H, hipStream_t s)
+{
+    if (B <= 0 || n <= 0) return 0;
+    if (kp % 8 != 0 || kp < n) return -5;
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(cdiv(kp, 64), H, B), dim3(256), 0, s, (const f16 *)v, ldv, v_bs, n, (f16 *)vt, kp, vt_bs);
     SWX_CHECK_LAUNCH();
     return 0;
 }

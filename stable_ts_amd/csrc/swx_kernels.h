@@ -36,6 +36,8 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_FUSE_CROSS_Q 64    // cross-attention finishes q from the split-K slabs (no finish launch for the query projection)
 #define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
 #define SWX_FLAG_DEC_V3 512        // decode step on the un-split "dec" GEMMs (swx_decstep.hip) when the batch has enough rows
+#define SWX_FLAG_NO_PACKED_XKV 2048 // decode cross-attention reads the row-layout K / V^T instead of the fragment-ordered copy (A/B)
+#define SWX_FLAG_FLASH_V1 4096      // MFMA flash attention: first-generation kernel (A/B)
 #define SWX_FLAG_DEC_V3_FORCE 1024 // ... for every row count (tests)
 #define SWX_FLAG_GLDS_GEMM 256     // tiled f16 GEMM (encoder, cross-KV, scoring): direct-to-LDS operand staging (global_load_lds)
 #define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q | SWX_FLAG_DEC_V3 | SWX_FLAG_GLDS_GEMM)
@@ -129,10 +131,19 @@ struct AttnArgs {
     int B, H, nq, nk;
     int q_rows_per_batch;            // rows of q per batch item (== nq unless grouped)
     SlabRef qs;                      // qs.slabs != null: q = f16(bias + sum of slabs) instead of a.q (decode cross-attention only)
+    const void *kv_packed;           // decode cross-attention: K and V^T of batch item 0 in MFMA fragment order (swx_xkv_pack),
+                                     // batch stride k_bs; null = read a.k / a.v
 };
+// fragment-ordered copy of one layer's cross K / V^T for the decode-step cross-attention: per (window, head)
+// [K: blocks of 32 keys x 4 fragments x 64 lanes x 8 halfs | V^T: the same], zero padded past nk
+__host__ __device__ inline int64_t swx_xkv_packed_elems_per_head(int nk) { return (int64_t)((nk + 31) / 32) * 4 * 512 * 2; }
+int swx_xkv_pack(const void *k, const void *vt, void *packed, int B, int H, int nk, int ldk, int vt_kp, int64_t batch_stride,
+                 hipStream_t s);
 #define SWX_VT_KP 1536               // padded key count of the transposed cross-attention V (64-key tiles never run off a row)
 // dense (non-causal) attention over nk keys: encoder self-attention and cross-attention
 int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s);
+// V [B][n][ldv] -> per-head transposed V^T [B][H][64][kp] (keys contiguous, zero padded): feeds the MFMA flash kernel's vector path
+int swx_transpose_v(const void *v, int64_t ldv, int64_t v_bs, int n, void *vt, int kp, int64_t vt_bs, int B, int H, hipStream_t s);
 // decoder self-attention over the per-row KV cache with ancestor indirection
 struct SelfAttnArgs {
     const void *qkv; int64_t ldqkv;  // [R*n_new][3d]: q | k | v of the new tokens

@@ -308,9 +308,17 @@ int gemm_residual(swx_model *m, const void *A, int64_t lda, size_t w_off, size_t
     return swx_gemm(m->dtype, g, 0, s);
 }
 
-inline int64_t xkv_chunk_elems(const swx_dims &D)
+inline int64_t xkv_plain_elems(const swx_dims &D)      // K [1500][d] | V^T [d][KP]
 {
     return (int64_t)D.n_audio_ctx * D.n_text_state + (int64_t)D.n_text_state * SWX_VT_KP;
+}
+inline int64_t xkv_packed_elems(const swx_dims &D)     // f16 only: K and V^T again, in MFMA fragment order per head (swx_attn.hip)
+{
+    return (int64_t)D.n_text_head * swx_xkv_packed_elems_per_head(D.n_audio_ctx);
+}
+inline int64_t xkv_chunk_elems(const swx_model *m)
+{
+    return xkv_plain_elems(m->dims) + (m->dtype == SWX_F16 ? xkv_packed_elems(m->dims) : 0);
 }
 
 // ------------------------------------------------------------------------------------------------ decoder forward
@@ -343,7 +351,7 @@ int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
     SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, rows, 1, m->arena + m->o_tok_emb,
                       m->A<float>(m->o_dec_pos), d, x, s));
     SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->dec[0].ln1_g), m->A<float>(m->dec[0].ln1_b), h, d, rows, d, s));
-    const int64_t chunk = xkv_chunk_elems(D);
+    const int64_t chunk = xkv_chunk_elems(m);
     // cross-attention rows of a window are its f.rpw consecutive rows: q row (b, qn) = b * rpw + qn, as the slabs are laid out
     const bool fuse_self = (g_debug_flags & SWX_FLAG_FUSE_SELF) && swx_pg_splits(3 * d, d) <= 16;
     const bool fuse_cq = (g_debug_flags & SWX_FLAG_FUSE_CROSS_Q) && f.rpw <= 16 && D.n_audio_ctx >= 128 && swx_pg_splits(d, d) <= 16;
@@ -413,7 +421,7 @@ int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
     float *slabs = m->Wp<float>(m->L.slabs);
     SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, rows, 1, m->arena + m->o_tok_emb,
                       m->A<float>(m->o_dec_pos), d, x, s));
-    const int64_t chunk = xkv_chunk_elems(D);
+    const int64_t chunk = xkv_chunk_elems(m);
     for (int l = 0; l < D.n_text_layer; ++l) {
         const LayerW &w = m->dec[l];
         f16 *kc = (f16 *)(f.kcache + (size_t)l * f.layer_stride), *vc = (f16 *)(f.vcache + (size_t)l * f.layer_stride);
@@ -443,6 +451,7 @@ int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
         ca.q = q; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
         ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
         ca.B = f.W; ca.H = H; ca.nq = f.rpw; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw;
+        ca.kv_packed = kl + (size_t)xkv_plain_elems(D) * e;          // fragment-ordered copy of this layer's K / V^T
         SWX_TRY(swx_attention(m->dtype, ca, 0, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
@@ -497,7 +506,7 @@ int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
         SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.lnx_g), m->A<float>(w.lnx_b), h, d, rows, d, s));
         SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wcq, d, m->A<float>(w.bcq), qkv, d, rows, d, d, EPI_BIAS), 0, s));
         // cross K/V of this layer: per window [K: 1500 x d row-major | V^T: d x SWX_VT_KP, keys contiguous]
-        const int64_t chunk = xkv_chunk_elems(D);
+        const int64_t chunk = xkv_chunk_elems(m);
         const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
         AttnArgs ca{};
         ca.q = qkv; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
@@ -881,6 +890,12 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
         a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * e; a.v = qkv + (size_t)2 * d * e; a.ldkv = 3 * d; a.o = att; a.ldo = d;
         a.k_bs = (int64_t)S_ * 3 * d; a.v_bs = a.k_bs; a.vt_kp = 0;
         a.B = B; a.H = H; a.nq = S_; a.nk = S_; a.q_rows_per_batch = S_;
+        if (m->dtype == SWX_F16 && !(g_debug_flags & SWX_FLAG_FLASH_V1)) {
+            // V of this layer transposed per head (one streaming pass, ~35 us for 20 windows): the flash kernel then stages both
+            // operands with 16-byte vector stores; the `u` buffer (MLP hidden, 4d wide) is free until the MLP of this layer
+            SWX_TRY(swx_transpose_v(a.v, 3 * d, a.v_bs, S_, u, SWX_VT_KP, (int64_t)H * 64 * SWX_VT_KP, B, H, s));
+            a.v = u; a.vt_kp = SWX_VT_KP; a.v_bs = (int64_t)H * 64 * SWX_VT_KP;
+        }
         SWX_TRY(swx_attention(m->dtype, a, 0, s));
         SWX_TRY(gemm_residual(m, att, d, w.wo, w.bo, x, d, rows, d, d, s));
         SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.ln2_g), m->A<float>(w.ln2_b), h, d, rows, d, s));
@@ -894,7 +909,7 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
 size_t swx_cross_kv_bytes(const swx_model *m, int B)
 {
     if (!m) return 0;
-    return (size_t)m->dims.n_text_layer * B * (size_t)xkv_chunk_elems(m->dims) * m->esz;
+    return (size_t)m->dims.n_text_layer * B * (size_t)xkv_chunk_elems(m) * m->esz;
 }
 
 int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *stream)
@@ -904,7 +919,7 @@ int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *strea
     const int d = D.n_text_state, S_ = D.n_audio_ctx;
     const size_t e = m->esz;
     if (D.n_audio_state != d) return -1;
-    const int64_t chunk = xkv_chunk_elems(D);
+    const int64_t chunk = xkv_chunk_elems(m);
     hipStream_t s = S(stream);
     // the key padding of V^T (columns S_..KP) must be finite: it is multiplied by exact-zero probabilities
     SWX_TRY(swx_fill_zero(d_xkv, swx_cross_kv_bytes(m, B), s));
@@ -920,6 +935,9 @@ int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *strea
                                 base + (size_t)S_ * d * e, d, B * S_, d, d, EPI_BIAS | EPI_STORE_VT);
         gv.vt_s = S_; gv.vt_kp = SWX_VT_KP; gv.vt_bs = chunk;
         SWX_TRY(swx_gemm(m->dtype, gv, 0, s));
+        if (m->dtype == SWX_F16)      // the decode-step cross-attention streams the fragment-ordered copy
+            SWX_TRY(swx_xkv_pack(base, base + (size_t)S_ * d * e, base + (size_t)xkv_plain_elems(D) * e, B, D.n_text_head, S_, d,
+                                 SWX_VT_KP, chunk, s));
     }
     return 0;
 }

@@ -296,6 +296,32 @@ def test_decode_f16_dec_step_equals_general_path(name, beam, windows):
 
 
 @pytest.mark.parametrize("name,beam", [("tiny.en", False), ("base.en", True)])
+def test_decode_f16_packed_cross_kv_is_bit_identical(name, beam):
+    # the decode-step cross-attention reading the fragment-ordered copy of K / V^T (swx_xkv_pack) vs the row layout (flag
+    # 2048): only the load addresses differ, so tokens and sums of log-probabilities must be IDENTICAL
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 91, B=3)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=32,
+                                                     beam_size=5 if beam else None))
+    kw = dict(n_group=task.n_group, beam=beam, sample_len=32, sot_index=task.sot_index, min_tokens=32,
+              **_tok_cfg(task.tokenizer, task))
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    old = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(old | 1024)
+        packed = eng.decode(xkv, [list(task.initial_tokens)] * 3, **kw)
+        lib.swx_debug_flags(old | 1024 | 2048)
+        rows = eng.decode(xkv, [list(task.initial_tokens)] * 3, **kw)
+    finally:
+        lib.swx_debug_flags(old)
+    assert np.array_equal(np.asarray(packed["lens"]), np.asarray(rows["lens"]))
+    assert np.array_equal(np.asarray(packed["tokens"]), np.asarray(rows["tokens"]))
+    assert np.array_equal(np.asarray(packed["sum_logprobs"]), np.asarray(rows["sum_logprobs"]))
+
+
+@pytest.mark.parametrize("name,beam", [("tiny.en", False), ("base.en", True)])
 @pytest.mark.parametrize("flags", [4, 16, 32, 64, 4 | 16, 4 | 16 | 64, 4 | 16 | 32 | 64])
 def test_decode_f16_step_switches_are_bit_identical(name, beam, flags):
     # SWX_FLAG_* switches of the fused decode step: write-through partial slabs (4), self-attention (16) and cross-attention (64)
