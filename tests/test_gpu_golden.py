@@ -220,3 +220,88 @@ def test_pending_device_paths_in_subprocess(inner):
                         "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, SWX_INNER_TESTS="1"), cwd=os.path.dirname(HERE))
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("name", ["default_thresholds", "both_ends", "coarse_rel", "starts_only"])
+def test_refine_end_to_end_matches_reference(name):
+    # model.refine() on the device (mute-and-probe bisection of refiner.py around the seam-B3 callable) against the reference's
+    # refine() run on the CPU oracle (tests/golden/make_refine_e2e_golden.py), starting from the reference's own align() result.
+    # Every probe decision compares probabilities of ~1e-5 against relative thresholds, so a word may stop one precision step
+    # earlier or later than on the CPU: >= 90 % of the words within 20 ms, none further off than two precision steps.
+    from stable_ts_amd.result import WhisperResult
+    with open(os.path.join(HERE, "golden", "reference_refine_e2e.json")) as f:
+        g = json.load(f)
+    case, want = g["case"], g["refined"][name]
+    model = _model(case)
+    audio = _synth_audio(case["seconds"], case["seed"])
+    words = [dict(w) for w in g["before"]]
+    res = WhisperResult(dict(segments=[dict(start=words[0]["start"], end=words[-1]["end"], text="".join(w["word"] for w in words),
+                                            words=words)], language="en"))
+    out = model.refine(audio, res, verbose=None, **want["kw"])
+    got = out.all_words()
+    assert [w.word for w in got] == [w["word"] for w in want["words"]]
+    prec = float(want["kw"].get("precision") or 0.1)
+    dev = [max(abs(a.start - b["start"]), abs(a.end - b["end"])) for a, b in zip(got, want["words"])]
+    close = sum(d <= 0.02 + 1e-9 for d in dev)
+    moved_ref = sum(abs(a["start"] - b["start"]) > 1e-9 or abs(a["end"] - b["end"]) > 1e-9 for a, b in zip(g["before"], want["words"]))
+    moved_got = sum(abs(a["start"] - b.start) > 1e-9 or abs(a["end"] - b.end) > 1e-9 for a, b in zip(g["before"], got))
+    assert close >= 0.9 * len(dev) and max(dev) <= 2 * prec + 0.02, (close, len(dev), max(dev), moved_ref, moved_got)
+    if moved_ref == 0:
+        assert moved_got == 0
+
+
+def test_temperature_ladder_on_device():
+    # decode_with_fallback (original_whisper.py:349-393) driven on hardware: thresholds that reject the T = 0 attempt force the
+    # ladder.  What does not depend on the sampling stream is compared with the reference-equivalent host logic on the CPU
+    # oracle: the T = 0 attempt itself (tokens, avg_logprob, compression ratio) and the DECISION to retry; the sampled retries
+    # follow this library's own counter-based stream (include/swx.h, swx_decode_cfg.window_uid), so for them the contract is
+    # checked instead: reproducible for a given (seed, window), independent of the batch the window is decoded in.
+    import stable_ts_amd as sw
+    from stable_ts_amd.decoding import DecodingOptions, DecodingPlan
+    from stable_ts_amd import transcribe as T
+    from oracle import stable as ost
+    from oracle.whisper import model as om
+    from oracle.whisper.decoding import DecodingOptions as ODO
+    case = dict(model="tiny.en", gain=2.0, ts_gain=0.5)
+    model = _model(case)
+    model.engine.reserve(3, 15)
+    ref = om.build_model("tiny.en", seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5)
+    audio = _synth_audio(90.0, 11)
+    segs = [audio[k * 480000:(k + 1) * 480000] for k in range(3)]
+    mel = model.log_mel_batch(segs, [0, 0, 0])
+    xkv = model.cross_kv(model.encoder(mel))
+    base = dict(language="en", sample_len=24, max_initial_timestamp=None, fp16=False)
+    kw = dict(compression_ratio_threshold=None, logprob_threshold=-0.5, no_speech_threshold=None)      # avg_logprob of random weights is << -0.5
+    temps = [0.0, 0.4, 0.8]
+    calls = []
+    real_decode = model.engine.decode
+
+    def spy(xkv_, init, **k):
+        out = real_decode(xkv_, init, **k)
+        calls.append((k.get("temperature"), len(init), list(k.get("window_uid") or [])))
+        return out
+    model.engine.decode = spy
+    try:
+        res = T._decode_with_fallback(model, xkv, dict(base, best_of=3), temps, [None] * 3, None, uids=[0, 3000, 6000], **kw)
+    finally:
+        model.engine.decode = real_decode
+    # every window failed the logprob threshold at every temperature: three attempts each, all windows retried together
+    assert [c[0] for c in calls] == temps and all(c[1] == 3 for c in calls) and calls[1][2] == [0, 3000, 6000]
+    assert all(r.temperature == 0.8 for r in res)
+    # the T = 0 attempt against the oracle, window by window
+    t0 = T._decode_with_fallback(model, xkv, dict(base), [0.0], [None] * 3, None, **kw)
+    for w in range(3):
+        want, _ = ost.decode_stable(ref, mel[w].cpu(), ODO(fp16=False, language="en", max_initial_timestamp=None, sample_len=24))
+        assert t0[w].tokens == want.tokens and abs(t0[w].avg_logprob - want.avg_logprob) < 1e-3
+        assert abs(t0[w].compression_ratio - want.compression_ratio) < 1e-9
+        assert want.avg_logprob < -0.5                       # i.e. the reference would retry as well
+    # sampling contract: window 1 decoded alone with its uid gives the tokens it got inside the batch of three
+    plan = DecodingPlan(model, DecodingOptions(temperature=0.8, best_of=3, **base))
+    sub = T._xkv_select(model, xkv, [1])
+    alone = model.engine.decode(sub, [list(plan.initial_tokens)], window_uid=[3000], **plan.engine_kwargs())
+    r_alone = plan.results(alone, [None], ["en"])[0]
+    assert r_alone.tokens == res[1].tokens and abs(r_alone.avg_logprob - res[1].avg_logprob) < 1e-6
+    again = T._decode_with_fallback(model, xkv, dict(base, best_of=3), temps, [None] * 3, None, uids=[0, 3000, 6000], **kw)
+    assert [r.tokens for r in again] == [r.tokens for r in res]
+    other = model.engine.decode(sub, [list(plan.initial_tokens)], window_uid=[3001], **plan.engine_kwargs())
+    assert plan.results(other, [None], ["en"])[0].tokens != r_alone.tokens      # a different window draws differently
