@@ -123,7 +123,7 @@ typedef struct swx_decode_cfg {
                                      Sampling contract (temperature > 0): the draw of a sequence is a counter-based hash of
                                      (seed, window uid, slot within the window's group, step, token id) -- Gumbel-max over the
                                      filtered logits / T, i.e. a Categorical(logits / T) sample like upstream's GreedyDecoder,
-                                     but NOT torch's Philox stream: a T > 0 retry is reproducible for a given (seed, uid)
+                                     but NOT the reference's (framework Philox) random stream: a T > 0 retry is reproducible for a given (seed, uid)
                                      whatever the batch it is decoded in, and is not token-identical with the reference's.
                                      NULL: the window's index in this job is its uid. */
 } swx_decode_cfg;
@@ -170,9 +170,11 @@ int swx_forward_logits(swx_model *m, const int32_t *d_tokens, const int32_t *h_n
                        const void *d_xkv, float *d_logits, void *stream);
 
 /* ---- a7 stand-alone (test hook + extra_models path): weights f32 [W][H][N][ld_f] raw qk ->
- * neg_matrix f32 [W][N][1500] */
+ * neg_matrix f32 [W][N][1500].  d_scratch: swx_align_weights_scratch_bytes(W, H, N) bytes of device memory (no entry point of
+ * this library allocates device memory) */
+size_t swx_align_weights_scratch_bytes(int W, int H, int N);
 int swx_align_weights(const float *d_qk, int W, int H, int N, int ld_f, const int32_t *h_n_frames, float qk_scale,
-                      int medfilt_width, float *d_neg_matrix, void *stream);
+                      int medfilt_width, float *d_neg_matrix, void *d_scratch, size_t scratch_bytes, void *stream);
 
 /* ---- whisper.timing.median_filter (timing.py:110,138): f32 [rows][n] -> [rows][n], reflect padding */
 int swx_median_filter(const float *d_x, int64_t rows, int n, int width, float *d_out, void *stream);

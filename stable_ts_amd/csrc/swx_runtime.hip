@@ -274,6 +274,9 @@ struct ProfRec { int cls; double work; hipEvent_t a, b; };
 bool g_prof_enabled = false;
 // decode-step switches (SWX_FLAG_* in swx_kernels.h); the environment variable SWX_FLAGS overrides the built-in default
 int g_debug_flags = [] { const char *e = getenv("SWX_FLAGS"); return e ? atoi(e) : SWX_DEFAULT_FLAGS; }();
+// the un-split "dec" step is used from this many live sequences on (below it a launch has too few workgroups: the split-K step
+// spreads a small batch over more CUs); SWX_DEC_MIN_ROWS overrides
+int g_dec_min_rows = [] { const char *e = getenv("SWX_DEC_MIN_ROWS"); return e ? atoi(e) : 48; }();
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -474,7 +477,7 @@ int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
     if (m->dtype == SWX_F16 && m->folded && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.rpw <= 16 && m->dims.n_audio_ctx >= 128 &&
         !(g_debug_flags & SWX_FLAG_NO_FAST_STEP) &&
-        ((g_debug_flags & SWX_FLAG_DEC_V3_FORCE) || ((g_debug_flags & SWX_FLAG_DEC_V3) && f.W * f.rpw >= 48)) &&
+        ((g_debug_flags & SWX_FLAG_DEC_V3_FORCE) || ((g_debug_flags & SWX_FLAG_DEC_V3) && f.W * f.rpw >= g_dec_min_rows)) &&
         (size_t)f.W * f.rpw <= (size_t)m->L.rows_big)
         return decoder_step_v3(m, f, s);
     if (!(g_debug_flags & SWX_FLAG_NO_FAST_STEP) && m->dtype == SWX_F16 && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.W * f.rpw <= 128 &&
@@ -1153,7 +1156,8 @@ int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int
 
     SWX_TRY(score_token_probs(m, d_tokens, W, max_n, n_sot, eot, d_token_probs, s));
     // alignment matrix
-    SWX_TRY(swx_align_weights_launch(m->Wp<float>(m->L.cap), m->Wp<float>(m->L.cap), m->Wp<float>(m->L.mean), m->Wp<float>(m->L.sd),
+    // scratch for the row statistics: the [W][H][1500] f32 region (>= W*H*max_n float2, max_n <= 448); the raw scores stay intact
+    SWX_TRY(swx_align_weights_launch(m->Wp<float>(m->L.cap), m->Wp<float>(m->L.mean), m->Wp<float>(m->L.mean), m->Wp<float>(m->L.sd),
                                      W, m->n_align, max_n, D.n_audio_ctx, d_small, d_small + W, qk_scale, medfilt_width,
                                      d_neg_matrix, max_n, D.n_audio_ctx, s));
     return 0;
@@ -1192,27 +1196,29 @@ int swx_forward_logits(swx_model *m, const int32_t *d_tokens, const int32_t *h_n
 }
 
 // ----------------------------------------------------------------------------- stand-alone alignment weights
-int swx_align_weights(const float *d_qk, int W, int H, int N, int ld_f, const int32_t *h_n_frames, float qk_scale,
-                      int medfilt_width, float *d_neg_matrix, void *stream)
+size_t swx_align_weights_scratch_bytes(int W, int H, int N)
 {
-    // test hook / extra_models path: allocates its own scratch (the only call that does; not used on the hot path)
+    if (W <= 0 || H <= 0 || N <= 0) return 0;
+    return align_up((size_t)W * H * N * sizeof(float2)) + align_up((size_t)2 * W * sizeof(int32_t));
+}
+
+int swx_align_weights(const float *d_qk, int W, int H, int N, int ld_f, const int32_t *h_n_frames, float qk_scale,
+                      int medfilt_width, float *d_neg_matrix, void *d_scratch, size_t scratch_bytes, void *stream)
+{
+    // stand-alone a7 (test hook / extra_models path).  Like every entry point it allocates nothing: the caller hands in
+    // swx_align_weights_scratch_bytes(W, H, N) of device scratch (row statistics + the per-window counts)
     if (W <= 0) return 0;
+    if (!d_scratch || scratch_bytes < swx_align_weights_scratch_bytes(W, H, N)) return -8;
     hipStream_t s = S(stream);
-    float *p = nullptr, *mean = nullptr, *sd = nullptr;
-    int32_t *cnt = nullptr;
-    const size_t nel = (size_t)W * H * N * ld_f;
-    if (hipMalloc(&p, nel * 4) != hipSuccess) return -100;
-    if (hipMalloc(&mean, (size_t)W * H * ld_f * 4) != hipSuccess) return -100;
-    if (hipMalloc(&sd, (size_t)W * H * ld_f * 4) != hipSuccess) return -100;
-    if (hipMalloc(&cnt, (size_t)2 * W * 4) != hipSuccess) return -100;
+    float *rstat = (float *)d_scratch;
+    int32_t *cnt = (int32_t *)((unsigned char *)d_scratch + align_up((size_t)W * H * N * sizeof(float2)));
     std::vector<int32_t> hv(2 * W);
     for (int w = 0; w < W; ++w) { hv[w] = N; hv[W + w] = h_n_frames[w]; }
-    hipMemcpy(cnt, hv.data(), hv.size() * 4, hipMemcpyHostToDevice);
-    int r = swx_align_weights_launch(d_qk, p, mean, sd, W, H, N, ld_f, cnt, cnt + W, qk_scale, medfilt_width, d_neg_matrix,
-                                     N, ld_f, s);
-    hipStreamSynchronize(s);
-    hipFree(p); hipFree(mean); hipFree(sd); hipFree(cnt);
-    return r;
+    hipError_t er = hipMemcpyAsync(cnt, hv.data(), hv.size() * 4, hipMemcpyHostToDevice, s);
+    if (er == hipSuccess) er = hipStreamSynchronize(s);      // hv is a stack-lifetime staging buffer
+    if (er != hipSuccess) return -100 - (int)er;
+    return swx_align_weights_launch(d_qk, rstat, nullptr, nullptr, W, H, N, ld_f, cnt, cnt + W, qk_scale, medfilt_width, d_neg_matrix,
+                                    N, ld_f, s);
 }
 
 // ------------------------------------------------------------------------------------------------ test hooks

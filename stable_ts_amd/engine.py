@@ -371,6 +371,7 @@ def align_weights(qk: torch.Tensor, n_frames: Sequence[int], qk_scale: float = 1
     W, H, N, ld_f = qk.shape
     out = torch.zeros(W, N, ld_f, dtype=torch.float32, device=qk.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(qk.device).cuda_stream)
+    scratch = torch.empty(max(lib.swx_align_weights_scratch_bytes(W, H, N), 256), dtype=torch.uint8, device=qk.device)
     check(lib.swx_align_weights(_ptr(qk), W, H, N, ld_f, _i32arr(n_frames), float(qk_scale), int(medfilt_width), _ptr(out),
-                                stream), "swx_align_weights")
+                                _ptr(scratch), scratch.numel(), stream), "swx_align_weights")
     return out
