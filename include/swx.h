@@ -179,6 +179,15 @@ int swx_align_weights(const float *d_qk, int W, int H, int N, int ld_f, const in
 /* ---- whisper.timing.median_filter (timing.py:110,138): f32 [rows][n] -> [rows][n], reflect padding */
 int swx_median_filter(const float *d_x, int64_t rows, int n, int width, float *d_out, void *stream);
 
+/* ---- device half of the non-VAD silence analysis (stabilization/nonvad.py:16-39 audio2loudness), on the PCM that is resident
+ * for the spectrogram.  d_pcm f32 [W] windows pcm_stride samples apart; d_nk int32 [W][2] = {valid samples n, k};
+ * d_idx int32 [W][n_idx] sample indices; d_out f32 [W][1 + n_idx]: out[w][0] = the k-th largest |x| of the window (the value
+ * of the reference's `topk(|x|, k).values[-1]`, nonvad.py:22, found by a radix select: an element of the input, no arithmetic; NaN when
+ * k == 0), out[w][1 + j] = |x[idx[w][j]]| (0 for an index outside [0, n)).  The floating-point part of the analysis stays in
+ * host code on these values (stable_ts_amd/stabilization.py::loudness_from_probe). */
+int swx_loudness_probe(const float *d_pcm, int64_t pcm_stride, const int32_t *d_nk, const int32_t *d_idx, int n_idx, int W,
+                       float *d_out, void *stream);
+
 /* ---- a8: DTW + backtrace (replaces whisper.timing.dtw at timing.py:195; CPU tie-break)
  * d_x f32 [W][ld_n][ld_m] (row-major; window w uses rows 0..N[w), cols 0..M[w));
  * outputs int32 [W][ld_n+ld_m] text/time indices in forward order and int32 [W] path lengths.

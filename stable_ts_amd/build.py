@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libswx.so")
 SOURCES = ["swx_runtime.hip", "swx_gemm.hip", "swx_norm.hip", "swx_attn.hip", "swx_decode.hip", "swx_align.hip",
-           "swx_mel.hip", "swx_dtw.hip", "swx_decstep.hip"]
+           "swx_mel.hip", "swx_dtw.hip", "swx_decstep.hip", "swx_loudness.hip"]
 
 
 def _newest(paths):
@@ -44,10 +44,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(out.decode())
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+    tmp = OUT + f".{os.getpid()}.tmp"          # link beside the target, then rename: a process that is loading the
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs      # library never sees a half-written file
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, OUT)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return OUT
 
 

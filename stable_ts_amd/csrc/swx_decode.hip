@@ -266,6 +266,164 @@ __global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int 
     }
 }
 
+// The same filter + select with the row held in REGISTERS (51 logits per thread at V = 51 866): the kernel above walks the
+// row 11-16 times through L2 (three timestamp-rule passes, the nan pass, the exp pass, G + 1 arg-max rounds) and takes 105 us
+// per decode step at 100 rows; here the row is read once.  Bit-identical by construction: every thread owns the elements
+// i = tid + k * SEL_T the loops above give it, sums are accumulated in ascending k, and the one sum whose loop above starts
+// at timestamp_begin (a rotated element-to-thread assignment) is rotated back through LDS before the block reduction.
+// Point suppressions (blank / eot / suppress list / no_timestamps) are still written to the row in memory first, because a
+// register array cannot be indexed by a run-time token id; nothing reads the row after this kernel (the next step's logits
+// GEMM rewrites it), so the filtered values are not written back.
+template <int NV>
+__global__ __launch_bounds__(SEL_T) void decode_select_reg_kernel(DecodeBufs b, int step, int cur)
+{
+    __shared__ float shf[SEL_T / 64];
+    __shared__ ArgMax sha[SEL_T / 64];
+    __shared__ float sh_rot[SEL_T];
+    __shared__ int sh_last_ts;
+    __shared__ float sh_raw;
+    const int r = blockIdx.x, w = r / b.G, V = b.V, tid = threadIdx.x;
+    const swx_decode_cfg &c = b.cfg;
+    if (b.win_done[w]) return;
+    float *lg = b.logits + (size_t)r * V;
+    int32_t *tok = b.tokens[cur] + (size_t)r * b.TS;
+    const int len = b.n_init + step;
+    const int nsamp = len - c.sample_begin;
+    const int tsb = c.timestamp_begin;
+
+    if (c.suppress_blank && nsamp == 0 && tid == 0) { if (c.blank_token >= 0) lg[c.blank_token] = NEG_INF; lg[c.eot] = NEG_INF; }
+    for (int i = tid; i < c.n_suppress; i += SEL_T) { const int t = b.suppress[i]; if ((unsigned)t < (unsigned)V) lg[t] = NEG_INF; }
+    if (c.min_tokens > 0 && nsamp < c.min_tokens && tid == 0) lg[c.eot] = NEG_INF;
+    if (c.apply_timestamp_rules && tid == 0) { sh_last_ts = -1; if (c.no_timestamps >= 0) lg[c.no_timestamps] = NEG_INF; }
+    __syncthreads();
+
+    float v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { const int i = tid + k * SEL_T; v[k] = i < V ? lg[i] : NEG_INF; }
+
+    if (c.apply_timestamp_rules) {
+        int my = -1;
+        for (int i = c.sample_begin + tid; i < len; i += SEL_T) if (tok[i] >= tsb) my = i;
+        if (my >= 0) atomicMax(&sh_last_ts, my);
+        __syncthreads();
+        const int last_ts_pos = sh_last_ts;
+        const bool last_was_ts = nsamp >= 1 && tok[len - 1] >= tsb;
+        const bool penult_was_ts = nsamp < 2 || tok[len - 2] >= tsb;
+        int lo0 = 0, hi0 = 0;
+        if (last_was_ts) { if (penult_was_ts) { lo0 = tsb; hi0 = V; } else { lo0 = 0; hi0 = c.eot; } }
+        int hi1 = tsb;
+        if (last_ts_pos >= 0) {
+            const int tl = tok[last_ts_pos];
+            hi1 = (last_was_ts && !penult_was_ts) ? tl : tl + 1;
+        }
+        int hi2 = 0, lo3 = V;
+        if (nsamp == 0) { hi2 = tsb; if (c.max_initial_timestamp_index >= 0) lo3 = tsb + c.max_initial_timestamp_index + 1; }
+        float mx_text = NEG_INF, mx_ts = NEG_INF;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = tid + k * SEL_T;
+            if (i < V) {
+                if ((i >= lo0 && i < hi0) || (i >= tsb && i < hi1) || (i < hi2) || (i >= lo3)) v[k] = NEG_INF;
+                if (i < tsb) mx_text = fmaxf(mx_text, v[k]); else mx_ts = fmaxf(mx_ts, v[k]);
+            }
+        }
+        mx_text = block_max(mx_text, shf);
+        mx_ts = block_max(mx_ts, shf);
+        // the loop above this kernel gives element i >= tsb to thread (i - tsb) % SEL_T: accumulate per owner here (same
+        // ascending order), then hand each partial sum to the thread that would have held it
+        float s_own = 0.f;
+        if (mx_ts > NEG_INF) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { const int i = tid + k * SEL_T; if (i >= tsb && i < V) s_own += expf(v[k] - mx_ts); }
+        }
+        sh_rot[(tid - tsb) & (SEL_T - 1)] = s_own;
+        __syncthreads();
+        float s_ts = block_sum(sh_rot[tid], shf);
+        const float lse_ts = (mx_ts > NEG_INF) ? mx_ts + logf(s_ts) : NEG_INF;
+        if (lse_ts > mx_text) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) if (tid + k * SEL_T < tsb) v[k] = NEG_INF;
+        }
+    }
+
+    const uint8_t *tmask = b.ts_mask ? b.ts_mask + (size_t)w * 1501 : nullptr;
+    float mx = NEG_INF;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int i = tid + k * SEL_T;
+        if (i < V) {
+            float x = v[k];
+            if (tmask && i >= tsb && i - tsb < 1501 && tmask[i - tsb]) x = NEG_INF;
+            if (x != x) x = NEG_INF;
+            else if (x == NEG_INF) x = -3.4028234663852886e38f;
+            else if (x == -NEG_INF) x = 3.4028234663852886e38f;
+            v[k] = x;
+            mx = fmaxf(mx, x);
+        }
+    }
+    mx = block_max(mx, shf);
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) if (tid + k * SEL_T < V) se += expf(v[k] - mx);
+    se = block_sum(se, shf);
+    const float lse = logf(se);
+
+    if (!c.beam) {
+        ArgMax best; best.v = NEG_INF; best.i = 0x7fffffff;
+        float raw_own = 0.f;                     // filtered logit at this thread's own best index
+        if (c.temperature == 0.f) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = tid + k * SEL_T;
+                if (i < V) { ArgMax x; x.v = v[k]; x.i = i; const ArgMax nb = argmax_combine(best, x); if (nb.i != best.i) raw_own = v[k]; best = nb; }
+            }
+        } else {
+            const float invT = 1.0f / c.temperature;
+            const unsigned row_uid = b.win_uid ? (unsigned)b.win_uid[r / b.G] * 0x9E3779B1u + (unsigned)(r % b.G) : (unsigned)r;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = tid + k * SEL_T;
+                if (i < V) {
+                    ArgMax x; x.v = v[k] * invT + gumbel(c.seed, row_uid, (unsigned)step, (unsigned)i); x.i = i;
+                    const ArgMax nb = argmax_combine(best, x);
+                    if (nb.i != best.i) raw_own = v[k];
+                    best = nb;
+                }
+            }
+        }
+        const int own_i = best.i;
+        best = block_argmax(best, sha);
+        if (own_i == best.i) sh_raw = raw_own;
+        __syncthreads();
+        if (tid == 0) {
+            int next = best.i;
+            const bool prev_eot = tok[len - 1] == c.eot;
+            const float lp = (sh_raw - mx) - lse;
+            if (!prev_eot) b.sum_lp[r] += lp; else next = c.eot;
+            tok[len] = next;
+            b.pos0[r] = len;
+            b.row_done[r] = (next == c.eot) ? 1 : 0;
+        }
+    } else {
+        const int K = b.G + 1;
+        for (int kk = 0; kk < K; ++kk) {
+            ArgMax best; best.v = NEG_INF; best.i = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int i = tid + k * SEL_T;
+                if (i < V) { ArgMax x; x.v = v[k]; x.i = i; best = argmax_combine(best, x); }
+            }
+            best = block_argmax(best, sha);
+            if (tid == 0) {
+                b.cand_lp[(size_t)r * K + kk] = (best.v - mx) - lse;
+                b.cand_tok[(size_t)r * K + kk] = best.i;
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) if (tid + k * SEL_T == best.i) v[k] = NEG_INF;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- beam update
 // grid (W), 256 threads.  cur = token/ancestor buffer holding the current beams; the new beams go to cur^1.
 __global__ __launch_bounds__(256) void decode_beam_update_kernel(DecodeBufs b, int step, int cur)
@@ -458,7 +616,11 @@ int swx_decode_after_prefill(const DecodeBufs &b, const float *lg2, float *nospe
 int swx_decode_select(const DecodeBufs &b, int step, int cur, hipStream_t s)
 {
     SwxProfScope prof(PC_SELECT, (double)b.M * b.V * 4.0, s);
-    hipLaunchKernelGGL(decode_select_kernel, dim3(b.M), dim3(SEL_T), 0, s, b, step, cur);
+    const bool mem_kernel = swx_flags() & SWX_FLAG_SELECT_MEM;       // A/B and bit-identity reference of the register kernel
+    if (!mem_kernel && b.V <= 51 * SEL_T)
+        hipLaunchKernelGGL(decode_select_reg_kernel<51>, dim3(b.M), dim3(SEL_T), 0, s, b, step, cur);
+    else
+        hipLaunchKernelGGL(decode_select_kernel, dim3(b.M), dim3(SEL_T), 0, s, b, step, cur);
     if (b.cfg.beam) {
         hipLaunchKernelGGL(decode_beam_update_kernel, dim3(b.W), dim3(256), 0, s, b, step, cur);
         hipLaunchKernelGGL(decode_beam_commit_kernel, dim3(cdiv(b.M, 256)), dim3(256), 0, s, b);

@@ -215,9 +215,10 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)xres[t][e];
         } else if (E_QKV && n >= g.d) {
-            const int pos = g.pos0[m];
+            const int rps = g.rps > 1 ? g.rps : 1;
+            const int seq = m / rps, pos = g.pos0[seq] + (m - seq * rps);
             f16 *cache = n < 2 * g.d ? g.kcache : g.vcache;
-            dst = cache + ((size_t)m * g.n_ctx + pos) * g.d + (n < 2 * g.d ? n - g.d : n - 2 * g.d);
+            dst = cache + ((size_t)seq * g.n_ctx + pos) * g.d + (n < 2 * g.d ? n - g.d : n - 2 * g.d);
         } else {
             dst = g.C + (size_t)m * g.ldc + n;
         }

@@ -43,11 +43,13 @@ constexpr int BM = 128, BN = 128;
 constexpr int BK16 = 64, LD16 = BK16 + 8;   // halfs; 144-byte rows keep every fragment read 16-byte aligned
 constexpr int CLD = BN + 4;                 // f32 staging row of the epilogue
 
-// Epilogue of the direct-to-LDS kernel below (the same code as gemm_f16_tiled's inline epilogue, which stays textually
-// untouched until this variant has been validated on hardware): special layouts element-wise, otherwise accumulators ->
-// f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32).  `smem` must hold 128 x CLD floats.
+// Shared tile epilogue of the two tiled f16 kernels: special layouts element-wise, otherwise accumulators -> f32 tile in LDS
+// (two halves of 64 rows, 33.8 KB) -> 16-byte row-contiguous stores with bias / GELU / residual in f32.  The bias (the same
+// 8 columns for every row group of a thread) and the residual rows of a half are requested BEFORE the accumulators are
+// staged: loaded per row group after the previous group's store (a store through a f16 pointer may alias the f32 bias, so
+// hipcc keeps the order) they were eight dependent L2 round trips per tile -- 43 % of a K = 1280 launch (see below).
 __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][4], int m0, int n0,
-                                                  int tid, int lane, int wm, int wn)
+                                                     int tid, int lane, int wm, int wn)
 {
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
     const bool plain = !(g.epi & (EPI_STORE_VT | EPI_CBATCH | EPI_OUT_F32 | EPI_RESF32MOD)) && (g.ldc % 8 == 0) &&
@@ -62,52 +64,65 @@ __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned ch
                     epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
         return;
     }
-    // coalesced epilogue: accumulators -> f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32)
-    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 128 x 132 x 4 B = 67.6 KB <= 73.7 KB
+    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 64 x 132 x 4 B = 33.8 KB per half
+    const int c8 = (tid & 15) * 8, rb = tid >> 4, gn = n0 + c8;
+    const bool col_ok = gn < g.N, full = gn + 8 <= g.N;
+    float bv[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 8; ++e) bv[e] = ((g.epi & EPI_BIAS) && gn + e < g.N) ? g.bias[gn + e] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+    for (int half = 0; half < 2; ++half) {
+        f16x8 rv[4];
+        if (g.epi & EPI_RES) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[wm * 64 + i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int c = tid + 256 * it, row = c >> 4, c8 = (c & 15) * 8;
-        const int gm = m0 + row, gn = n0 + c8;
-        if (gm >= g.M || gn >= g.N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Cs[row][c8 + e];
-        const bool full = gn + 8 <= g.N;
-        if (g.epi & EPI_BIAS) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || gn + e < g.N) v[e] += g.bias[gn + e];
-        }
-        if (g.epi & EPI_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        }
-        f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
-        if (full) {
-            if (g.epi & EPI_RES) {
-                const f16x8 rv = *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-            }
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-            *(f16x8 *)cp = o;
-        } else {
-            for (int e = 0; e < 8 && gn + e < g.N; ++e) {
-                float t = v[e];
-                if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
-                cp[e] = (f16)t;
+            for (int it = 0; it < 4; ++it) {
+                const int gm = m0 + half * 64 + it * 16 + rb;
+                rv[it] = (gm < g.M && full) ? *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn) : (f16x8)(f16)0;
             }
         }
+        if (wm == half) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 16 + rb, gm = m0 + half * 64 + row;
+            if (gm >= g.M || !col_ok) continue;
+            const f32x4 lo = *(const f32x4 *)&Cs[row][c8], hi = *(const f32x4 *)&Cs[row][c8 + 4];
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            if (g.epi & EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            }
+            f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
+            if (full) {
+                if (g.epi & EPI_RES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[it][e];
+                }
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+                *(f16x8 *)cp = o;
+            } else {
+                for (int e = 0; e < 8 && gn + e < g.N; ++e) {
+                    float t = v[e];
+                    if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
+                    cp[e] = (f16)t;
+                }
+            }
+        }
+        if (half == 0) __syncthreads();
     }
 }
+
 
 __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 {
@@ -173,64 +188,7 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
         __syncthreads();
     }
 
-    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
-    const bool plain = !(g.epi & (EPI_STORE_VT | EPI_CBATCH | EPI_OUT_F32 | EPI_RESF32MOD)) && (g.ldc % 8 == 0) &&
-                       (!(g.epi & EPI_RES) || g.ldr % 8 == 0);
-    if (!plain) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
-        return;
-    }
-    // coalesced epilogue: accumulators -> f32 tile in LDS -> 16-byte row-contiguous stores (bias / GELU / residual in f32)
-    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 128 x 132 x 4 B = 67.6 KB <= 73.7 KB
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[wm * 64 + i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int c = tid + 256 * it, row = c >> 4, c8 = (c & 15) * 8;
-        const int gm = m0 + row, gn = n0 + c8;
-        if (gm >= g.M || gn >= g.N) continue;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Cs[row][c8 + e];
-        const bool full = gn + 8 <= g.N;
-        if (g.epi & EPI_BIAS) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (full || gn + e < g.N) v[e] += g.bias[gn + e];
-        }
-        if (g.epi & EPI_GELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-        }
-        f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
-        if (full) {
-            if (g.epi & EPI_RES) {
-                const f16x8 rv = *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
-            }
-            f16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-            *(f16x8 *)cp = o;
-        } else {
-            for (int e = 0; e < 8 && gn + e < g.N; ++e) {
-                float t = v[e];
-                if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
-                cp[e] = (f16)t;
-            }
-        }
-    }
+    tile_epilogue_f16(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------- tiled f16, direct-to-LDS
@@ -243,15 +201,27 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 // of the slot with (row >> 1) & 7, applied on the SOURCE address of the load (the LDS destination is fixed by the
 // hardware) and on the read address.  Blocks are renumbered so that each XCD (private L2) works on neighbouring tiles.
 // Requires K % 64 == 0; rows past M / N are clamped to the last valid row (their results are never stored).
+//
+// Generation 2 (round 2).  What the K = 1280 shapes of the encoder showed for the first kernel (double buffered, one barrier
+// per K step, 67.6 KB of f32 epilogue staging -> two workgroups per CU; profiles/r02_kb_gemm_glds.txt): time = 103 us per
+// 1280 of K + 79 us that do not depend on K -- at M = 30000, N = 1280 the fixed part was 43 % of the launch: the epilogue's
+// dependent bias / residual loads (see tile_epilogue_f16), with only one other workgroup on the CU to hide them.
+// SINGLE = one operand buffer, two barriers per K step, 33.8 KB of LDS -> three to four workgroups per CU: the occupancy, not
+// a software pipeline, overlaps one workgroup's loads and epilogue with its neighbours' MFMAs.  Measured at M = 30000
+// (profiles/r02_kb_gemm_gen2.txt, TFLOP/s, first kernel -> <false,2> -> <true,4> -> <true,3>): N = K = 1280: 522 -> 737 -> 783
+// -> 768; N = 3840: 536 -> 704 -> 754 -> 737; N = 5120: 523 -> 748 -> 809 -> 788; K = 5120: 715 -> 783 -> 816 -> 854.  All
+// variants produce bit-identical results (same MFMA order per accumulator, same f32 epilogue arithmetic;
+// tests/hw_checks/gemm_glds_check.py).  Default: <true, 3>.
 constexpr int GL_TILE = 128 * 128;          // bytes of one operand tile: 128 rows x 64 halfs
-constexpr int GL_SMEM = 128 * CLD * 4 > 4 * GL_TILE ? 128 * CLD * 4 : 4 * GL_TILE;
+constexpr int GL2_EPI = 64 * CLD * 4;
 
-__global__ __launch_bounds__(256) void gemm_f16_glds(GemmArgs g)
+template <bool SINGLE, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_f16_glds(GemmArgs g)
 {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[GL_SMEM];
+    constexpr int MAIN = (SINGLE ? 2 : 4) * GL_TILE;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[MAIN > GL2_EPI ? MAIN : GL2_EPI];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware, bijective renumbering of the workgroups (consecutive ids go to different XCDs in hardware)
     int bx = blockIdx.x, by = blockIdx.y;
     {
         const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
@@ -269,12 +239,11 @@ __global__ __launch_bounds__(256) void gemm_f16_glds(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane source rows of the four 8-row chunks this wave stages per operand (chunk = wave * 4 + c)
     const f16 *srcA[4], *srcW[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const int r = (wave * 4 + c) * 8 + (lane >> 3);          // tile row of this lane's 16 bytes
-        const int slot = (lane & 7) ^ ((r >> 1) & 7);             // logical 16-byte column slot it must fetch
+        const int r = (wave * 4 + c) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
         const int gm = m0 + r < g.M ? m0 + r : g.M - 1, gn = n0 + r < g.N ? n0 + r : g.N - 1;
         srcA[c] = A + (size_t)gm * g.lda + slot * 8;
         srcW[c] = W + (size_t)gn * g.ldw + slot * 8;
@@ -284,20 +253,15 @@ __global__ __launch_bounds__(256) void gemm_f16_glds(GemmArgs g)
         unsigned char *ta = smem + buf * 2 * GL_TILE, *tb = ta + GL_TILE;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int off = (wave * 4 + c) * 1024;                // wave-uniform LDS base of the chunk
+            const int off = (wave * 4 + c) * 1024;
             __builtin_amdgcn_global_load_lds(srcA[c] + kt * 64, (lds_void *)(ta + off), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(srcW[c] + kt * 64, (lds_void *)(tb + off), 16, 0, 0);
         }
     };
-
     const int KT = g.K / 64;
     const int fr = lane & 15, fs = lane >> 4;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
-        const unsigned char *ta = smem + cur * 2 * GL_TILE, *tb = ta + GL_TILE;
+    auto compute = [&](int buf) {
+        const unsigned char *ta = smem + buf * 2 * GL_TILE, *tb = ta + GL_TILE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             f16x8 a[4], b[4];
@@ -317,7 +281,23 @@ __global__ __launch_bounds__(256) void gemm_f16_glds(GemmArgs g)
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();          // also drains this iteration's direct-to-LDS loads (vmcnt) before the next tile is read
+    };
+    if (SINGLE) {
+        for (int kt = 0; kt < KT; ++kt) {
+            stage(kt, 0);
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        stage(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
     }
     tile_epilogue_f16(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
@@ -833,7 +813,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
     if (dtype == SWX_F16) {
         if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;   // tiled: K % 32, skinny: K % 128
         const bool skinny_ok = g.M <= 128 && g.K % 128 == 0 && g.K / 128 <= 10 && g.N <= 16384;   // vocabulary-sized N: tiled
-        const bool use_skinny = force_kernel == 2 ? skinny_ok : ((force_kernel == 1 || force_kernel == 4) ? false : skinny_ok);
+        const bool use_skinny = force_kernel == 2 ? skinny_ok : ((force_kernel == 1 || force_kernel >= 4) ? false : skinny_ok);
         if (force_kernel == 2 && !skinny_ok) return -4;
         if (use_skinny) {
             SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * ((g.epi & EPI_OUT_F32) ? 4 : 2), s);
@@ -853,9 +833,13 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
             dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
             const bool glds_ok = g.K % 64 == 0 && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0);
-            if (force_kernel == 4 && !glds_ok) return -4;
-            if (glds_ok && (force_kernel == 4 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
-                hipLaunchKernelGGL(gemm_f16_glds, grid, dim3(256), 0, s, g);
+            if (force_kernel >= 4 && !glds_ok) return -4;
+            if (glds_ok && (force_kernel == 4 || force_kernel == 5))
+                hipLaunchKernelGGL((gemm_f16_glds<false, 2>), grid, dim3(256), 0, s, g);
+            else if (glds_ok && force_kernel == 6)
+                hipLaunchKernelGGL((gemm_f16_glds<true, 4>), grid, dim3(256), 0, s, g);
+            else if (glds_ok && (force_kernel == 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
+                hipLaunchKernelGGL((gemm_f16_glds<true, 3>), grid, dim3(256), 0, s, g);
             else
                 hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
         }

@@ -38,6 +38,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_DEC_V3 512        // decode step on the un-split "dec" GEMMs (swx_decstep.hip) when the batch has enough rows
 #define SWX_FLAG_NO_PACKED_XKV 2048 // decode cross-attention reads the row-layout K / V^T instead of the fragment-ordered copy (A/B)
 #define SWX_FLAG_FLASH_V1 4096      // MFMA flash attention: first-generation kernel (A/B)
+#define SWX_FLAG_SELECT_MEM 8192    // logit filters + token selection: the kernel that walks the row in memory (A/B and bit-identity reference)
 #define SWX_FLAG_DEC_V3_FORCE 1024 // ... for every row count (tests)
 #define SWX_FLAG_GLDS_GEMM 256     // tiled f16 GEMM (encoder, cross-KV, scoring): direct-to-LDS operand staging (global_load_lds)
 #define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q | SWX_FLAG_DEC_V3 | SWX_FLAG_GLDS_GEMM)
@@ -83,6 +84,7 @@ struct DecGemmArgs {
     _Float16 *X; int64_t ldx;
     float *slabs;                        // swx_dec_slab_floats(M, N, K) floats when the shape runs K-split
     _Float16 *kcache, *vcache; const int32_t *pos0; int n_ctx, d;
+    int rps;                             // DEC_QKV: rows per sequence (0 / 1: one new token per row); row m = sequence m / rps, token m % rps
     int ks2, kslice, n_rg; int64_t slab_stride;   // filled by the launcher
     int abl;                             // experiment switches (SWX_DEC_ABL, scripts/dec_ablate.sh); 0 in production
 };

@@ -67,6 +67,7 @@ struct swx_model {
         size_t kcache, vcache, sk, sv, cap, mean, sd, suppress, slabs, heads, win_uid;
         size_t total;
         int64_t rows_big, logits_rows;
+        size_t slab_bytes;
     } L;
 
     template <typename P> P *A(size_t off) const { return (P *)(arena + off); }
@@ -258,7 +259,10 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
         for (auto &sh : shapes) { const size_t f = swx_skinny_slab_floats(128, sh[0], sh[1]); if (f > mx) mx = f; }
         const size_t f3 = swx_dec_slab_floats(Mmax > 128 ? Mmax : 128, dt, 4 * dt);     // the K = 4d projection of the "dec" step
         if (f3 > mx) mx = f3;
+        const size_t f4 = swx_dec_slab_floats(160, dt, 4 * dt);      // the small multi-token pass on the dec GEMMs
+        if (f4 > mx) mx = f4;
         L.slabs = take(mx * 4 + 256);
+        L.slab_bytes = mx * 4;
     }
     // the alignment-head list lives with the workspace, not with the weights: views that share one weight arena
     // (swx_bind_weights on the same buffer) may be configured with different heads
@@ -274,9 +278,10 @@ struct ProfRec { int cls; double work; hipEvent_t a, b; };
 bool g_prof_enabled = false;
 // decode-step switches (SWX_FLAG_* in swx_kernels.h); the environment variable SWX_FLAGS overrides the built-in default
 int g_debug_flags = [] { const char *e = getenv("SWX_FLAGS"); return e ? atoi(e) : SWX_DEFAULT_FLAGS; }();
-// the un-split "dec" step is used from this many live sequences on (below it a launch has too few workgroups: the split-K step
-// spreads a small batch over more CUs); SWX_DEC_MIN_ROWS overrides
-int g_dec_min_rows = [] { const char *e = getenv("SWX_DEC_MIN_ROWS"); return e ? atoi(e) : 48; }();
+// the un-split "dec" step is used from this many live sequences on; SWX_DEC_MIN_ROWS overrides.  Measured (round 2, call 7): with
+// the threshold at 48 rows the sequential transcribe() (5 rows) ran 48x real time, batch 4 295x, batch 8 502x; at 1: 62x /
+// 394x / 654x -- the un-split step wins at every row count, so it is always used.
+int g_dec_min_rows = [] { const char *e = getenv("SWX_DEC_MIN_ROWS"); return e ? atoi(e) : 1; }();
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -473,8 +478,75 @@ int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
     return 0;
 }
 
+// Multi-token teacher-forced pass over a SMALL number of rows (align(): one window of ~110 tokens; refine / locate probes) on
+// the same un-split "dec" GEMMs as the decode step: at <= 160 rows the tiled MFMA GEMM launches one or two row blocks and the
+// 16-column skinny kernel 27 us per projection, while a dec launch finishes its outputs (bias / GELU / residual / K,V scatter,
+// LayerNorm folded) in ~7 us.  Self-attention (causal over the new tokens), cross-attention and the alignment-head capture are
+// the general kernels.  Leaves the raw residual stream in `x` (returns 0).
+int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
+{
+    const swx_dims &D = m->dims;
+    const int d = D.n_text_state, H = D.n_text_head;
+    const size_t e = m->esz;
+    const int R = f.W * f.rpw, rows = R * f.n_new;
+    f16 *x = m->Wp<f16>(m->L.x), *q = m->Wp<f16>(m->L.qkv), *att = m->Wp<f16>(m->L.att), *u = m->Wp<f16>(m->L.u);
+    float *slabs = m->Wp<float>(m->L.slabs);
+    SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, R, f.n_new, m->arena + m->o_tok_emb,
+                      m->A<float>(m->o_dec_pos), d, x, s));
+    const int64_t chunk = xkv_chunk_elems(m);
+    for (int l = 0; l < D.n_text_layer; ++l) {
+        const LayerW &w = m->dec[l];
+        f16 *kc = (f16 *)(f.kcache + (size_t)l * f.layer_stride), *vc = (f16 *)(f.vcache + (size_t)l * f.layer_stride);
+        DecGemmArgs g{};
+        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wqkv_f); g.ldw = d; g.N = 3 * d; g.K = d; g.epi = DEC_LN | DEC_QKV;
+        g.c1 = m->A<float>(w.qkv_c1); g.c2 = m->A<float>(w.qkv_c2); g.C = q; g.ldc = d;
+        g.kcache = kc; g.vcache = vc; g.pos0 = f.pos0; g.n_ctx = D.n_text_ctx; g.d = d; g.rps = f.n_new;
+        SWX_TRY(swx_gemm_dec(g, s));
+        SelfAttnArgs sa{};
+        sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
+        sa.R = R; sa.n_new = f.n_new; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
+        SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
+        g = DecGemmArgs{};
+        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        g = DecGemmArgs{};
+        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
+        g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
+        AttnArgs ca{};
+        ca.q = q; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
+        ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
+        ca.B = f.W; ca.H = H; ca.nq = f.rpw * f.n_new; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw * f.n_new;
+        SWX_TRY(swx_attention(m->dtype, ca, 0, s));
+        if (f.capture && !m->heads_by_layer[l].empty()) {
+            SWX_TRY(swx_qk_capture(m->dtype, q, d, f.rpw * f.n_new, f.cap_row0, f.cap_rows, kl, d, chunk, D.n_audio_ctx,
+                                   m->Wp<int32_t>(m->L.heads) + m->head_slot0[l], (int)m->heads_by_layer[l].size(),
+                                   m->head_slot0[l], m->n_align, f.W, m->Wp<float>(m->L.cap), f.cap_ld_n, D.n_audio_ctx, s));
+        }
+        g = DecGemmArgs{};
+        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.c2 = m->A<float>(w.bco); g.X = x; g.ldx = d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        g = DecGemmArgs{};
+        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.w1_f); g.ldw = d; g.N = 4 * d; g.K = d; g.epi = DEC_LN | DEC_GELU;
+        g.c1 = m->A<float>(w.w1_c1); g.c2 = m->A<float>(w.w1_c2); g.C = u; g.ldc = 4 * d;
+        SWX_TRY(swx_gemm_dec(g, s));
+        g = DecGemmArgs{};
+        g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
+        g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
+        SWX_TRY(swx_gemm_dec(g, s));
+    }
+    return 0;
+}
+
 int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
+    if (m->dtype == SWX_F16 && m->folded && f.n_new > 1 && f.row_mul == 1 && f.W * f.rpw * f.n_new <= 160 &&
+        (g_debug_flags & SWX_FLAG_DEC_V3) && !(g_debug_flags & SWX_FLAG_NO_FAST_STEP) &&
+        swx_dec_slab_floats(f.W * f.rpw * f.n_new, m->dims.n_text_state, 4 * m->dims.n_text_state) * 4 <= m->L.slab_bytes)
+        return decoder_forward_dec(m, f, s);
     if (m->dtype == SWX_F16 && m->folded && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.rpw <= 16 && m->dims.n_audio_ctx >= 128 &&
         !(g_debug_flags & SWX_FLAG_NO_FAST_STEP) &&
         ((g_debug_flags & SWX_FLAG_DEC_V3_FORCE) || ((g_debug_flags & SWX_FLAG_DEC_V3) && f.W * f.rpw >= g_dec_min_rows)) &&

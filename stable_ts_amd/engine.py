@@ -347,6 +347,41 @@ def dtw(x: torch.Tensor, N: Sequence[int], M: Sequence[int]):
     return [(ti[w, :ln[w]].astype(np.int64), tj[w, :ln[w]].astype(np.int64)) for w in range(W)]
 
 
+def loudness_probe(chunks: Sequence[torch.Tensor]) -> list:
+    """Device half of the non-VAD silence analysis for a batch of windows that are resident on the GPU
+    (``swx_loudness_probe``): per window ``(n, thr, idx, vals)`` -- the k-th largest |x| (k = 0.1 % of the samples,
+    nonvad.py:19-22) and |x| at ``stabilization.probe_indices(n)`` -- or None for a window too short for a mask.  One launch,
+    one copy-out of 24 KB per window (the full-length host path copies 1.9 MB per window and selects on the host)."""
+    from .stabilization import probe_indices
+    lib = _lib.load()
+    W = len(chunks)
+    dev = chunks[0].device
+    ns = [int(c.shape[-1]) for c in chunks]
+    idxs = [probe_indices(n) for n in ns]
+    n_idx = max((len(i) for i in idxs if i is not None), default=0)
+    if n_idx == 0:
+        return [None] * W
+    stride = max(ns)
+    buf = torch.empty(W, stride, dtype=torch.float32, device=dev)
+    h_idx = np.full((W, n_idx), -1, dtype=np.int32)
+    h_nk = np.zeros((W, 2), dtype=np.int32)
+    for w, (c, n, ix) in enumerate(zip(chunks, ns, idxs)):
+        buf[w, :n] = c.detach().to(dtype=torch.float32)
+        h_nk[w] = (n, int(n * 0.001))
+        if ix is not None:
+            h_idx[w, :len(ix)] = ix
+    d_idx = torch.from_numpy(h_idx).to(dev)
+    d_nk = torch.from_numpy(h_nk).to(dev)
+    out = torch.empty(W, n_idx + 1, dtype=torch.float32, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    check(lib.swx_loudness_probe(_ptr(buf), stride, _ptr(d_nk), _ptr(d_idx), n_idx, W, _ptr(out), stream), "swx_loudness_probe")
+    h = out.cpu()
+    res = []
+    for w, (n, ix) in enumerate(zip(ns, idxs)):
+        res.append(None if ix is None else (n, float(h[w, 0]), ix, h[w, 1:1 + len(ix)].clone()))
+    return res
+
+
 def median_filter(x: torch.Tensor, width: int) -> torch.Tensor:
     """whisper.timing.median_filter on the device (f32, last axis)."""
     lib = _lib.load()

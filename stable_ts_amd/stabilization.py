@@ -6,7 +6,9 @@ stabilization/nonvad.py:16-88 (loudness quantisation), stabilization/utils.py:43
 stabilization/__init__.py:16-135,241-254 (NonSpeechPredictor, non-VAD branch) and :300-379 (suppress_silence),
 result.py:681-705 (per-word ``keep_end`` policy).  Silero VAD (``vad=True``) needs torch.hub + network: out of scope.
 """
-from typing import List, Optional, Tuple
+import functools
+import threading
+from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -59,9 +61,60 @@ def timing2mask(starts: np.ndarray, ends: np.ndarray, size: int) -> torch.Tensor
     return out
 
 
-def wav2mask(audio: torch.Tensor, q_levels: int = 20, k_size: int = 5) -> Optional[torch.Tensor]:
-    """nonvad.py:43-88: boolean SILENCE mask per 20-ms unit, or None when the window has no silence."""
-    loud = audio2loudness(audio)
+@functools.lru_cache(maxsize=64)
+def probe_indices(n: int) -> Optional[np.ndarray]:
+    """The sample indices that ``F.interpolate(|x|, size=units, mode='linear')`` of ``audio2loudness`` reads for a window of
+    ``n`` samples (two per 20-ms unit: ``floor(src)`` and its right neighbour, ``src = scale (i + 0.5) - 0.5`` in float32),
+    plus one more sample on either side so that a last-bit difference in ``src`` cannot matter.  int32 [4 * units], or None
+    when the window is too short for a mask (nonvad.py:27-29)."""
+    units = round(n / N_SAMPLES_PER_TOKEN) + 1
+    if units <= 2:
+        return None
+    scale = np.float32(n) / np.float32(units)
+    src = np.maximum(scale * (np.arange(units, dtype=np.float32) + np.float32(0.5)) - np.float32(0.5), np.float32(0.0))
+    i0 = src.astype(np.int64)
+    idx = np.stack([i0 - 1, i0, i0 + 1, i0 + 2], axis=1).clip(0, n - 1)
+    return np.ascontiguousarray(idx.reshape(-1).astype(np.int32))
+
+
+_probe_scratch = threading.local()
+
+
+def loudness_from_probe(n: int, thr: float, idx: np.ndarray, vals: torch.Tensor) -> Union[torch.Tensor, None, bool]:
+    """``audio2loudness`` of a window of ``n`` samples from the device probe (``swx_loudness_probe``): ``thr`` = the k-th
+    largest |x| (bit for bit the value the host selection returns), ``vals`` = |x| at ``idx = probe_indices(n)``.  The
+    division and the interpolation run through the SAME torch expressions as the full-length path, on a length-``n`` array
+    that holds the gathered samples at their positions and NaN everywhere else: the interpolation reads two samples per
+    output, so the result is the full path's bit for bit -- and if it ever read a sample that was not gathered the NaN
+    would show, in which case False is returned and the caller takes the full path."""
+    units = round(n / N_SAMPLES_PER_TOKEN) + 1
+    if units <= 2:
+        return None
+    if not np.isfinite(thr):
+        return False                                   # k == 0 (fewer than 1000 samples): the quantile branch, host path
+    thr_t = torch.tensor(np.float32(thr))
+    if thr_t < 1e-5:
+        return torch.zeros(units, dtype=torch.float32)
+    cache = getattr(_probe_scratch, "buf", None)
+    if cache is None:
+        cache = _probe_scratch.buf = {}
+    x = cache.get(n)
+    if x is None:
+        if len(cache) > 4:
+            cache.clear()
+        x = cache[n] = torch.full((n,), float("nan"), dtype=torch.float32)
+    x[torch.from_numpy(idx.astype(np.int64))] = vals / min(1.0, float(thr_t) * 1.75)
+    out = F.interpolate(x[None, None], size=units, mode="linear", align_corners=False)[0, 0]
+    if bool(torch.isnan(out).any()):
+        return False
+    return out
+
+
+def wav2mask(audio: Optional[torch.Tensor], q_levels: int = 20, k_size: int = 5, *, loud=False) -> Optional[torch.Tensor]:
+    """nonvad.py:43-88: boolean SILENCE mask per 20-ms unit, or None when the window has no silence.  ``loud``: the window's
+    loudness curve when it was computed elsewhere (``loudness_from_probe``); False = compute it from ``audio``."""
+    if loud is False:
+        loud = audio2loudness(audio)
     if loud is None:
         return None
     p = k_size // 2 if k_size else 0
@@ -112,7 +165,19 @@ class NonSpeechPredictor:
         pad[:n] = mask[:n]
         return pad
 
-    def predict(self, audio: torch.Tensor, offset: float = 0.0) -> dict:
+    def predict(self, audio: Optional[torch.Tensor], offset: float = 0.0, *, loud=False) -> dict:
+        """``loud``: the loudness curve of the window from the device probe (``loudness_from_probe``; None = window too short
+        for a mask); with it ``audio`` is not read."""
+        if loud is False and self.loudness and audio is not None and audio.is_cuda:
+            # a window that is resident on the GPU: k-th largest level + the samples the curve reads come from the device
+            # probe (24 KB instead of a 1.9 MB copy-out and a host selection); same values, same arithmetic
+            from .engine import loudness_probe
+            pr = loudness_probe([audio.reshape(-1)])[0]
+            got = None if pr is None else loudness_from_probe(*pr)
+            if got is not False:
+                loud = got
+        if loud is not False and self.loudness:
+            return self._from_mask(wav2mask(None, self.q_levels, self.k_size, loud=loud), offset)
         audio = audio.detach().float().cpu().contiguous()
         if not self.loudness:
             # :271-286 with get_mask: one flag per 20-ms unit, True where EVERY sample of the unit is non-zero
@@ -127,7 +192,9 @@ class NonSpeechPredictor:
             mask = torch.all(audio.reshape(-1, N_SAMPLES_PER_TOKEN) != 0, dim=-1)
             silent = bool((mask.shape[-1] - int(mask.count_nonzero())) < self.min_units_per_word)
             return dict(timings=None, mask=self._pad(mask), is_silent=silent)
-        mask = wav2mask(audio, self.q_levels, self.k_size)
+        return self._from_mask(wav2mask(audio, self.q_levels, self.k_size), offset)
+
+    def _from_mask(self, mask: Optional[torch.Tensor], offset: float) -> dict:
         timings = mask2timing(mask, time_offset=offset)
         if timings is not None:
             timings = np.stack(timings, axis=0)

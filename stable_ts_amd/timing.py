@@ -272,6 +272,8 @@ def find_alignment_batch(model, jobs: Sequence[AlignmentJob], xkv, *, medfilt_wi
     """timing.py:202-306 for W windows at once: scoring pass + alignment matrix + DTW on the device."""
     tok = jobs[0].tokenizer
     eng = model.engine
+    import time
+    _t0 = time.perf_counter()
     if dynamic_heads or extra_models or aligner != "legacy" or getattr(model, "missing_alignment_heads", False):
         res = _find_alignment_variants(model, jobs, xkv, medfilt_width=medfilt_width, qk_scale=qk_scale,
                                        dynamic_heads=dynamic_heads, aligner=aligner, extra_models=extra_models, mel=mel,
@@ -281,6 +283,11 @@ def find_alignment_batch(model, jobs: Sequence[AlignmentJob], xkv, *, medfilt_wi
         probs, neg, T = eng.score(xkv, [j.tokens for j in jobs], [j.n_frames for j in jobs], n_sot=len(tok.sot_sequence),
                                   eot=tok.eot, qk_scale=qk_scale, medfilt_width=medfilt_width)
         paths = eng.dtw(neg, [t + 1 for t in T], [j.n_frames for j in jobs])
+    from . import transcribe as _tr
+    if _tr.PHASE_TIMES is not None:                       # diagnostic: device part of the word-timestamp stage
+        import time
+        _tr.PHASE_TIMES["  of which device (score + a7 + DTW, synchronous copy-out)"] = (
+            _tr.PHASE_TIMES.get("  of which device (score + a7 + DTW, synchronous copy-out)", 0.0) + time.perf_counter() - _t0)
     out = []
     for w, job in enumerate(jobs):
         text_idx, time_idx = paths[w]

@@ -13,6 +13,7 @@ Two drivers share one per-batch routine:
     SURVEY.md 8e describes for throughput / sharding; its oracle is "the reference run on each 30-s clip separately".
 Out of scope here: yt-dlp URLs, denoisers, VAD models, resume (non-WAVE containers need ffmpeg on PATH).
 """
+import time
 import warnings
 from dataclasses import replace
 from typing import Callable, List, Optional, Sequence, Tuple, Union
@@ -26,6 +27,21 @@ from .decoding import DecodingOptions, DecodingPlan, DecodingResult
 from .result import WhisperResult
 from .timing import APPEND_PUNCTUATIONS, PREPEND_PUNCTUATIONS, add_word_timestamps_batch
 from .tokenizer import get_tokenizer
+
+# Diagnostic only (bench.py --phase-times): when set to a dict, _process_batch synchronises the device at each stage boundary
+# and accumulates wall seconds per stage, so that the host-side share of a pass can be read off.  None in normal operation
+# (the product path never synchronises between the stages).
+PHASE_TIMES: Optional[dict] = None
+
+
+def _phase(name: str, t0: float) -> float:
+    import time
+    if PHASE_TIMES is None:
+        return t0
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    PHASE_TIMES[name] = PHASE_TIMES.get(name, 0.0) + (t - t0)
+    return t
 
 _DECODE_KEYS = set(DecodingOptions.__dataclass_fields__)
 
@@ -166,9 +182,13 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
     W = len(batch)
     audios = [b["audio"] for b in batch]
     seg_samples = [int(a.shape[-1]) for a in audios]
+    import time
+    t_ph = time.perf_counter() if PHASE_TIMES is not None else 0.0
     mel = model.log_mel_batch(audios, [max(N_SAMPLES - n, 0) for n in seg_samples])          # :528-530
+    t_ph = _phase("mel", t_ph)
     xa = model.encoder(mel)
     xkv = model.cross_kv(xa)
+    t_ph = _phase("encoder+cross_kv", t_ph)
     ts_masks = [b.get("ts_mask") for b in batch] if o["suppress_ts_tokens"] else None
     if ts_masks is not None and all(m is None for m in ts_masks):
         ts_masks = None
@@ -177,6 +197,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
     results = _decode_with_fallback(model, xkv, o["decode_options"], o["temperatures"], [b["prompt"] for b in batch],
                                     ts_masks, o["compression_ratio_threshold"], o["logprob_threshold"],
                                     o["no_speech_threshold"], uids=[int(b["seek_sample"]) // 160 for b in batch])
+    t_ph = _phase("decode (device loop + result copy)", t_ph)
     time_precision = (N_FRAMES // model.dims.n_audio_ctx) * HOP_LENGTH / SAMPLE_RATE
     punct = o["prepend_punctuations"] + o["append_punctuations"]
     outs = []
@@ -219,6 +240,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
         out["num_samples"] = (min(round(end_ts_pos * N_SAMPLES_PER_TOKEN), seg_samples[w]) if end_ts_pos > 0
                               else seg_samples[w])                                              # :629-633
 
+    t_ph = _phase("host: segment slicing", t_ph)
     if o["word_timestamps"]:
         idx = [w for w in range(W) if outs[w]["segments"]]
         if idx:
@@ -230,6 +252,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
                 split_callback=o["split_callback"], gap_padding=o["gap_padding"], dynamic_heads=o.get("dynamic_heads"),
                 aligner=o.get("aligner", "legacy"), extra_models=o.get("extra_models"),
                 mel=mel[idx] if o.get("extra_models") else None)
+        t_ph = _phase("word timestamps (scoring pass + a7 + DTW + host word assembly)", t_ph)
         for w in idx:
             out = outs[w]
             segs = out["segments"]
@@ -371,11 +394,34 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     def host_copy(seg: torch.Tensor) -> torch.Tensor:
         return seg.detach().float().cpu()                       # silence analysis is host-side vector code (CPU)
 
+    def predict_nonspeech(tr_ns, chunks: List[torch.Tensor], offsets: List[float], pool_=None) -> List[dict]:
+        """The silence analysis of some windows.  Windows that are resident on the GPU go through the device probe (k-th
+        largest level + the ~6000 samples the loudness curve reads; engine.loudness_probe) and only the curve's arithmetic
+        runs on the host -- the same expressions on the same values, so the masks are those of the full-length host path,
+        which is what windows on the host, the exact-zero mode (suppress_silence=False) and probe refusals still take."""
+        from .stabilization import loudness_from_probe
+        probes = [False] * len(chunks)
+        if tr_ns.loudness and chunks and all(c.is_cuda for c in chunks):
+            from .engine import loudness_probe
+            probes = loudness_probe(chunks)
+
+        def one(a):
+            ch, off, pr = a
+            if pr is False:
+                return tr_ns.predict(host_copy(ch), offset=off)
+            loud = None if pr is None else loudness_from_probe(*pr)
+            if loud is False:
+                return tr_ns.predict(host_copy(ch), offset=off)
+            return tr_ns.predict(None, offset=off, loud=loud)
+
+        args = list(zip(chunks, offsets, probes))
+        return list(pool_.map(one, args)) if (pool_ is not None and len(args) > 1) else [one(a) for a in args]
+
     def window_input(tr: _Track, seek: int, seg: torch.Tensor, prompt: List[int], pred: Optional[dict] = None):
         item = dict(audio=seg, seek_sample=seek, prompt=prompt, ts_mask=None, silence=None, skip=False)
         if tr.nonspeech is not None:
             if pred is None:
-                pred = tr.nonspeech.predict(host_copy(seg), offset=seek / SAMPLE_RATE)
+                pred = predict_nonspeech(tr.nonspeech, [seg], [seek / SAMPLE_RATE])[0]
             item["silence"] = pred["timings"] if suppress_silence else None
             item["ts_mask"] = pred["mask"]
             item["skip"] = pred["is_silent"]
@@ -486,9 +532,11 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
         try:
             for group in batches():
                 preds = [None] * len(group)
+                t_ph = time.perf_counter() if PHASE_TIMES is not None else 0.0
                 if pool is not None and len(group) > 1:
-                    preds = list(pool.map(lambda g: nonspeech.predict(host_copy(g[1]), offset=g[0] / SAMPLE_RATE), group))
+                    preds = predict_nonspeech(nonspeech, [g[1] for g in group], [g[0] / SAMPLE_RATE for g in group], pool)
                 items = [window_input(tr0, sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
+                t_ph = _phase("host: silence analysis of the batch (copy-out + loudness, 8 threads)", t_ph)
                 live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
                 tr0.started = tr0.started or bool(live)
                 if live:
@@ -503,8 +551,10 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                     outs = [x for r in lane_pool.map(run_lane, lanes, parts) for x in r]
                 else:
                     outs = _process_batch(model, tokenizer, live, o) if live else []
+                t_ph = time.perf_counter() if PHASE_TIMES is not None else 0.0
                 for it, out in zip(live, outs):
                     commit(tr0, it, out)
+                t_ph = _phase("host: commit (silence suppression of the word times)", t_ph)
                 done += len(items)
                 if progress_callback is not None:
                     total = loader.get_total_samples()
@@ -561,7 +611,9 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
 
     if _span_bounds:
         return [(tr.offset, finish(tr)) for tr in tracks]
+    t_ph = time.perf_counter() if PHASE_TIMES is not None else 0.0
     result = finish(tr0)
+    _phase("host: result assembly (WhisperResult, non-speech sections)", t_ph)
     if interrupted:
         result.unfinished_start = interrupted[0]                                                # :776
     if len(result.text) == 0:

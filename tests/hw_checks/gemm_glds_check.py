@@ -1,6 +1,6 @@
-"""Hardware check of the direct-to-LDS tiled GEMM (gemm_f16_glds, force_kernel = 4): it runs the same MFMA sequence per
-accumulator as gemm_f16_tiled (force_kernel = 1), so the two must agree BIT FOR BIT; both are also held to a torch fp32
-reference.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
+"""Hardware check of the direct-to-LDS tiled GEMM (gemm_f16_glds<SINGLE, OCC>, force_kernel = 5 double buffered, 6 / 7
+single buffered at 4 / 3 workgroups per CU; 7 is the default): each runs the same MFMA sequence per accumulator as
+gemm_f16_tiled (force_kernel = 1), so all must agree BIT FOR BIT; they are also held to a CPU float64 reference.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
 
     python tests/hw_checks/gemm_glds_check.py
 """
@@ -26,13 +26,14 @@ def main() -> int:
     bad = 0
     for (M, N, K, epi) in [(128, 128, 64, 0), (300, 384, 384, EPI_BIAS), (1500, 1280, 1280, EPI_BIAS | EPI_GELU),
                            (1000, 1152, 3840, EPI_BIAS | EPI_RES), (3000, 1000, 1280, EPI_BIAS), (257, 5120, 5120, EPI_BIAS | EPI_RES),
-                           (4500, 3840, 1280, EPI_BIAS)]:
+                           (4500, 3840, 1280, EPI_BIAS), (30000, 1280, 1280, EPI_BIAS | EPI_RES), (77, 136, 128, EPI_BIAS | EPI_RES),
+                           (1500, 5120, 1280, EPI_BIAS | EPI_GELU)]:
         a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
         w = (torch.randn(N, K, generator=g) * 0.03).half().to(dev)
         bias = torch.randn(N, generator=g).float().to(dev)
         res = torch.randn(M, N, generator=g).half().to(dev)
         outs = []
-        for force in (1, 4):
+        for force in (1, 5, 6, 7):
             c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
             rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), p(res) if epi & EPI_RES else None, p(c), N, M, N, K, epi, force, st)
             torch.cuda.synchronize()
@@ -44,8 +45,8 @@ def main() -> int:
             ref = torch.nn.functional.gelu(ref)
         if epi & EPI_RES:
             ref = ref + res.cpu().double()
-        (rc1, c1), (rc4, c4) = outs
-        same = rc1 == 0 and rc4 == 0 and torch.equal(c1, c4)
+        (rc1, c1), (rc4, c4) = outs[0], outs[1]
+        same = rc1 == 0 and all(rc == 0 and torch.equal(c1, c) for rc, c in outs[1:])     # 5 / 6 / 7: generation-2 variants
         err = ((c4.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max().item() if rc4 == 0 else float("inf")
         ok = same and err < 4e-3
         print(("ok   " if ok else "FAIL ") + f"M={M} N={N} K={K} epi={epi}: rc={rc1},{rc4} identical to tiled={same} max rel err vs CPU f64 {err:.2e}")

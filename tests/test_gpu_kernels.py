@@ -3,6 +3,7 @@
 bit-exact: DTW paths, median filter.   Tolerances (stated per test) for floating-point kernels.
 """
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -307,7 +308,7 @@ def test_attention_decode_cross_kernel(B, H, nq, nk):
 
 @pytest.mark.parametrize("check", ["splitk_hook_check.py", "gemm_glds_check.py", "mel_ragged_check.py", "score_qk_check.py"])
 def test_new_kernel_paths_in_subprocess(check):
-    # swx_test_gemm_splitk (new C-ABI test hook), gemm_f16_glds (direct-to-LDS tiled GEMM, off by default) and
+    # swx_test_gemm_splitk (new C-ABI test hook), gemm_f16_glds (direct-to-LDS tiled GEMM, all three variants) and
     # swx_log_mel_ragged (the un-padded spectrogram of refine / locate; index logic CPU-checked in test_mel_ragged_cpu),
     # swx_score_qk (raw per-head scores for the dynamic-heads / 'new' aligner variants; host logic CPU-checked).  Own
     # process: a first-ever hardware run of new device code must not be able to disturb this process's GPU context.
@@ -423,3 +424,46 @@ def test_dec_gemm_qkv_scatter(M, d):
         mask = np.ones(n_ctx, bool)
         mask[pos0[m]] = False
         assert (got["kcache"][m, mask] == 0).all() and (got["vcache"][m, mask] == 0).all()      # nothing else is touched
+
+
+# ------------------------------------------------------------------------------------- silence analysis, device half
+def test_loudness_probe_kernel():
+    # swx_loudness_probe vs numpy on the same samples: the k-th largest |x| (radix select on the bit patterns) must be the
+    # element np.partition returns, the gathered |x| the elements at probe_indices -- bit for bit (a selection and a gather,
+    # no arithmetic); then NonSpeechPredictor on DEVICE audio (which goes through the probe) must return what it returns
+    # for the same audio on the host (full-length path): timings, padded mask, is_silent.
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_cpu import _probe_cases
+    from stable_ts_amd.engine import loudness_probe
+    from stable_ts_amd.stabilization import NonSpeechPredictor, probe_indices
+    cases = _probe_cases()
+    g = torch.Generator().manual_seed(5)
+    cases += [torch.randn(480000, generator=g) * s for s in (1.0, 1e-3, 30.0)]
+    cases += [torch.full((480000,), 0.25), torch.cat([torch.zeros(479000), torch.ones(1000) * 0.5])]     # ties at the threshold
+    probes = loudness_probe([c.cuda() for c in cases])
+    n_checked = 0
+    for x, pr in zip(cases, probes):
+        n = x.numel()
+        idx = probe_indices(n)
+        if idx is None:
+            assert pr is None
+            continue
+        pn, thr, pidx, vals = pr
+        assert pn == n and np.array_equal(pidx, idx)
+        ax = x.abs().numpy()
+        k = int(n * 0.001)
+        if k:
+            want = np.partition(ax, ax.size - k)[ax.size - k]
+            assert np.float32(thr).tobytes() == np.float32(want).tobytes(), (n, thr, want)
+        else:
+            assert np.isnan(thr)
+        assert np.array_equal(vals.numpy(), ax[idx]), n
+        a, b = NonSpeechPredictor(get_mask=True), NonSpeechPredictor(get_mask=True)
+        r1, r2 = a.predict(x.clone(), offset=7.0), b.predict(x.cuda(), offset=7.0)
+        assert (r1["timings"] is None) == (r2["timings"] is None)
+        assert r1["timings"] is None or np.array_equal(r1["timings"], r2["timings"])
+        assert (r1["mask"] is None) == (r2["mask"] is None) and (r1["mask"] is None or torch.equal(r1["mask"], r2["mask"]))
+        assert r1["is_silent"] == r2["is_silent"]
+        n_checked += 1
+    assert n_checked >= 12

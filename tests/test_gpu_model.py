@@ -321,6 +321,42 @@ def test_decode_f16_packed_cross_kv_is_bit_identical(name, beam):
     assert np.array_equal(np.asarray(packed["sum_logprobs"]), np.asarray(rows["sum_logprobs"]))
 
 
+@pytest.mark.parametrize("name,mode", [("tiny.en", "greedy"), ("tiny.en", "beam"), ("base.en", "sample"), ("base.en", "beam_masks"),
+                                       ("tiny.en", "greedy_free")])
+def test_decode_select_register_kernel_is_bit_identical(name, mode):
+    # decode_select_reg_kernel (the logits row read once into registers) vs decode_select_kernel (11-16 walks of the row in
+    # memory, flag 8192): same element-to-thread assignment and summation order by construction, so tokens, lengths, sums of
+    # log-probabilities must be IDENTICAL -- greedy, beam, temperature sampling (Gumbel keyed on the window id), with the
+    # timestamp rules on / off, a max_initial_timestamp, silence-masked timestamp tokens, EOT allowed early (min_tokens 0).
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 97, B=3)
+    beam = mode.startswith("beam")
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", sample_len=36,
+                                                     max_initial_timestamp=1.0 if mode == "beam_masks" else None,
+                                                     beam_size=5 if beam else None))
+    kw = dict(n_group=task.n_group, beam=beam, sample_len=36, sot_index=task.sot_index,
+              min_tokens=0 if mode == "greedy_free" else 36, **_tok_cfg(task.tokenizer, task))
+    if mode == "sample":
+        kw.update(temperature=0.7, seed=1234, window_uid=[7, 300, 12])
+    if mode == "beam_masks":
+        g = torch.Generator().manual_seed(3)
+        kw.update(ts_mask=torch.rand(3, 1501, generator=g) < 0.4, max_initial_timestamp_index=50)
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    old = lib.swx_debug_flags(-1)
+    try:
+        assert not (old & 8192)
+        reg = eng.decode(xkv, [list(task.initial_tokens)] * 3, **kw)
+        lib.swx_debug_flags(old | 8192)
+        mem = eng.decode(xkv, [list(task.initial_tokens)] * 3, **kw)
+    finally:
+        lib.swx_debug_flags(old)
+    assert np.array_equal(np.asarray(reg["lens"]), np.asarray(mem["lens"]))
+    assert np.array_equal(np.asarray(reg["tokens"]), np.asarray(mem["tokens"]))
+    assert np.array_equal(np.asarray(reg["sum_logprobs"]), np.asarray(mem["sum_logprobs"]))
+
+
 @pytest.mark.parametrize("name,beam", [("tiny.en", False), ("base.en", True)])
 @pytest.mark.parametrize("flags", [4, 16, 32, 64, 4 | 16, 4 | 16 | 64, 4 | 16 | 32 | 64])
 def test_decode_f16_step_switches_are_bit_identical(name, beam, flags):
@@ -385,6 +421,54 @@ def test_score_alignment_dtw_strict(name, heads):
         ri, rj = cache["dtw_path"]
         ti, tj = paths[w]
         assert ti.tolist() == ri.tolist() and tj.tolist() == rj.tolist()
+
+
+@pytest.mark.parametrize("name", ["tiny.en", "base.en"])
+def test_score_f16_small_pass_on_dec_gemms_equals_general_path(name):
+    # teacher-forced pass of ONE window (<= 160 rows) on the decode-step "dec" GEMMs (decoder_forward_dec: LayerNorm folded,
+    # K / V scattered by the QKV epilogue at pos0 + token index) vs the per-op path (flag 512 cleared), both f16, on weights
+    # with non-trivial LayerNorm gamma / beta; then both against the f32 oracle.  This is the pass align() runs per window.
+    from stable_ts_amd import _lib
+    from stable_ts_amd.engine import Engine, ModelDimensions
+    lib = _lib.load()
+    d = _dims(name)
+    key = ("ej1", name)
+    if key not in _CACHE:
+        eng = Engine(ModelDimensions(**d.__dict__), dtype="f16", max_windows=1, max_rows=5)
+        eng.load_state_dict(om.random_state_dict(d, 1234, 0.02, 3.0, 1.0, 0.1))
+        _CACHE[key] = eng
+    if ("oj", name) not in _CACHE:
+        _CACHE[("oj", name)] = om.build_model(name, seed=1234, std=0.02, embed_gain=3.0, ln_jitter=0.1)
+    eng, m = _CACHE[key], _CACHE[("oj", name)]
+    heads_list = [tuple(p) for p in m.alignment_heads.indices().T.tolist()]
+    eng.set_alignment_heads(heads_list)
+    tok = get_tokenizer(False, num_languages=m.num_languages)
+    mels = _mel(m.dims.n_mels, 67, B=1)
+    g = torch.Generator().manual_seed(9)
+    text = torch.randint(18, 50000, (97,), generator=g).tolist()
+    wt, cache = ost.find_alignment(m, tok, text, mels[0], 480000, return_cache=True)
+    toks = [[*tok.sot_sequence, tok.no_timestamps, *text, tok.eot]]
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    old = lib.swx_debug_flags(-1)
+    try:
+        assert old & 512
+        p_fast, neg_fast, T = eng.score(xkv, toks, [1500], n_sot=len(tok.sot_sequence), eot=tok.eot)
+        neg_fast = neg_fast.clone()
+        lib.swx_debug_flags(old & ~512)
+        p_slow, neg_slow, _ = eng.score(xkv, toks, [1500], n_sot=len(tok.sot_sequence), eot=tok.eot)
+        neg_slow = neg_slow.clone()
+    finally:
+        lib.swx_debug_flags(old)
+    ref_p = np.asarray(cache["text_token_probs"])
+    ref_neg = cache["neg_matrix"]
+    n = T[0] + 1
+    e_fast = (neg_fast[0, :n].cpu() - ref_neg).abs().max().item()
+    e_slow = (neg_slow[0, :n].cpu() - ref_neg).abs().max().item()
+    assert not torch.equal(neg_fast, neg_slow)          # the two paths really are different code
+    assert e_fast < max(2.5 * e_slow, 0.05), (e_fast, e_slow)
+    pe_fast = np.abs(np.asarray(p_fast[0]) - ref_p).max()
+    pe_slow = np.abs(np.asarray(p_slow[0]) - ref_p).max()
+    assert pe_fast < max(2.5 * pe_slow, 2e-2 * max(ref_p.max(), 1e-3)), (pe_fast, pe_slow)
 
 
 @pytest.mark.parametrize("name,policy", [("tiny.en", "1536x384=1,1152x384=1,384x384=1,384x1536=2"),

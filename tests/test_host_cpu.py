@@ -101,6 +101,57 @@ def test_stabilization_matches_reference_semantics():
     assert seg["words"][0]["start"] == 2.0 and seg["words"][1]["end"] == 6.0
 
 
+def _probe_cases():
+    g = torch.Generator().manual_seed(11)
+    t = torch.arange(560000) / 16000.0
+    speech = 0.3 * torch.sin(2 * np.pi * 220 * t) * (torch.sin(2 * np.pi * 0.4 * t) > -0.2) + 0.004 * torch.randn(560000, generator=g)
+    return [speech[:480000], speech[80000:], speech, speech[:1234], speech[:999], speech[:12345] * 1e-7,
+            torch.randn(333333, generator=g) * 0.1, torch.zeros(480000), speech[:480001], speech[:641]]
+
+
+def test_loudness_from_probe_is_the_full_length_path_bit_for_bit():
+    """The host half of the device silence analysis (stabilization.loudness_from_probe) on probe values produced here by
+    numpy (k-th largest |x| by np.partition, |x| at probe_indices): the loudness curve, and everything NonSpeechPredictor
+    derives from it, must equal the full-length path's exactly; the GPU test checks the kernel against the same numpy
+    expressions (tests/test_gpu_kernels.py::test_loudness_probe_kernel)."""
+    from stable_ts_amd.stabilization import NonSpeechPredictor, audio2loudness, loudness_from_probe, probe_indices
+    n_equal = 0
+    for x in _probe_cases():
+        n = x.numel()
+        ref = audio2loudness(x.clone())
+        idx = probe_indices(n)
+        if idx is None:
+            assert ref is None
+            continue
+        assert idx.min() >= 0 and idx.max() < n
+        k = int(n * 0.001)
+        ax = x.abs().numpy()
+        thr = float(np.partition(ax, ax.size - k)[ax.size - k]) if k else float("nan")
+        got = loudness_from_probe(n, thr, idx, torch.from_numpy(ax[idx]))
+        if not k:
+            assert got is False                  # the quantile branch stays on the full path
+            continue
+        assert torch.equal(got, ref), n
+        a, b = NonSpeechPredictor(get_mask=True), NonSpeechPredictor(get_mask=True)
+        r1, r2 = a.predict(x.clone(), offset=3.0), b.predict(None, offset=3.0, loud=got)
+        assert (r1["timings"] is None) == (r2["timings"] is None)
+        assert r1["timings"] is None or np.array_equal(r1["timings"], r2["timings"])
+        assert (r1["mask"] is None) == (r2["mask"] is None) and (r1["mask"] is None or torch.equal(r1["mask"], r2["mask"]))
+        assert r1["is_silent"] == r2["is_silent"] and a.timings() == b.timings()
+        n_equal += 1
+    assert n_equal >= 7
+    # a sample the interpolation reads but the probe did not deliver must be noticed, not silently read as something else
+    x = _probe_cases()[0]
+    idx = probe_indices(x.numel())
+    short = idx.copy()
+    short[4 * 700: 4 * 700 + 4] = short[0]
+    import stable_ts_amd.stabilization as st
+    st._probe_scratch.buf = {}
+    ax = x.abs().numpy()
+    assert loudness_from_probe(x.numel(), float(np.partition(ax, ax.size - 480)[ax.size - 480]), short, torch.from_numpy(ax[short])) is False
+    st._probe_scratch.buf = {}
+
+
 def test_result_container():
     from stable_ts_amd.result import UnsortedException, WhisperResult
     r = WhisperResult(dict(language="en", segments=[dict(start=0.0, end=1.0, text=" a b", seek=0.0, tokens=[1, 2], words=[
