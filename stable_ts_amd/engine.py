@@ -257,7 +257,7 @@ class Engine:
 
     # ------------------------------------------------------------------ a6/a7 score
     def score(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], n_frames: Sequence[int], n_sot: int, eot: int,
-              qk_scale: float = 1.0, medfilt_width: int = 7):
+              qk_scale: float = 1.0, medfilt_width: int = 7, _defer: bool = False):
         """tokens[w] = [*sot_sequence, no_timestamps, *text_tokens, eot].  Returns (token_probs list, neg_matrix
         device tensor [W, max_n, 1500], T list)."""
         W = len(tokens)
@@ -274,8 +274,20 @@ class Engine:
                                  float(qk_scale), int(medfilt_width), _ptr(xkv), _ptr(probs), _ptr(neg), self.stream),
               "swx_score")
         T = [n - n_sot - 2 for n in n_tok]
+        if _defer:
+            return probs, neg, T                     # enqueued, not waited for: score_finish() copies the probabilities out
+        return self.score_finish((probs, neg, T))
+
+    def score_start(self, *args, **kw):
+        """`score` without waiting for the device: the caller does host work (word splitting) under the pass and then calls
+        `score_finish` with the returned handle."""
+        return self.score(*args, _defer=True, **kw)
+
+    @staticmethod
+    def score_finish(handle):
+        probs, neg, T = handle
         p = probs.cpu().numpy()
-        return [p[w, :T[w]].astype(np.float64).tolist() for w in range(W)], neg, T
+        return [p[w, :T[w]].astype(np.float64).tolist() for w in range(len(T))], neg, T
 
     def score_qk(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], *, n_sot: int, eot: int, row0: int, n_rows: int):
         """Teacher-forced pass that hands out the raw (pre-softmax) attention scores of this engine's alignment heads

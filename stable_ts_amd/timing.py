@@ -268,7 +268,7 @@ def _find_alignment_variants(model, jobs, xkv, *, medfilt_width, qk_scale, dynam
 
 def find_alignment_batch(model, jobs: Sequence[AlignmentJob], xkv, *, medfilt_width: int = 7, qk_scale: float = 1.0,
                          dynamic_heads=None, aligner: Union[str, dict] = "legacy", extra_models: Optional[list] = None,
-                         mel=None, return_debug: bool = False) -> List[List[WordTiming]]:
+                         mel=None, return_debug: bool = False, started=None) -> List[List[WordTiming]]:
     """timing.py:202-306 for W windows at once: scoring pass + alignment matrix + DTW on the device."""
     tok = jobs[0].tokenizer
     eng = model.engine
@@ -280,8 +280,12 @@ def find_alignment_batch(model, jobs: Sequence[AlignmentJob], xkv, *, medfilt_wi
                                        return_debug=return_debug)
         probs, paths = [r[0] for r in res], [(r[1], r[2]) for r in res]
     else:
-        probs, neg, T = eng.score(xkv, [j.tokens for j in jobs], [j.n_frames for j in jobs], n_sot=len(tok.sot_sequence),
-                                  eot=tok.eot, qk_scale=qk_scale, medfilt_width=medfilt_width)
+        if started is not None:              # the scoring pass was enqueued before the words were split (same tokens: checked)
+            assert started["tokens"] == [j.tokens for j in jobs]
+            probs, neg, T = eng.score_finish(started["handle"])
+        else:
+            probs, neg, T = eng.score(xkv, [j.tokens for j in jobs], [j.n_frames for j in jobs], n_sot=len(tok.sot_sequence),
+                                      eot=tok.eot, qk_scale=qk_scale, medfilt_width=medfilt_width)
         paths = eng.dtw(neg, [t + 1 for t in T], [j.n_frames for j in jobs])
     from . import transcribe as _tr
     if _tr.PHASE_TIMES is not None:                       # diagnostic: device part of the word-timestamp stage
@@ -316,6 +320,26 @@ def add_word_timestamps_batch(*, model, tokenizer, windows: Sequence[dict], xkv,
     append_punctuations = APPEND_PUNCTUATIONS if append_punctuations is None else append_punctuations
     min_word_dur = min_word_dur or 0
     assert all(len(wd["segments"]) > 0 for wd in windows)
+    # The scoring pass only needs the token sequences, which are known before the words are: on the default path enqueue it
+    # first and split the words (tokenizer decoding, ~0.6 ms per window of host time) while the device runs it.
+    started = None
+    eng = getattr(model, "engine", None)
+    if (split_callback is None and not dynamic_heads and not extra_models and aligner == "legacy"
+            and not getattr(model, "missing_alignment_heads", False) and hasattr(eng, "score_start")):
+        pad = None if gap_padding is None else (tokenizer.encode(gap_padding) if isinstance(gap_padding, str) else [gap_padding])
+        toks, frames = [], []
+        for wd in windows:
+            flat = []
+            for si, seg in enumerate(wd["segments"]):
+                text_only = [t for t in seg["tokens"] if not isinstance(t, int) or t < tokenizer.eot]
+                if (pad is not None and text_only and text_only[0] != pad and (len(flat) == 0 or flat[-1] != pad)
+                        and (pad_first_seg or si != 0)):
+                    flat.extend(pad)
+                flat.extend(text_only)
+            toks.append([*tokenizer.sot_sequence, tokenizer.no_timestamps, *flat, tokenizer.eot])
+            frames.append(round(wd["num_samples"] / N_SAMPLES_PER_TOKEN))
+        started = dict(tokens=toks, handle=eng.score_start(xkv, toks, frames, n_sot=len(tokenizer.sot_sequence),
+                                                           eot=tokenizer.eot, qk_scale=qk_scale, medfilt_width=medfilt_width))
     jobs, seg_maps = [], []
     for wd in windows:
         for seg in wd["segments"]:
@@ -324,8 +348,11 @@ def add_word_timestamps_batch(*, model, tokenizer, windows: Sequence[dict], xkv,
                                                            split_callback=split_callback, pad_first_seg=pad_first_seg)
         jobs.append(AlignmentJob(tokenizer, flat, wd["num_samples"], token_split))
         seg_maps.append(seg_of_word)
+    if started is not None and started["tokens"] != [j.tokens for j in jobs]:
+        started = None                         # cannot happen with the built-in splitter; a mismatch just costs a second pass
     alignments = find_alignment_batch(model, jobs, xkv, medfilt_width=medfilt_width, qk_scale=qk_scale,
-                                      dynamic_heads=dynamic_heads, aligner=aligner, extra_models=extra_models, mel=mel)
+                                      dynamic_heads=dynamic_heads, aligner=aligner, extra_models=extra_models, mel=mel,
+                                      started=started)
     for wd, alignment, seg_of_word in zip(windows, alignments, seg_maps):
         segments = wd["segments"]
         lead = pop_empty_alignment(alignment, seg_of_word)

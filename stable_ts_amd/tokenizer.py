@@ -93,9 +93,16 @@ class SyntheticEncoding:
         self.n_vocab = n
         self.eot_token = self.special_tokens["<|endoftext|>"]
         self._special_by_id = {v: k for k, v in self.special_tokens.items()}
+        self._str_cache: Dict[int, str] = {}
 
     def token_str(self, t: int) -> str:
         t = int(t)                      # callers hand over 0-dim tensors too (alignment.py:1002-1003); never mutate them
+        s = self._str_cache.get(t)
+        if s is None:
+            s = self._str_cache[t] = self._token_str(t)
+        return s
+
+    def _token_str(self, t: int) -> str:
         if t >= self.n_text:
             return self._special_by_id[t]
         if t < len(_PUNCT):

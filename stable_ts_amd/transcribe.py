@@ -176,18 +176,42 @@ def _slice_segments(tokens: List[int], result: DecodingResult, tokenizer, time_o
     return segs, single_ts_ending, end_ts_pos
 
 
-def _process_batch(model, tokenizer, batch: List[dict], o: dict) -> List[dict]:
+def _audio_key(a: torch.Tensor):
+    return (a.data_ptr(), int(a.shape[-1]))
+
+
+def _start_encoder(model, audios: List[torch.Tensor]) -> dict:
+    """Enqueues spectrogram, encoder and cross-K/V projection of some windows WITHOUT waiting for them (none of the three
+    entry points synchronises): the window-parallel driver calls this before the host half of the silence analysis, which
+    then runs while the device works.  `_process_batch` picks the results up for the windows that are still in the batch
+    unchanged (the usual case); a window the analysis skips or truncates is simply not used / encoded again."""
+    seg_samples = [int(a.shape[-1]) for a in audios]
+    mel = model.log_mel_batch(audios, [max(N_SAMPLES - n, 0) for n in seg_samples])          # :528-530
+    xkv = model.cross_kv(model.encoder(mel))
+    return dict(keys=[_audio_key(a) for a in audios], mel=mel, xkv=xkv)
+
+
+def _process_batch(model, tokenizer, batch: List[dict], o: dict, pre: Optional[dict] = None) -> List[dict]:
     """Runs the hot path for a batch of windows.  batch[w] = dict(audio=1-D f32 tensor (<=480000), seek_sample=int,
-    prompt=list[int], ts_mask=bool[1501] | None).  Returns per window dict(segments, segment_samples, result, skipped)."""
+    prompt=list[int], ts_mask=bool[1501] | None).  Returns per window dict(segments, segment_samples, result, skipped).
+    ``pre``: what `_start_encoder` enqueued earlier for (a superset of) these windows."""
     W = len(batch)
     audios = [b["audio"] for b in batch]
     seg_samples = [int(a.shape[-1]) for a in audios]
     import time
     t_ph = time.perf_counter() if PHASE_TIMES is not None else 0.0
-    mel = model.log_mel_batch(audios, [max(N_SAMPLES - n, 0) for n in seg_samples])          # :528-530
-    t_ph = _phase("mel", t_ph)
-    xa = model.encoder(mel)
-    xkv = model.cross_kv(xa)
+    mel = xkv = None
+    if pre is not None:
+        where = {k: i for i, k in enumerate(pre["keys"])}
+        idx = [where.get(_audio_key(a)) for a in audios]
+        if all(i is not None for i in idx):
+            same = idx == list(range(len(pre["keys"])))
+            mel = pre["mel"] if same else pre["mel"][idx]
+            xkv = pre["xkv"] if same else _xkv_select(model, pre["xkv"], idx)
+    if xkv is None:
+        mel = model.log_mel_batch(audios, [max(N_SAMPLES - n, 0) for n in seg_samples])          # :528-530
+        t_ph = _phase("mel", t_ph)
+        xkv = model.cross_kv(model.encoder(mel))
     t_ph = _phase("encoder+cross_kv", t_ph)
     ts_masks = [b.get("ts_mask") for b in batch] if o["suppress_ts_tokens"] else None
     if ts_masks is not None and all(m is None for m in ts_masks):
@@ -394,7 +418,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     def host_copy(seg: torch.Tensor) -> torch.Tensor:
         return seg.detach().float().cpu()                       # silence analysis is host-side vector code (CPU)
 
-    def predict_nonspeech(tr_ns, chunks: List[torch.Tensor], offsets: List[float], pool_=None) -> List[dict]:
+    def predict_nonspeech(tr_ns, chunks: List[torch.Tensor], offsets: List[float], pool_=None, between=None) -> List[dict]:
         """The silence analysis of some windows.  Windows that are resident on the GPU go through the device probe (k-th
         largest level + the ~6000 samples the loudness curve reads; engine.loudness_probe) and only the curve's arithmetic
         runs on the host -- the same expressions on the same values, so the masks are those of the full-length host path,
@@ -404,6 +428,8 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
         if tr_ns.loudness and chunks and all(c.is_cuda for c in chunks):
             from .engine import loudness_probe
             probes = loudness_probe(chunks)
+        if between is not None:
+            between()                      # device work that may run under the host half below
 
         def one(a):
             ch, off, pr = a
@@ -415,7 +441,11 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             return tr_ns.predict(None, offset=off, loud=loud)
 
         args = list(zip(chunks, offsets, probes))
-        return list(pool_.map(one, args)) if (pool_ is not None and len(args) > 1) else [one(a) for a in args]
+        # the probe leaves ~0.8 ms of small tensor operations per window: a thread pool only adds contention there (measured:
+        # 20 windows 15 ms in line, 35-48 ms through 8 threads); the full-length path (2-5 ms per window in numpy / torch
+        # calls that release the GIL) is the one that gains from the pool
+        use_pool = pool_ is not None and len(args) > 1 and any(pr is False for pr in probes)
+        return list(pool_.map(one, args)) if use_pool else [one(a) for a in args]
 
     def window_input(tr: _Track, seek: int, seg: torch.Tensor, prompt: List[int], pred: Optional[dict] = None):
         item = dict(audio=seg, seek_sample=seek, prompt=prompt, ts_mask=None, silence=None, skip=False)
@@ -533,8 +563,14 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
             for group in batches():
                 preds = [None] * len(group)
                 t_ph = time.perf_counter() if PHASE_TIMES is not None else 0.0
+                pre = {}
                 if pool is not None and len(group) > 1:
-                    preds = predict_nonspeech(nonspeech, [g[1] for g in group], [g[0] / SAMPLE_RATE for g in group], pool)
+                    def start_device_work():
+                        force = getattr(model, "prestart_encoder", None)     # tests switch it on for the host stand-in
+                        if not lanes and (force or (force is None and all(g[1].is_cuda for g in group))):
+                            pre.update(_start_encoder(model, [g[1] for g in group]))
+                    preds = predict_nonspeech(nonspeech, [g[1] for g in group], [g[0] / SAMPLE_RATE for g in group], pool,
+                                              between=start_device_work)
                 items = [window_input(tr0, sk, ch, list(initial_prompt_tokens), pr) for (sk, ch), pr in zip(group, preds)]
                 t_ph = _phase("host: silence analysis of the batch (copy-out + loudness, 8 threads)", t_ph)
                 live = [it for it in items if not it["skip"] and it["audio"].shape[-1] > 0]
@@ -550,7 +586,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                     parts = [live[k * per:(k + 1) * per] for k in range(len(lanes))]
                     outs = [x for r in lane_pool.map(run_lane, lanes, parts) for x in r]
                 else:
-                    outs = _process_batch(model, tokenizer, live, o) if live else []
+                    outs = _process_batch(model, tokenizer, live, o, pre=pre or None) if live else []
                 t_ph = time.perf_counter() if PHASE_TIMES is not None else 0.0
                 for it, out in zip(live, outs):
                     commit(tr0, it, out)

@@ -114,6 +114,15 @@ class OracleEngine:
         return probs, neg, T
 
     @torch.no_grad()
+    def score_start(self, *args, **kw):
+        """the product enqueues the scoring pass before it splits the words and collects it afterwards; the stand-in has no
+        queue: it runs the pass here and hands the result over in `score_finish`"""
+        return self.score(*args, **kw)
+
+    @staticmethod
+    def score_finish(handle):
+        return handle
+
     def score_qk(self, xkv, tokens, *, n_sot, eot, row0, n_rows):
         """raw scores of the alignment heads (or of every head on the ``all_heads()`` view), rows row0 .. row0+n_rows-1"""
         from oracle.whisper.model import disable_sdpa

@@ -145,6 +145,36 @@ def test_window_parallel_streams_equal_single_lane(models, monkeypatch):
             assert wa[:3] == wb[:3] and wa[4] == wb[4] and abs(wa[3] - wb[3]) <= 1e-5 * max(wa[3], 1e-9) + 1e-9
 
 
+def test_window_parallel_prestarted_encoder_changes_nothing(models, monkeypatch):
+    """batch_size mode with the encoder enqueued BEFORE the host half of the silence analysis (what the GPU path does so that
+    the analysis runs under the encoder; `prestart_encoder` switches it on for the stand-in): windows the analysis then skips
+    (silent) or truncates (`nonspeech_skip`) must be dropped from / re-encoded for the batch, the rest reuse the pre-started
+    results -- word for word the result without the pre-start."""
+    G, _ref_model, mine = models
+    from oracle_engine import install
+    install(monkeypatch)
+    a = G.synth_audio(150.0, seed=9)
+    a[16000 * 30: 16000 * 60] = 0.0                       # window 1: silent -> skipped
+    a[16000 * 95: 16000 * 104] = 0.0                      # window 3: a 9-s hole -> truncated by nonspeech_skip
+    kw = dict(BASE, language="en", batch_size=5, regroup=False, nonspeech_skip=5.0)
+    calls = []
+    import stable_ts_amd.transcribe as T
+    real = T._start_encoder
+    monkeypatch.setattr(T, "_start_encoder", lambda m, au: calls.append(len(au)) or real(m, au))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = mine.transcribe(a, **kw)
+        assert not calls
+        mine.prestart_encoder = True
+        try:
+            pre = mine.transcribe(a, **kw)
+        finally:
+            del mine.prestart_encoder
+    assert calls == [5]
+    assert _snap(pre) == _snap(plain) and len(_snap(plain)) > 0
+    assert pre.to_dict() == plain.to_dict()
+
+
 @pytest.mark.parametrize("kind", ["half_second", "silent", "one_window_exact", "tail_of_200_samples"])
 def test_transcribe_edge_inputs_match_reference(models, monkeypatch, kind):
     """degenerate inputs: shorter than a frame budget, all-zero audio (every window skipped), exactly one window, and a
