@@ -31,9 +31,16 @@ def make_alignment_func(model, tokenizer, extra_models: Optional[list] = None, d
         return compute_timestamps_batch([audio_segment], [word_tokens])[0]
 
     def compute_timestamps_batch(audio_segments: Sequence[torch.Tensor], word_tokens_list: Sequence[List[WordToken]]):
+        from . import transcribe as _tr                     # diagnostic stage timer (bench.py --phase-times), off by default
+        import time
+        t_ph = time.perf_counter() if _tr.PHASE_TIMES is not None else 0.0
         n = [int(a.shape[-1]) for a in audio_segments]
         mel = model.log_mel_batch(list(audio_segments), [max(N_SAMPLES - k, 0) for k in n])
-        xkv = model.cross_kv(model.encoder(mel))
+        t_ph = _tr._phase("align: audio upload + mel", t_ph)
+        xa = model.encoder(mel)
+        t_ph = _tr._phase("align: encoder", t_ph)
+        xkv = model.cross_kv(xa)
+        t_ph = _tr._phase("align: cross K/V", t_ph)
         windows = []
         for k, wts in zip(n, word_tokens_list):
             seg = dict(seek=0, tokens=([w.word for w in wts], [list(w.tokens) for w in wts]))
@@ -42,6 +49,7 @@ def make_alignment_func(model, tokenizer, extra_models: Optional[list] = None, d
                                   split_callback=lambda x, _: x, gap_padding=None,
                                   prepend_punctuations="", append_punctuations="", extra_models=extra_models,
                                   dynamic_heads=dynamic_heads, aligner=aligner, mel=mel if extra_models else None)
+        _tr._phase("align: word timestamps (scoring pass + a7 + DTW + host)", t_ph)
         return [w["segments"][0]["words"] for w in windows]
 
     compute_timestamps.batch = compute_timestamps_batch

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
                                                        const int *__restrict__ Nw, const int *__restrict__ Mw,
                                                        int *__restrict__ text_idx, int *__restrict__ time_idx,
                                                        int *__restrict__ out_len, unsigned char *__restrict__ ws_all,
-                                                       size_t ws_stride, int PITCH)
+                                                       size_t ws_stride, int PITCH, int abl)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *bnd = (float *)smem;                                   // [3][D4_BR]: bottom row of waves 0..2, ring over steps
@@ -248,7 +248,6 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
     const int nch = (steps + D4_CH - 1) / D4_CH;
     const float INF = __builtin_inff();
     const int L = tid;
-    const unsigned Meff = L < nl ? (unsigned)M : 0u;
 
     // x of this window: a lane needs 16 consecutive floats of each of its rows per chunk: four 16-byte loads (4-byte aligned;
     // one float per load measured 4x slower here -- every lane is on its own cache line, so the 64 line requests of a wave
@@ -263,7 +262,10 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const unsigned e0 = (unsigned)((L * R + r) * ld_m + (c * D4_CH - L));
-            if (e0 + (D4_CH - 1) <= last_e) {
+            if (abl & 2) {                 // experiment: no x loads
+#pragma unroll
+                for (int q = 0; q < D4_CH; ++q) dst[r][q] = 0.5f;
+            } else if (e0 + (D4_CH - 1) <= last_e) {
 #pragma unroll
                 for (int g = 0; g < D4_CH / 4; ++g) {
                     const f4u v = *(const f4u *)(xw + e0 + 4 * g);
@@ -279,6 +281,10 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
         }
     };
     issue(0, xc); issue(1, x1); issue(2, x2);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < D4_CH; ++q) xc[r][q] = (q - L >= 0) ? xc[r][q] : INF;      // chunk 0: columns j = q - L
 
     float prev[R];
 #pragma unroll
@@ -298,12 +304,16 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] = 0u;
             int bcol = 0;
+            // No per-step "is this lane inside its column range" selects on the dependent chain:
+            //  * before a lane's first column (j < 0) its x is +inf (set when the chunk's registers are rotated in), so its
+            //    cells stay +inf -- the border values cost[i][0] the recurrence expects, and `diag_in` = the previous `up` is
+            //    +inf likewise (the lane above starts one step earlier);
+            //  * after its last column (j >= M), and for lanes / rows past N, it computes on whatever the loads returned: those
+            //    cells feed only cells that are outside the matrix as well, and their trace bits are never read.
 #pragma unroll
             for (int q = 0; q < D4_CH; ++q) {
                 const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(bv[q]), __float_as_int(bottom), 0x138, 0xf, 0xf, false));
-                const bool valid = (unsigned)(jbase + q) < Meff;
                 float c0 = diag_in, c1 = up;
-                float nvs[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const float c2 = prev[r];
@@ -312,14 +322,12 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
                     const float cm = s0 ? c0 : (s1 ? c1 : c2);
                     acc[r] |= (s0 ? 0u : (s1 ? 1u : 2u)) << (2 * q);
                     const float nv = __fadd_rn(xc[r][q], cm);
-                    nvs[r] = nv;
+                    prev[r] = nv;
                     c0 = c2;
                     c1 = nv;
                 }
-#pragma unroll
-                for (int r = 0; r < R; ++r) prev[r] = valid ? nvs[r] : prev[r];
-                bottom = valid ? c1 : bottom;
-                diag_in = valid ? up : diag_in;
+                bottom = c1;
+                diag_in = up;
                 // lane 63's bottom after this step -> lane q of bcol (handed to the wave below at the end of the chunk)
                 {
                     const int sb = __builtin_amdgcn_readlane(__float_as_int(bottom), 63);
@@ -329,16 +337,18 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
 #pragma unroll
             for (int r = 0; r < R; ++r) tr[((size_t)L * PITCH + c) * R + r] = acc[r];
             if (wave < 3 && lane < D4_CH) bnd[wave * D4_BR + ((t0 + lane) & (D4_BR - 1))] = __int_as_float(bcol);
+            const int jnext = jbase + D4_CH;                 // first column of the next chunk for this lane
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int q = 0; q < D4_CH; ++q) { xc[r][q] = x1[r][q]; x1[r][q] = x2[r][q]; }
+                for (int q = 0; q < D4_CH; ++q) { xc[r][q] = (jnext + q >= 0) ? x1[r][q] : INF; x1[r][q] = x2[r][q]; }
             issue(c + 3, x2);
         }
         __syncthreads();
     }
     if (!TLDS) { __threadfence_block(); __syncthreads(); }
 
+    if (abl & 1) { if (tid == 0) out_len[w] = 0; return; }      // experiment: no backtrace
     // ---- backtrace over runs (wave 0, scalar), then expansion by all threads
     if (wave == 0) {
         int i = N, j = M, n = 0, k = 0;
@@ -429,7 +439,7 @@ extern "C" int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_
                 attr_done4 = true; \
             } \
             hipLaunchKernelGGL((swx_dtw4_kernel<RR, TL>), dim3(W), dim3(256), lds, s, d_x, ld_n, ld_m, d_N, d_M, d_text_idx, d_time_idx, \
-                               d_len, (unsigned char *)d_trace_ws, per, PITCH); } while (0)
+                               d_len, (unsigned char *)d_trace_ws, per, PITCH, abl); } while (0)
         const bool fits = base + (size_t)256 * PITCH * 4 <= 160 * 1024 - 1024 - 64;
         if (ld_n <= 256) { if (fits) SWX_DTW4(1, true); else SWX_DTW4(1, false); }
         else SWX_DTW4(2, false);
