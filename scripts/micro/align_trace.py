@@ -32,12 +32,19 @@ def main():
         setattr(eng, name, w)
     for n in ("log_mel", "encode", "cross_kv", "score", "dtw"):
         wrap(n)
-    for rep in range(2):
+    import gc
+    for rep in range(3):
         log.clear()
+        if rep == 2:
+            gc.disable()
+        st0 = torch.cuda.memory_stats()
         t0 = time.perf_counter()
         model.align(audio, list(toks), language="en", token_step=100)
         torch.cuda.synchronize()
-        print(f"pass {rep}: {time.perf_counter() - t0:.3f} s")
+        st1 = torch.cuda.memory_stats()
+        print(f"pass {rep}: {time.perf_counter() - t0:.3f} s   segments allocated {st1['segment.all.allocated'] - st0['segment.all.allocated']} "
+              f"freed {st1['segment.all.freed'] - st0['segment.all.freed']}  alloc retries {st1['num_alloc_retries'] - st0['num_alloc_retries']} "
+              f"reserved {st1['reserved_bytes.all.current'] / 1e9:.2f} GB  gc enabled {gc.isenabled()} counts {gc.get_count()}")
     for n, v in log.items():
         host = sorted(x[0] for x in v); tot = sorted(x[1] for x in v)
         print(f"{n:10s} calls {len(v):3d}  host enqueue median {host[len(host)//2]:7.2f} ms  call+sync median {tot[len(tot)//2]:7.2f} ms  max {tot[-1]:7.2f}  sum {sum(tot):8.1f} ms")

@@ -12,6 +12,7 @@ from typing import List, Optional, Sequence, Union
 
 import torch
 
+from .stabilization import host_single_thread
 from .audio import N_SAMPLES, SAMPLE_RATE
 from .result import WhisperResult
 from .timing import add_word_timestamps_batch
@@ -77,6 +78,7 @@ def make_refinement_func(model, tokenizer):
     return inference_func
 
 
+@host_single_thread
 def align(model, audio, text: Union[str, List[int], WhisperResult], language: str = None, *, tokenizer=None,
           ignore_compatibility: bool = False, remove_instant_words: bool = False, token_step: int = 100,
           original_split: bool = False, word_dur_factor: Optional[float] = 2.0, max_word_dur: Optional[float] = 3.0,
@@ -107,12 +109,15 @@ def align(model, audio, text: Union[str, List[int], WhisperResult], language: st
                       max_segment_length=N_SAMPLES, remove_instant_words=remove_instant_words, token_step=token_step,
                       original_split=original_split, word_dur_factor=word_dur_factor, max_word_dur=max_word_dur,
                       nonspeech_skip=nonspeech_skip, fast_mode=fast_mode, failure_threshold=failure_threshold, **options)
-    result = aligner.align(as_waveform(audio, **audio_options).detach().float().cpu(), text)
+    # the waveform stays where it is: windows of a recording that is resident on the GPU are analysed there (device probe of
+    # the silence analysis) and are not uploaded again
+    result = aligner.align(as_waveform(audio, **audio_options).detach().float(), text)
     if result is not None:
         result.language = lang_code or language or (None if model.is_multilingual else "en")    # alignment.py:388-393
     return result
 
 
+@host_single_thread
 def align_words(model, audio, result: Union[WhisperResult, List[dict]], language: str = None, *,
                 ignore_compatibility: bool = False, tokenizer=None, normalize_text: bool = True, inplace: bool = True,
                 batch_size: int = 8, **options) -> WhisperResult:
@@ -145,11 +150,12 @@ def align_words(model, audio, result: Union[WhisperResult, List[dict]], language
     aligner = Aligner(inference_func=lambda seg, words: clipped(func.batch)([seg], [words])[0], decode=tokenizer.decode,
                       encode=tokenizer.encode, split_words_by_space=lang_code not in {"zh", "ja", "th", "lo", "my"},
                       sample_rate=SAMPLE_RATE, max_segment_length=N_SAMPLES, token_step=model.dims.n_text_ctx, **options)
-    out = aligner.align_words(as_waveform(audio, **audio_options).detach().float().cpu(), result, normalize_text, inplace,
+    out = aligner.align_words(as_waveform(audio, **audio_options).detach().float(), result, normalize_text, inplace,
                               batch_inference=clipped(func.batch), batch_size=batch_size)
     out.language = lang_code or language or (None if model.is_multilingual else "en")
     return out
 
+@host_single_thread
 def refine(model, audio, result: WhisperResult, *, steps: str = None, rel_prob_decrease: float = .03,
            abs_prob_decrease: float = .05, rel_rel_prob_decrease: Optional[float] = None, prob_threshold: float = .5,
            rel_dur_change: Optional[float] = .5, abs_dur_change: Optional[float] = None, word_level: bool = True,

@@ -22,6 +22,7 @@ from typing import List, Optional, Tuple, Union
 import numpy as np
 import torch
 
+from .stabilization import host_single_thread
 from .audio import FRAMES_PER_SECOND, N_FFT, N_FRAMES, N_SAMPLES, SAMPLE_RATE
 from .decoding import DecodingOptions, DecodingPlan
 from .result import Segment
@@ -43,6 +44,7 @@ def _pad_frames(mel: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@host_single_thread
 def locate(model, audio, text: Union[str, List[int]], language: str, count: int = 1,
            duration_window: Union[float, Tuple[float, float]] = 3.0, *, mode: int = 0, start: float = None,
            end: float = None, probability_threshold: float = 0.5, eots: int = 1, max_token_per_seg: int = 20,

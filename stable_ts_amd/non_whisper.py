@@ -16,6 +16,7 @@ from typing import Callable, Optional, Union
 import numpy as np
 import torch
 
+from .stabilization import host_single_thread
 from .audio_io import (AudioLoader, audio_to_tensor_resample, check_source, get_samplerate, load_audio, reject_denoiser,
                        resample, to_s16, voice_freq_filter, write_wav)
 from .result import WhisperResult
@@ -38,6 +39,7 @@ def _wav_bytes(audio: torch.Tensor, sr: int) -> bytes:
         return f.getvalue()
 
 
+@host_single_thread
 def transcribe_any(inference_func: Callable, audio: Union[str, np.ndarray, torch.Tensor, bytes, AudioLoader],
                    audio_type: Optional[str] = None, input_sr: Optional[int] = None, model_sr: Optional[int] = None,
                    inference_kwargs: Optional[dict] = None, temp_file: Optional[str] = None, verbose: Optional[bool] = False,

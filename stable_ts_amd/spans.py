@@ -19,6 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+from .stabilization import host_single_thread
 from .audio import N_SAMPLES, SAMPLE_RATE
 from .result import WhisperResult
 from .stabilization import NonSpeechPredictor
@@ -66,6 +67,7 @@ def merge_span_results(parts: Sequence[Tuple[int, WhisperResult]], language: Opt
     return out
 
 
+@host_single_thread
 def transcribe_spans(model, audio, n_spans: int = 8, *, spans: Optional[List[Tuple[int, int]]] = None, search: float = 10.0,
                      **kw) -> WhisperResult:
     """``model.transcribe`` semantics per span, all spans advanced together on this device.  ``spans`` (sample ranges)

@@ -18,6 +18,40 @@ from .audio import FRAMES_PER_SECOND, N_SAMPLES_PER_TOKEN, TOKENS_PER_SECOND
 from .timing import APPEND_PUNCTUATIONS
 
 
+class _single_host_thread:
+    """The full-length host path below runs a handful of element-wise tensor operations over 480 000 samples; with torch's
+    default intra-op pool every one of them wakes all OpenMP workers, which then busy-wait for more work for a while.  In a
+    container with a CPU quota (the MI355X boxes this was measured on) those spinning workers get the whole process
+    throttled 45-65 ms at a time -- `align()` of a host waveform ran at 580x real time with them and 1 270x without
+    (DESIGN.md section 5).  The operations are far too small to gain from threads, so they run on the calling thread."""
+
+    def __enter__(self):
+        self.n = torch.get_num_threads()
+        if self.n != 1:
+            torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        if self.n != 1:
+            torch.set_num_threads(self.n)
+        return False
+
+
+def host_single_thread(fn):
+    """Decorator of the public entry points (model.transcribe / align / align_words / refine / locate / transcribe_spans):
+    everything this package computes on the host is small (token bookkeeping, 1501-point loudness curves, index lists); the
+    arithmetic is on the GPU.  torch's intra-op pool is therefore parked for the duration of the call (and restored after),
+    for the reason given at `_single_host_thread`."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        # a model object that does its arithmetic on the host (the CPU stand-in of the test-suite: tests/oracle_engine.py)
+        # says so and keeps the pool -- there the pool IS the compute
+        if args and getattr(args[0], "computes_on_host", False):
+            return fn(*args, **kw)
+        with _single_host_thread():
+            return fn(*args, **kw)
+    return wrapped
+
+
 def audio2loudness(x: torch.Tensor) -> Optional[torch.Tensor]:
     """nonvad.py:16-39: |x| normalised by (1.75 x the 99.9th-percentile level), resampled to one value per 20 ms."""
     x = x.abs()
@@ -178,6 +212,10 @@ class NonSpeechPredictor:
                 loud = got
         if loud is not False and self.loudness:
             return self._from_mask(wav2mask(None, self.q_levels, self.k_size, loud=loud), offset)
+        with _single_host_thread():
+            return self._predict_host(audio, offset)
+
+    def _predict_host(self, audio: torch.Tensor, offset: float) -> dict:
         audio = audio.detach().float().cpu().contiguous()
         if not self.loudness:
             # :271-286 with get_mask: one flag per 20-ms unit, True where EVERY sample of the unit is non-zero

@@ -21,6 +21,7 @@ from typing import Callable, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
+from .stabilization import host_single_thread
 from .audio import HOP_LENGTH, N_FRAMES, N_SAMPLES, N_SAMPLES_PER_TOKEN, SAMPLE_RATE
 from .audio_io import AudioLoader, audioloader_not_supported, prep_audio
 from .decoding import DecodingOptions, DecodingPlan, DecodingResult
@@ -302,6 +303,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict, pre: Optional[d
     return outs
 
 
+@host_single_thread
 def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
                       temperature: Union[float, Tuple[float, ...]] = (0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
                       compression_ratio_threshold: Optional[float] = 2.4, logprob_threshold: Optional[float] = -1.0,
@@ -657,6 +659,7 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
     return result
 
 
+@host_single_thread
 def transcribe_minimal(model, audio, *, verbose: Optional[bool] = False, word_timestamps: bool = True,
                        regroup: Union[bool, str] = True, suppress_silence: bool = True, suppress_word_ts: bool = True,
                        use_word_position: bool = True, q_levels: int = 20, k_size: int = 5, denoiser: Optional[str] = None,

@@ -8,13 +8,31 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _cpu_quota() -> int:
+    """CPUs this process may actually use: the cgroup quota when there is one (the MI355X boxes show 256 hardware threads under
+    a 16-CPU quota), else the affinity mask"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def _limit_threads():
-    # the CPU oracle runs inside the GPU tests; xdist workers x 64 default torch threads thrash the host
-    if not os.environ.get("PYTEST_XDIST_WORKER"):
-        return
+    # the CPU oracle runs inside the GPU tests.  torch sizes its intra-op pool by the visible hardware threads; more OpenMP
+    # workers than the container's CPU quota get the whole process throttled (they busy-wait between parallel regions), and
+    # xdist workers multiply it
     try:
         import torch
-        torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
+        n = _cpu_quota()
+        if os.environ.get("PYTEST_XDIST_WORKER"):
+            n = min(8, max(1, n // 2))
+        if torch.get_num_threads() > n:
+            torch.set_num_threads(n)
     except Exception:
         pass
 

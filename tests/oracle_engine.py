@@ -177,6 +177,8 @@ class OracleEngine:
 class CpuWhisper:
     """the attributes and methods of stable_ts_amd.model.Whisper that the host code reads"""
 
+    computes_on_host = True      # the product parks torch's intra-op pool inside its entry points; here the pool is the compute
+
     def __init__(self, oracle_model):
         from stable_ts_amd.transcribe import transcribe_stable
         self.om = oracle_model
