@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             for (int e = 0; e < 4; ++e) v[e] += (float)xres[t][e];
         } else if (E_QKV && n >= g.d) {
             const int rps = g.rps > 1 ? g.rps : 1;
-            const int seq = m / rps, pos = g.pos0[seq] + (m - seq * rps);
+            const int seq = m / rps, crow = seq * (g.row_mul > 1 ? g.row_mul : 1), pos = g.pos0[crow] + (m - seq * rps);
             f16 *cache = n < 2 * g.d ? g.kcache : g.vcache;
-            dst = cache + ((size_t)seq * g.n_ctx + pos) * g.d + (n < 2 * g.d ? n - g.d : n - 2 * g.d);
+            dst = cache + ((size_t)crow * g.n_ctx + pos) * g.d + (n < 2 * g.d ? n - g.d : n - 2 * g.d);
         } else {
             dst = g.C + (size_t)m * g.ldc + n;
         }

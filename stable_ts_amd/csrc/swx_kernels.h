@@ -85,6 +85,7 @@ struct DecGemmArgs {
     float *slabs;                        // swx_dec_slab_floats(M, N, K) floats when the shape runs K-split
     _Float16 *kcache, *vcache; const int32_t *pos0; int n_ctx, d;
     int rps;                             // DEC_QKV: rows per sequence (0 / 1: one new token per row); row m = sequence m / rps, token m % rps
+    int row_mul;                         // DEC_QKV: cache row (and pos0 index) of sequence q = q * row_mul (0 / 1: q itself; the prefill writes row w * G)
     int ks2, kslice, n_rg; int64_t slab_stride;   // filled by the launcher
     int abl;                             // experiment switches (SWX_DEC_ABL, scripts/dec_ablate.sh); 0 in production
 };

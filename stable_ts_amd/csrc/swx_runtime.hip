@@ -478,7 +478,8 @@ int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
     return 0;
 }
 
-// Multi-token teacher-forced pass over a SMALL number of rows (align(): one window of ~110 tokens; refine / locate probes) on
+// Multi-token teacher-forced pass over a SMALL number of rows (align(): one window of ~110 tokens; refine / locate probes; the
+// prefill of a decode: W windows x the initial tokens, cache rows w * G) on
 // the same un-split "dec" GEMMs as the decode step: at <= 160 rows the tiled MFMA GEMM launches one or two row blocks and the
 // 16-column skinny kernel 27 us per projection, while a dec launch finishes its outputs (bias / GELU / residual / K,V scatter,
 // LayerNorm folded) in ~7 us.  Self-attention (causal over the new tokens), cross-attention and the alignment-head capture are
@@ -500,12 +501,12 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         DecGemmArgs g{};
         g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wqkv_f); g.ldw = d; g.N = 3 * d; g.K = d; g.epi = DEC_LN | DEC_QKV;
         g.c1 = m->A<float>(w.qkv_c1); g.c2 = m->A<float>(w.qkv_c2); g.C = q; g.ldc = d;
-        g.kcache = kc; g.vcache = vc; g.pos0 = f.pos0; g.n_ctx = D.n_text_ctx; g.d = d; g.rps = f.n_new;
+        g.kcache = kc; g.vcache = vc; g.pos0 = f.pos0; g.n_ctx = D.n_text_ctx; g.d = d; g.rps = f.n_new; g.row_mul = f.row_mul;
         SWX_TRY(swx_gemm_dec(g, s));
         SelfAttnArgs sa{};
         sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = R; sa.n_new = f.n_new; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
-        SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
+        SWX_TRY(swx_self_attention(m->dtype, sa, f.row_mul, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
@@ -543,7 +544,8 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
 
 int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
-    if (m->dtype == SWX_F16 && m->folded && f.n_new > 1 && f.row_mul == 1 && f.W * f.rpw * f.n_new <= 160 &&
+    static const bool no_dec_prefill = [] { const char *e = getenv("SWX_NO_DEC_PREFILL"); return e && atoi(e) != 0; }();   // A/B
+    if (m->dtype == SWX_F16 && m->folded && f.n_new > 1 && f.W * f.rpw * f.n_new <= 160 && !(no_dec_prefill && f.row_mul > 1) &&
         (g_debug_flags & SWX_FLAG_DEC_V3) && !(g_debug_flags & SWX_FLAG_NO_FAST_STEP) &&
         swx_dec_slab_floats(f.W * f.rpw * f.n_new, m->dims.n_text_state, 4 * m->dims.n_text_state) * 4 <= m->L.slab_bytes)
         return decoder_forward_dec(m, f, s);
