@@ -248,26 +248,34 @@ __global__ __launch_bounds__(256) void attn_flash2_f16(AttnArgs a)
                 sc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tt][0], qf[qb][0], sc[tt], 0, 0, 0);
                 sc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tt][1], qf[qb][1], sc[tt], 0, 0, 0);
             }
+            // softmax bookkeeping on the RAW scores (the 1/8 scale is positive: max commutes with it) and in the exp2 domain:
+            // per element one max, one fma, one v_exp_f32, one add -- the key-range mask only on the last tile.  This loop,
+            // not the MFMAs, bounds the kernel (32 MFMAs = 512 cycles against ~350 VALU operations = 1400 cycles per 64-key
+            // tile and wave before; ~200 now).
+            constexpr float SC2 = 0.125f * 1.4426950408889634f;
+            if (kt0 + FL_KT > a.nk) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt0 + tt * 16 + g * 4 + r >= a.nk) sc[tt][r] = -__builtin_inff();
+            }
             float tmax = -__builtin_inff();
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt0 + tt * 16 + g * 4 + r;
-                    const float v = (key < a.nk) ? sc[tt][r] * 0.125f : -__builtin_inff();
-                    sc[tt][r] = v;
-                    tmax = fmaxf(tmax, v);
-                }
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[tt][r]);
             tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float m_new = fmaxf(m_run[qb], tmax);
-            const float alpha = __expf(m_run[qb] - m_new);      // m_run = -inf on the first tile -> 0
+            const float m_new = fmaxf(m_run[qb], tmax);                               // raw units
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * SC2);    // m_run = -inf on the first tile -> 0
+            const float mc = m_new * SC2;
             float psum = 0.f;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __expf(sc[tt][r] - m_new);
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[tt][r], SC2, -mc));
                     sc[tt][r] = p;
                     psum += p;
                 }
@@ -988,6 +996,32 @@ int swx_transpose_v(const void *v, int64_t ldv, int64_t v_bs, int n, void *vt, i
     if (B <= 0 || n <= 0) return 0;
     if (kp % 8 != 0 || kp < n) return -5;
     hipLaunchKernelGGL(transpose_v_kernel, dim3(cdiv(kp, 64), H, B), dim3(256), 0, s, (const f16 *)v, ldv, v_bs, n, (f16 *)vt, kp, vt_bs);
+    SWX_CHECK_LAUNCH();
+    return 0;
+}
+
+// zeroes `pad_bytes` at byte offset `off_bytes` of each of `rows` rows (row stride `row_bytes`) of `nb` batch items (stride
+// `batch_bytes`): the key padding of the transposed cross-attention V (columns n .. kp of every [64 x kp] head block), which
+// is multiplied by exact-zero probabilities and therefore has to be finite.  (Filling the whole cross-K/V buffer with zeros
+// first -- 9.8 GB per 20-window batch -- cost 1.9 ms per pass.)
+__global__ __launch_bounds__(256) void pad_zero_kernel(unsigned char *base, int64_t row_bytes, int64_t batch_bytes, int off_bytes,
+                                                       int pad_bytes, int rows)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    unsigned char *p = base + (size_t)blockIdx.y * batch_bytes + (size_t)r * row_bytes + off_bytes;
+    if ((((uintptr_t)p) & 7) == 0 && (pad_bytes & 7) == 0) {
+        for (int i = 0; i < pad_bytes; i += 8) *(unsigned long long *)(p + i) = 0ull;
+    } else {
+        for (int i = 0; i < pad_bytes; ++i) p[i] = 0;
+    }
+}
+
+int swx_pad_zero(void *base, int64_t row_bytes, int64_t batch_bytes, int off_bytes, int pad_bytes, int rows, int nb, hipStream_t s)
+{
+    if (rows <= 0 || nb <= 0 || pad_bytes <= 0) return 0;
+    hipLaunchKernelGGL(pad_zero_kernel, dim3(cdiv(rows, 256), nb), dim3(256), 0, s, (unsigned char *)base, row_bytes, batch_bytes,
+                       off_bytes, pad_bytes, rows);
     SWX_CHECK_LAUNCH();
     return 0;
 }

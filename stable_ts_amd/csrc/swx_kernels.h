@@ -147,6 +147,7 @@ int swx_xkv_pack(const void *k, const void *vt, void *packed, int B, int H, int 
 int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s);
 // V [B][n][ldv] -> per-head transposed V^T [B][H][64][kp] (keys contiguous, zero padded): feeds the MFMA flash kernel's vector path
 int swx_transpose_v(const void *v, int64_t ldv, int64_t v_bs, int n, void *vt, int kp, int64_t vt_bs, int B, int H, hipStream_t s);
+int swx_pad_zero(void *base, int64_t row_bytes, int64_t batch_bytes, int off_bytes, int pad_bytes, int rows, int nb, hipStream_t s);
 // decoder self-attention over the per-row KV cache with ancestor indirection
 struct SelfAttnArgs {
     const void *qkv; int64_t ldqkv;  // [R*n_new][3d]: q | k | v of the new tokens

@@ -998,8 +998,10 @@ int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *strea
     if (D.n_audio_state != d) return -1;
     const int64_t chunk = xkv_chunk_elems(m);
     hipStream_t s = S(stream);
-    // the key padding of V^T (columns S_..KP) must be finite: it is multiplied by exact-zero probabilities
-    SWX_TRY(swx_fill_zero(d_xkv, swx_cross_kv_bytes(m, B), s));
+    // the key padding of V^T (columns S_..KP of each of the d rows of every layer's / window's V^T block) must be finite: it is
+    // multiplied by exact-zero probabilities.  Everything else in the buffer is written below (K rows, V^T columns, packed copy).
+    SWX_TRY(swx_pad_zero((unsigned char *)d_xkv + (size_t)S_ * d * e, (int64_t)SWX_VT_KP * e, chunk * (int64_t)e, (int)(S_ * e),
+                         (int)((SWX_VT_KP - S_) * e), d, D.n_text_layer * B, s));
     for (int l = 0; l < D.n_text_layer; ++l) {
         const LayerW &w = m->dec[l];
         unsigned char *base = (unsigned char *)d_xkv + (size_t)l * B * chunk * e;
