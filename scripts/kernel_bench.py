@@ -45,7 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--only", default="")
-    ap.add_argument("--gemm-kernel", type=int, default=1, help="force_kernel of the tiled GEMM: 1 register-staged, 4 direct-to-LDS")
+    ap.add_argument("--gemm-kernel", type=int, default=1, help="force_kernel of the tiled GEMM: 1 register-staged, 5-7 direct-to-LDS variants, 8 / 9 = 64-column tiles always / never")
     args = ap.parse_args()
     from stable_ts_amd import _lib
     lib = _lib.load()
@@ -59,7 +59,8 @@ def main():
     if args.only in ("", "gemm"):
         print(f"-- tiled MFMA GEMM (encoder / cross-KV / scoring shapes), f16, bias epilogue, force_kernel={args.gemm_kernel}")
         for M, N, K in [(30000, 1280, 1280), (30000, 3840, 1280), (30000, 5120, 1280), (30000, 1280, 5120), (30000, 2560, 1280),
-                        (2240, 1280, 1280), (2240, 5120, 1280), (100, 51866, 1280)]:
+                        (2240, 1280, 1280), (2240, 5120, 1280), (100, 51866, 1280), (1500, 1280, 1280), (1500, 3840, 1280),
+                        (1500, 5120, 1280), (1500, 1280, 5120)]:
             a, w, c = rnd(M, K), rnd(N, K), torch.empty(M, N, dtype=torch.half, device=dev)
             bias = torch.zeros(N, device=dev)
             us = timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, args.gemm_kernel, st), max(args.iters // 10, 5))

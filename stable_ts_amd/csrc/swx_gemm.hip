@@ -48,9 +48,12 @@ constexpr int CLD = BN + 4;                 // f32 staging row of the epilogue
 // 8 columns for every row group of a thread) and the residual rows of a half are requested BEFORE the accumulators are
 // staged: loaded per row group after the previous group's store (a store through a f16 pointer may alias the f32 bias, so
 // hipcc keeps the order) they were eight dependent L2 round trips per tile -- 43 % of a K = 1280 launch (see below).
-__device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][4], int m0, int n0,
+template <int NJ>      // NJ 16-column fragments per wave: tile width BNT = 32 NJ (128 or 64 columns)
+__device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][NJ], int m0, int n0,
                                                      int tid, int lane, int wm, int wn)
 {
+    constexpr int BNT = 32 * NJ, WN = 16 * NJ;        // tile width, columns per wave
+    constexpr int CLD_ = BNT + 4;
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
     // EPI_STORE_VT (the cross-attention V, stored transposed per head: element (row, col) at [col][row within the window]):
     // through LDS like the plain path, but read back COLUMN-wise -- a thread takes 4 consecutive rows of one column (8 bytes in
@@ -59,21 +62,22 @@ __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned ch
     // 61-83 us against 30 us for the same shape with a plain epilogue.
     if ((g.epi & EPI_STORE_VT) && !(g.epi & (EPI_RES | EPI_GELU | EPI_OUT_F32 | EPI_RESF32MOD | EPI_CBATCH)) && g.vt_s % 4 == 0 &&
         g.vt_kp % 4 == 0 && g.vt_bs % 4 == 0 && g.M % 4 == 0) {
-        constexpr int CLV = 129;                             // odd pitch: the column-wise read-back is 2-way conflicted at worst
+        constexpr int CLV = BNT + 1;                         // odd pitch: the column-wise read-back is 2-way conflicted at worst
         float (*Cv)[CLV] = (float (*)[CLV])smem;            // 64 x 129 x 4 B = 33.0 KB per half
         const int rg = tid & 15, cq = tid >> 4;
-        float bvt[8];                                        // this thread's 8 columns: requested before any store
+        constexpr int NKV = BNT / 16;
+        float bvt[NKV];                                      // this thread's columns: requested before any store
 #pragma unroll
-        for (int k = 0; k < 8; ++k) bvt[k] = ((g.epi & EPI_BIAS) && n0 + cq + 16 * k < g.N) ? g.bias[n0 + cq + 16 * k] : 0.f;
+        for (int k = 0; k < NKV; ++k) bvt[k] = ((g.epi & EPI_BIAS) && n0 + cq + 16 * k < g.N) ? g.bias[n0 + cq + 16 * k] : 0.f;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (wm == half) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) Cv[i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
+                        for (int r = 0; r < 4; ++r) Cv[i * 16 + row_l + r][wn * WN + j * 16 + col_l] = acc[i][j][r];
             }
             __syncthreads();
             const int gm = m0 + half * 64 + rg * 4;
@@ -81,7 +85,7 @@ __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned ch
                 const int wb = gm / g.vt_s, sidx = gm - wb * g.vt_s;
                 f16 *cbase = (f16 *)g.C + (size_t)wb * g.vt_bs + sidx;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
+                for (int k = 0; k < NKV; ++k) {
                     const int col = cq + 16 * k, gn = n0 + col;
                     if (gn >= g.N) continue;
                     const float b = bvt[k];
@@ -105,25 +109,26 @@ __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned ch
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
+                    epilogue_store<f16>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * WN + j * 16 + col_l, acc[i][j][r]);
         return;
     }
-    float (*Cs)[CLD] = (float (*)[CLD])smem;            // 64 x 132 x 4 B = 33.8 KB per half
-    const int c8 = (tid & 15) * 8, rb = tid >> 4, gn = n0 + c8;
+    float (*Cs)[CLD_] = (float (*)[CLD_])smem;          // 64 x 132 x 4 B = 33.8 KB per half (BNT = 128)
+    constexpr int TPR = BNT / 8, RPI = 256 / TPR, NIT = 64 / RPI;    // threads per row, rows per iteration, iterations per half
+    const int c8 = (tid % TPR) * 8, rb = tid / TPR, gn = n0 + c8;
     const bool col_ok = gn < g.N, full = gn + 8 <= g.N;
     float bv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bv[e] = ((g.epi & EPI_BIAS) && gn + e < g.N) ? g.bias[gn + e] : 0.f;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        f16x8 rv[4];
+        f16x8 rv[NIT];
         if (g.epi & EPI_RES) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int gm = m0 + half * 64 + it * 16 + rb;
+            for (int it = 0; it < NIT; ++it) {
+                const int gm = m0 + half * 64 + it * RPI + rb;
                 rv[it] = (gm < g.M && full) ? *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn) : (f16x8)(f16)0;
             }
         }
@@ -131,14 +136,14 @@ __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned ch
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Cs[i * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) Cs[i * 16 + row_l + r][wn * WN + j * 16 + col_l] = acc[i][j][r];
         }
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 16 + rb, gm = m0 + half * 64 + row;
+        for (int it = 0; it < NIT; ++it) {
+            const int row = it * RPI + rb, gm = m0 + half * 64 + row;
             if (gm >= g.M || !col_ok) continue;
             const f32x4 lo = *(const f32x4 *)&Cs[row][c8], hi = *(const f32x4 *)&Cs[row][c8 + 4];
             float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
         __syncthreads();
     }
 
-    tile_epilogue_f16(g, smem, acc, m0, n0, tid, lane, wm, wn);
+    tile_epilogue_f16<4>(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------- tiled f16, direct-to-LDS
@@ -264,13 +269,16 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 // variants produce bit-identical results (same MFMA order per accumulator, same f32 epilogue arithmetic;
 // tests/hw_checks/gemm_glds_check.py).  Default: <true, 3>.
 constexpr int GL_TILE = 128 * 128;          // bytes of one operand tile: 128 rows x 64 halfs
-constexpr int GL2_EPI = 64 * CLD * 4;
 
-template <bool SINGLE, int OCC>
+template <bool SINGLE, int OCC, int BNT>     // BNT = tile width: 128, or 64 for shapes whose 128-wide tiles would not fill the chip
 __global__ __launch_bounds__(256, OCC) void gemm_f16_glds(GemmArgs g)
 {
-    constexpr int MAIN = (SINGLE ? 2 : 4) * GL_TILE;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[MAIN > GL2_EPI ? MAIN : GL2_EPI];
+    constexpr int NJ = BNT / 32;                       // 16-column fragments per wave (2 x 2 waves: 64 rows x BNT / 2 columns each)
+    constexpr int TB = BNT * 128;                      // bytes of the B operand tile (BNT rows x 64 halfs)
+    constexpr int STAGE = GL_TILE + TB;
+    constexpr int MAIN = (SINGLE ? 1 : 2) * STAGE;
+    constexpr int EPI_ = 64 * (BNT + 4) * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[MAIN > EPI_ ? MAIN : EPI_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx = blockIdx.x, by = blockIdx.y;
@@ -280,56 +288,63 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16_glds(GemmArgs g)
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
         bx = wg % gx; by = wg / gx;
     }
-    const int m0 = by * BM, n0 = bx * BN;
+    const int m0 = by * BM, n0 = bx * BNT;
     const f16 *A = (const f16 *)g.A;
     const f16 *W = (const f16 *)g.W;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const f16 *srcA[4], *srcW[4];
+    // per-lane source rows of the 8-row chunks this wave stages: four of A, NJ of W (chunk = wave * n + c)
+    const f16 *srcA[4], *srcW[NJ];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const int r = (wave * 4 + c) * 8 + (lane >> 3);
         const int slot = (lane & 7) ^ ((r >> 1) & 7);
-        const int gm = m0 + r < g.M ? m0 + r : g.M - 1, gn = n0 + r < g.N ? n0 + r : g.N - 1;
+        const int gm = m0 + r < g.M ? m0 + r : g.M - 1;
         srcA[c] = A + (size_t)gm * g.lda + slot * 8;
+    }
+#pragma unroll
+    for (int c = 0; c < NJ; ++c) {
+        const int r = (wave * NJ + c) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        const int gn = n0 + r < g.N ? n0 + r : g.N - 1;
         srcW[c] = W + (size_t)gn * g.ldw + slot * 8;
     }
     typedef __attribute__((address_space(3))) void lds_void;
     auto stage = [&](int kt, int buf) {
-        unsigned char *ta = smem + buf * 2 * GL_TILE, *tb = ta + GL_TILE;
+        unsigned char *ta = smem + buf * STAGE, *tb = ta + GL_TILE;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int off = (wave * 4 + c) * 1024;
-            __builtin_amdgcn_global_load_lds(srcA[c] + kt * 64, (lds_void *)(ta + off), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(srcW[c] + kt * 64, (lds_void *)(tb + off), 16, 0, 0);
-        }
+        for (int c = 0; c < 4; ++c)
+            __builtin_amdgcn_global_load_lds(srcA[c] + kt * 64, (lds_void *)(ta + (wave * 4 + c) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NJ; ++c)
+            __builtin_amdgcn_global_load_lds(srcW[c] + kt * 64, (lds_void *)(tb + (wave * NJ + c) * 1024), 16, 0, 0);
     };
     const int KT = g.K / 64;
     const int fr = lane & 15, fs = lane >> 4;
     auto compute = [&](int buf) {
-        const unsigned char *ta = smem + buf * 2 * GL_TILE, *tb = ta + GL_TILE;
+        const unsigned char *ta = smem + buf * STAGE, *tb = ta + GL_TILE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            f16x8 a[4], b[4];
+            f16x8 a[4], b[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 64 + i * 16 + fr;
                 a[i] = *(const f16x8 *)(ta + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + fr;
+            for (int j = 0; j < NJ; ++j) {
+                const int row = wn * (BNT / 2) + j * 16 + fr;
                 b[j] = *(const f16x8 *)(tb + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16_glds(GemmArgs g)
             __syncthreads();
         }
     }
-    tile_epilogue_f16(g, smem, acc, m0, n0, tid, lane, wm, wn);
+    tile_epilogue_f16<NJ>(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------ tiled f32
@@ -885,12 +900,17 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
             const bool glds_ok = g.K % 64 == 0 && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0);
             if (force_kernel >= 4 && !glds_ok) return -4;
+            // 64-column tiles when 128-wide ones would leave CUs idle (encoder at batch 1: M = 1500, N = 1280 is 120 tiles of
+            // 128 x 128 for 256 CUs); force_kernel 8 / 9 = always / never for the A/B
+            const bool narrow = force_kernel == 8 || (force_kernel != 9 && g.N % 64 == 0 && (int64_t)grid.x * grid.y < 224);
             if (glds_ok && (force_kernel == 4 || force_kernel == 5))
-                hipLaunchKernelGGL((gemm_f16_glds<false, 2>), grid, dim3(256), 0, s, g);
+                hipLaunchKernelGGL((gemm_f16_glds<false, 2, 128>), grid, dim3(256), 0, s, g);
             else if (glds_ok && force_kernel == 6)
-                hipLaunchKernelGGL((gemm_f16_glds<true, 4>), grid, dim3(256), 0, s, g);
-            else if (glds_ok && (force_kernel == 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
-                hipLaunchKernelGGL((gemm_f16_glds<true, 3>), grid, dim3(256), 0, s, g);
+                hipLaunchKernelGGL((gemm_f16_glds<true, 4, 128>), grid, dim3(256), 0, s, g);
+            else if (glds_ok && narrow && (force_kernel >= 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
+                hipLaunchKernelGGL((gemm_f16_glds<true, 3, 64>), dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
+            else if (glds_ok && (force_kernel >= 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
+                hipLaunchKernelGGL((gemm_f16_glds<true, 3, 128>), grid, dim3(256), 0, s, g);
             else
                 hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
         }

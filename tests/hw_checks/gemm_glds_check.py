@@ -1,5 +1,6 @@
 """Hardware check of the direct-to-LDS tiled GEMM (gemm_f16_glds<SINGLE, OCC>, force_kernel = 5 double buffered, 6 / 7
-single buffered at 4 / 3 workgroups per CU; 7 is the default): each runs the same MFMA sequence per accumulator as
+single buffered at 4 / 3 workgroups per CU; 7 is the default, which picks 64-column tiles for shapes with few tiles:
+8 / 9 = always / never): each runs the same MFMA sequence per accumulator as
 gemm_f16_tiled (force_kernel = 1), so all must agree BIT FOR BIT; they are also held to a CPU float64 reference.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
 
     python tests/hw_checks/gemm_glds_check.py
@@ -33,7 +34,7 @@ def main() -> int:
         bias = torch.randn(N, generator=g).float().to(dev)
         res = torch.randn(M, N, generator=g).half().to(dev)
         outs = []
-        for force in (1, 5, 6, 7):
+        for force in (1, 5, 6, 7, 8, 9):
             c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
             rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), p(res) if epi & EPI_RES else None, p(c), N, M, N, K, epi, force, st)
             torch.cuda.synchronize()
