@@ -50,6 +50,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print(" ".join(cmd), flush=True)
     try:
         subprocess.check_call(cmd)
+        # a shared library links with unresolved symbols without complaint: load it once before it replaces the good one
+        probe = subprocess.run([sys.executable, "-c", f"import ctypes; ctypes.CDLL({tmp!r})"], capture_output=True, text=True)
+        if probe.returncode != 0:
+            raise RuntimeError("libswx.so does not load: " + probe.stderr.strip().splitlines()[-1])
         os.replace(tmp, OUT)
     finally:
         if os.path.exists(tmp):

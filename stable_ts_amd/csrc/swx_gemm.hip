@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 // tests/hw_checks/gemm_glds_check.py).  Default: <true, 3>.
 constexpr int GL_TILE = 128 * 128;          // bytes of one operand tile: 128 rows x 64 halfs
 
-template <bool SINGLE, int OCC, int BNT>     // BNT = tile width: 128, or 64 for shapes whose 128-wide tiles would not fill the chip
-__global__ __launch_bounds__(256, OCC) void gemm_f16_glds(GemmArgs g)
+template <bool SINGLE, int BNT>     // BNT = tile width: 128, or 64 for shapes whose 128-wide tiles would not fill the chip
+__device__ __forceinline__ void gemm_f16_glds_body(const GemmArgs &g)
 {
     constexpr int NJ = BNT / 32;                       // 16-column fragments per wave (2 x 2 waves: 64 rows x BNT / 2 columns each)
     constexpr int TB = BNT * 128;                      // bytes of the B operand tile (BNT rows x 64 halfs)
@@ -367,6 +367,12 @@ __global__ __launch_bounds__(256, OCC) void gemm_f16_glds(GemmArgs g)
     }
     tile_epilogue_f16<NJ>(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
+
+// the instantiations in use (second launch bound = workgroups per CU the register allocation must allow)
+__global__ __launch_bounds__(256, 2) void gemm_f16_glds_d2_128(GemmArgs g) { gemm_f16_glds_body<false, 128>(g); }
+__global__ __launch_bounds__(256, 4) void gemm_f16_glds_s4_128(GemmArgs g) { gemm_f16_glds_body<true, 128>(g); }
+__global__ __launch_bounds__(256, 3) void gemm_f16_glds_s3_128(GemmArgs g) { gemm_f16_glds_body<true, 128>(g); }
+__global__ __launch_bounds__(256, 3) void gemm_f16_glds_s3_64(GemmArgs g) { gemm_f16_glds_body<true, 64>(g); }
 
 // ------------------------------------------------------------------------------------------------ tiled f32
 constexpr int BK32 = 16, LD32 = BK32 + 1;
@@ -904,13 +910,13 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             // 128 x 128 for 256 CUs); force_kernel 8 / 9 = always / never for the A/B
             const bool narrow = force_kernel == 8 || (force_kernel != 9 && g.N % 64 == 0 && (int64_t)grid.x * grid.y < 224);
             if (glds_ok && (force_kernel == 4 || force_kernel == 5))
-                hipLaunchKernelGGL((gemm_f16_glds<false, 2, 128>), grid, dim3(256), 0, s, g);
+                hipLaunchKernelGGL(gemm_f16_glds_d2_128, grid, dim3(256), 0, s, g);
             else if (glds_ok && force_kernel == 6)
-                hipLaunchKernelGGL((gemm_f16_glds<true, 4, 128>), grid, dim3(256), 0, s, g);
+                hipLaunchKernelGGL(gemm_f16_glds_s4_128, grid, dim3(256), 0, s, g);
             else if (glds_ok && narrow && (force_kernel >= 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
-                hipLaunchKernelGGL((gemm_f16_glds<true, 3, 64>), dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
+                hipLaunchKernelGGL(gemm_f16_glds_s3_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
             else if (glds_ok && (force_kernel >= 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
-                hipLaunchKernelGGL((gemm_f16_glds<true, 3, 128>), grid, dim3(256), 0, s, g);
+                hipLaunchKernelGGL(gemm_f16_glds_s3_128, grid, dim3(256), 0, s, g);
             else
                 hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
         }
