@@ -366,6 +366,10 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     __shared__ float sm_o[4][DH][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
+    // blockIdx.z = group of 16 query rows of this (window, head): a teacher-forced pass of ~100 rows over ONE window has 20
+    // flash workgroups to offer 256 CUs; as groups of 16 rows on this kernel it has 100-160, each streaming the head's K / V^T
+    // (384 KB, L2-resident after the first group) with its 4 waves splitting the keys
+    const int q_base = blockIdx.z * 16;
     const int qn = lane & 15, g = lane >> 4;
     const f16 *Q = (const f16 *)a.q;
     const f16 *Kp = (const f16 *)a.k + (size_t)b * a.k_bs + h * DH;
@@ -418,8 +422,8 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         {
             const SlabRef sr = a.qs;
             const int row = tid >> 4, c0 = (tid & 15) * 4;          // 16 rows x 16 float4 columns = the 256 lanes
-            const bool rok = row < a.nq;
-            const float *sp = sr.slabs + ((size_t)b * a.q_rows_per_batch + (rok ? row : 0)) * sr.N + h * DH + c0;
+            const bool rok = q_base + row < a.nq;
+            const float *sp = sr.slabs + ((size_t)b * a.q_rows_per_batch + (rok ? q_base + row : 0)) * sr.N + h * DH + c0;
             // every slab load is issued before the first add (a rolled loop compiles to one round trip PER slab);
             // slots past ks2 re-read the last slab (clamped, never predicated) and are skipped in the sum
             f32x4 part[SLAB_KMAX];
@@ -439,9 +443,10 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         qf[0] = *(const f16x8 *)&qsh[qn][g * 8];
         qf[1] = *(const f16x8 *)&qsh[qn][32 + g * 8];
     } else {
-        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qn < a.nq ? qn : 0)) * a.ldq + h * DH + g * 8;
-        qf[0] = (qn < a.nq) ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
-        qf[1] = (qn < a.nq) ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
+        const bool qok = q_base + qn < a.nq;
+        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qok ? q_base + qn : 0)) * a.ldq + h * DH + g * 8;
+        qf[0] = qok ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
+        qf[1] = qok ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
     }
 
     auto compute_blk = [&](int cb, const f16x8 (&kf)[4], const f16x8 (&vf)[4]) {
@@ -517,7 +522,8 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) sm_o[wave][t * 16 + g * 4 + r][qn] = o[t][r];
     __syncthreads();
-    for (int i = tid; i < a.nq * DH; i += 256) {
+    const int nq_here = a.nq - q_base < 16 ? a.nq - q_base : 16;
+    for (int i = tid; i < nq_here * DH; i += 256) {
         const int q = i >> 6, d = i & 63;
         const float M = fmaxf(fmaxf(sm_m[0][q], sm_m[1][q]), fmaxf(sm_m[2][q], sm_m[3][q]));
         float L = 0.f, O = 0.f;
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
             L += sm_l[w][q] * f;
             O += sm_o[w][d][q] * f;
         }
-        ((f16 *)a.o)[((size_t)b * a.q_rows_per_batch + q) * a.ldo + h * DH + d] = (f16)(O / L);
+        ((f16 *)a.o)[((size_t)b * a.q_rows_per_batch + q_base + q) * a.ldo + h * DH + d] = (f16)(O / L);
     }
 }
 
@@ -953,14 +959,19 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     if (a.nk > RW_MAXK) return -5;
     const bool flash = (dtype == SWX_F16) && (force_kernel == 2 || (force_kernel == 0 && a.nq >= 32));
     const size_t esz = dtype == SWX_F16 ? 2 : 4;
-    const bool dec = (dtype == SWX_F16) && a.vt_kp > 0 && a.nq <= 16 && a.nk >= 128 && (force_kernel == 3 || force_kernel == 0);
+    // the decode kernel also takes a SMALL multi-row pass (align(): one window of ~100 rows) as groups of 16 rows, when the
+    // fragment-ordered K / V^T copy exists and the flash grid would be tiny
+    const int ngrp = cdiv(a.nq, 16);
+    const bool small_pass = a.nq > 16 && a.nq <= 160 && a.kv_packed && !a.qs.slabs && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV) &&
+                            (int64_t)a.B * a.H * ngrp <= 1024 && force_kernel == 0;
+    const bool dec = (dtype == SWX_F16) && a.vt_kp > 0 && (a.nq <= 16 || small_pass) && a.nk >= 128 && (force_kernel == 3 || force_kernel == 0);
     if (force_kernel == 3 && !dec) return -5;
     if (a.qs.slabs && !dec) return -5;         // only the decode kernel finishes q from slabs
     if (dec) {
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
         const bool qsl = a.qs.slabs != nullptr, pipe = (swx_flags() & SWX_FLAG_XATTN_PIPE) != 0;
         if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias || a.qs.ks2 < 1 || a.qs.ks2 > SLAB_KMAX)) return -5;
-        dim3 gd(a.H, a.B);
+        dim3 gd(a.H, a.B, a.nq <= 16 ? 1 : ngrp);
 #define SWX_XA(QS_, PP_) hipLaunchKernelGGL((attn_decode_cross_f16<QS_, PP_>), gd, dim3(256), 0, s, a)
         if (a.kv_packed && !qsl && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV))
             hipLaunchKernelGGL((attn_decode_cross_f16<false, false, true>), gd, dim3(256), 0, s, a);

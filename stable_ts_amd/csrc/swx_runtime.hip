@@ -520,6 +520,7 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         ca.q = q; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
         ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
         ca.B = f.W; ca.H = H; ca.nq = f.rpw * f.n_new; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw * f.n_new;
+        ca.kv_packed = kl + (size_t)xkv_plain_elems(D) * e;          // lets a small pass run as 16-row groups on the decode kernel
         SWX_TRY(swx_attention(m->dtype, ca, 0, s));
         if (f.capture && !m->heads_by_layer[l].empty()) {
             SWX_TRY(swx_qk_capture(m->dtype, q, d, f.rpw * f.n_new, f.cap_row0, f.cap_rows, kl, d, chunk, D.n_audio_ctx,
