@@ -152,6 +152,64 @@ def test_loudness_from_probe_is_the_full_length_path_bit_for_bit():
     st._probe_scratch.buf = {}
 
 
+def test_loudness_from_probe_random_lengths():
+    """the reconstruction for 40 random window lengths (the last window of a recording is ragged; clip sections and
+    nonspeech_skip cut windows anywhere): always the full-length curve bit for bit, never a NaN refusal"""
+    from stable_ts_amd.stabilization import audio2loudness, loudness_from_probe, probe_indices
+    g = torch.Generator().manual_seed(2024)
+    lens = [int(v) for v in torch.randint(1000, 480001, (36,), generator=g)] + [1000, 1001, 479999, 480000]
+    for n in lens:
+        x = torch.randn(n, generator=g) * (10.0 ** float(torch.empty(1).uniform_(-4, 0, generator=g)))
+        x[torch.rand(n, generator=g) < 0.3] *= 0.01
+        ref = audio2loudness(x.clone())
+        idx = probe_indices(n)
+        if idx is None:
+            assert ref is None
+            continue
+        ax = x.abs().numpy()
+        k = int(n * 0.001)
+        thr = float(np.partition(ax, ax.size - k)[ax.size - k])
+        got = loudness_from_probe(n, thr, idx, torch.from_numpy(ax[idx]))
+        assert got is not False and torch.equal(got, ref), n
+
+
+def test_entry_points_park_the_intra_op_pool():
+    """model.transcribe / align / ... run with torch's intra-op pool parked (stabilization.host_single_thread) and give it
+    back afterwards, also when the call raises; a model object that computes on the host (the test stand-in) keeps it"""
+    from stable_ts_amd.stabilization import host_single_thread
+    before = torch.get_num_threads()
+    if before == 1:
+        torch.set_num_threads(2)
+    n0 = torch.get_num_threads()
+    try:
+        seen = []
+
+        @host_single_thread
+        def entry(model, fail=False):
+            seen.append(torch.get_num_threads())
+            if fail:
+                raise ValueError("x")
+            return 7
+
+        class Dev:
+            pass
+
+        class Host:
+            computes_on_host = True
+
+        assert entry(Dev()) == 7 and seen[-1] == 1 and torch.get_num_threads() == n0
+        with pytest.raises(ValueError):
+            entry(Dev(), fail=True)
+        assert torch.get_num_threads() == n0
+        assert entry(Host()) == 7 and seen[-1] == n0
+        import stable_ts_amd.alignment as A
+        import stable_ts_amd.transcribe as T
+        for fn in (T.transcribe_stable, T.transcribe_minimal, A.align, A.align_words, A.refine):
+            assert hasattr(fn, "__wrapped__"), fn.__name__
+    finally:
+        torch.set_num_threads(before)
+
+
 def test_result_container():
     from stable_ts_amd.result import UnsortedException, WhisperResult
     r = WhisperResult(dict(language="en", segments=[dict(start=0.0, end=1.0, text=" a b", seek=0.0, tokens=[1, 2], words=[
