@@ -275,7 +275,9 @@ class Engine:
               "swx_score")
         T = [n - n_sot - 2 for n in n_tok]
         if _defer:
-            return probs, neg, T                     # enqueued, not waited for: score_finish() copies the probabilities out
+            # enqueued, not waited for: score_finish() copies the probabilities out.  The token tensor rides along so that its
+            # memory is not handed out again while the pass is still reading it
+            return probs, neg, T, d_tok
         return self.score_finish((probs, neg, T))
 
     def score_start(self, *args, **kw):
@@ -285,7 +287,7 @@ class Engine:
 
     @staticmethod
     def score_finish(handle):
-        probs, neg, T = handle
+        probs, neg, T = handle[:3]
         p = probs.cpu().numpy()
         return [p[w, :T[w]].astype(np.float64).tolist() for w in range(len(T))], neg, T
 

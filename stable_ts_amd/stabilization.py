@@ -212,10 +212,8 @@ class NonSpeechPredictor:
                 loud = got
         if loud is not False and self.loudness:
             return self._from_mask(wav2mask(None, self.q_levels, self.k_size, loud=loud), offset)
-        with _single_host_thread():
-            return self._predict_host(audio, offset)
-
-    def _predict_host(self, audio: torch.Tensor, offset: float) -> dict:
+        # (the public entry points run with torch's intra-op pool parked -- host_single_thread -- so the element-wise passes
+        # over 480 000 samples below do not wake OpenMP workers; a direct caller decides for itself)
         audio = audio.detach().float().cpu().contiguous()
         if not self.loudness:
             # :271-286 with get_mask: one flag per 20-ms unit, True where EVERY sample of the unit is non-zero
