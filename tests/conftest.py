@@ -3,6 +3,12 @@ import sys
 
 import pytest
 
+# The CPU oracle's matmuls must not depend on the machine's load: with dynamic thread adjustment a busy host (xdist workers
+# sharing a CPU quota) changes the BLAS / OpenMP partition from call to call, i.e. the last bits of the logits, and a token
+# comparison on random weights can then flip at a near-tie (seen once in ~6 runs of the GPU suite under -n 4).
+os.environ.setdefault("MKL_DYNAMIC", "FALSE")
+os.environ.setdefault("OMP_DYNAMIC", "FALSE")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
