@@ -97,3 +97,41 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
         assert first_barrier is not None and last_mfma is not None and first_barrier < last_mfma, name
         early = [d for d in drains if d < last_mfma]
         assert not early, f"{name}: s_waitcnt vmcnt(0) before the last MFMA (lines {early[:3]}): the weight stream is drained"
+
+
+def _kernel_meta(src_name):
+    """(kernel name -> dict of the metadata hipcc emits) for one csrc file, compiled for gfx950 (device only)"""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not present")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(ROOT, "stable_ts_amd", "csrc", src_name)
+        out = os.path.join(td, "k.s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", src, "-o", out], cwd=td, stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    meta = {}
+    for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size", text, re.S):
+        blk = m.group(0)
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(re.search(rf"\.{k}:\s+(\d+)", blk).group(1))
+                      for k in ("vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+    return meta
+
+
+@pytest.mark.parametrize("src,kernels,max_vgpr", [
+    # the default tiled GEMMs: three workgroups per CU need <= 168 VGPRs and <= 53 KB of LDS each
+    ("swx_gemm.hip", ["gemm_f16_glds_s3_128", "gemm_f16_glds_s3_64"], 168),
+    # DTW generation 3 (x chunks in registers) and the register-resident logit filters (1024 threads: <= 128 VGPRs)
+    ("swx_dtw.hip", ["swx_dtw4_kernelILi1ELb1E", "swx_dtw4_kernelILi2ELb0E"], 256),
+    ("swx_decode.hip", ["decode_select_reg_kernel"], 128),
+])
+def test_hot_kernels_do_not_spill(src, kernels, max_vgpr):
+    meta = _kernel_meta(src)
+    for want in kernels:
+        hits = {n: v for n, v in meta.items() if want in n}
+        assert hits, (want, sorted(meta)[:5])
+        for n, v in hits.items():
+            assert v["private_segment_fixed_size"] == 0, (n, v)            # no scratch: nothing spilled
+            assert v["vgpr_count"] <= max_vgpr, (n, v)
+            if "glds_s3" in n:
+                assert v["group_segment_fixed_size"] <= 53 * 1024, (n, v)
