@@ -113,6 +113,25 @@ def test_transcribe_window_parallel_equals_per_clip():
             assert abs(wa["start"] - wb["start"]) < 2e-3 and abs(wa["end"] - wb["end"]) < 2e-3
 
 
+def test_transcribe_device_resident_audio_equals_host_audio():
+    # the same recording handed over on the GPU and on the host: on the GPU the silence analysis takes the device probe
+    # (swx_loudness_probe) and, in batch mode, the encoder is enqueued under its host half; on the host it takes the
+    # full-length path.  The masks are the same by construction, so the whole result must be IDENTICAL -- sequential and
+    # window-parallel, with a silent window (skipped) and a long hole (nonspeech_skip) in the recording.
+    g = _golden()["tiny_en_t0_ss"]
+    case = g["case"]
+    model = _model(case)
+    audio = _synth_audio(100.0, 21).clone()
+    audio[16000 * 30: 16000 * 60] = 0.0
+    audio[16000 * 70: 16000 * 77] = 0.0
+    opts = dict(case["opts"])
+    for extra in (dict(), dict(batch_size=4), dict(batch_size=4, nonspeech_skip=5.0)):
+        host = model.transcribe(audio, language="en", regroup=False, **opts, **extra).to_dict()
+        dev = model.transcribe(audio.cuda(), language="en", regroup=False, **opts, **extra).to_dict()
+        assert len(host["segments"]) > 0
+        assert dev == host, extra
+
+
 def test_refinement_func_matches_reference_seam_b3():
     # the reference's get_whisper_refinement_func on the oracle model (golden) vs make_refinement_func on the device.
     # Runs in its own process: a first-ever hardware run of new device code must not be able to disturb the GPU context
