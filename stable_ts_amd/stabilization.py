@@ -283,6 +283,10 @@ def snap_to_speech(obj, starts: np.ndarray, ends: np.ndarray, min_word_dur: floa
     starts, ends = np.asarray(starts), np.asarray(ends)
     if len(starts) == 0 or (obj.end - obj.start) <= min_word_dur:
         return
+    # every rule below needs a section that reaches into the span (ends > start and starts < end, or it touches an edge):
+    # most words of a transcript have none, and this one test spares them the three masked searches
+    if not np.any((ends >= obj.start) & (starts <= obj.end)):
+        return
     if keep_end is None or keep_end:
         hit = np.all((starts <= obj.start, obj.start < ends, ends <= obj.end), axis=0).nonzero()[0]
         if len(hit):
