@@ -23,6 +23,7 @@ from typing import Callable, List, Optional, Sequence, Tuple, Union
 import numpy as np
 import torch
 
+from ._num import round3
 from .result import WhisperResult, WordTiming
 from .stabilization import NonSpeechPredictor
 from .timing import APPEND_PUNCTUATIONS, PREPEND_PUNCTUATIONS
@@ -285,7 +286,7 @@ class Aligner:
             if text == want.word:
                 if not want.is_padding:
                     a, b = min(t0, t_max), min(g["end"], t_max)
-                    out.append(TimedWord(want.word, round(a + time_offset, 3), round(b + time_offset, 3), want.tokens,
+                    out.append(TimedWord(want.word, round3(a + time_offset), round3(b + time_offset), want.tokens,
                                          np.mean(probs).item() if probs else 0.0))
                 k, text, t0, probs = k + 1, "", -1, []
             elif len(text) > len(want.word) or gi == len(got) - 1:

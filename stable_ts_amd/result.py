@@ -13,10 +13,12 @@ import json
 import warnings
 from typing import Iterator, List, Optional, Union
 
+from ._num import round3
+
 
 def _ms(ts):
     """result.py:38-41: timestamps are stored rounded to the millisecond (0 / None pass through)."""
-    return round(ts, 3) if ts else ts
+    return round3(ts) if ts else ts
 
 
 def _blend(a, b):

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from ._num import round3
 from .audio import FRAMES_PER_SECOND, N_SAMPLES_PER_TOKEN, TOKENS_PER_SECOND
 from .timing import APPEND_PUNCTUATIONS
 
@@ -290,13 +291,13 @@ def snap_to_speech(obj, starts: np.ndarray, ends: np.ndarray, min_word_dur: floa
     if keep_end is None or keep_end:
         hit = np.all((starts <= obj.start, obj.start < ends, ends <= obj.end), axis=0).nonzero()[0]
         if len(hit):
-            obj.start = min(float(ends[hit[0]]), round(obj.end - min_word_dur, 3))
+            obj.start = min(float(ends[hit[0]]), round3(obj.end - min_word_dur))
             if (obj.end - obj.start) <= min_word_dur:
                 return
     if not keep_end:
         hit = np.all((obj.start <= starts, starts < obj.end, obj.end <= ends), axis=0).nonzero()[0]
         if len(hit):
-            obj.end = max(float(starts[hit[0]]), round(obj.start + min_word_dur, 3))
+            obj.end = max(float(starts[hit[0]]), round3(obj.start + min_word_dur))
             if (obj.end - obj.start) <= min_word_dur:
                 return
     if nonspeech_error:
@@ -311,9 +312,9 @@ def snap_to_speech(obj, starts: np.ndarray, ends: np.ndarray, min_word_dur: floa
         if not (err_start <= nonspeech_error or err_end <= nonspeech_error):
             return
         if ke:
-            obj.start = min(e0, round(obj.end - min_word_dur, 3))
+            obj.start = min(e0, round3(obj.end - min_word_dur))
         else:
-            obj.end = max(s0, round(obj.start + min_word_dur, 3))
+            obj.end = max(s0, round3(obj.start + min_word_dur))
 
 
 def _snap(obj: dict, starts, ends, min_word_dur, nonspeech_error, keep_end):
@@ -331,7 +332,7 @@ def suppress_segment_silence(seg: dict, starts, ends, min_word_dur: float = 0.1,
             keep_end = (not (w["word"][-1] in APPEND_PUNCTUATIONS or i == len(sel))) if use_word_position else None
             _snap(w, starts, ends, min_word_dur, nonspeech_error, keep_end)
         for w in words:                                      # WordTiming stores millisecond-rounded stamps (result.py:38-41)
-            w["start"], w["end"] = (round(w["start"], 3) if w["start"] else w["start"]), (round(w["end"], 3) if w["end"] else w["end"])
+            w["start"], w["end"] = (round3(w["start"]) if w["start"] else w["start"]), (round3(w["end"]) if w["end"] else w["end"])
         seg["start"], seg["end"] = words[0]["start"], words[-1]["end"]
         # the reference round-trips the dict through Segment(...).to_dict() here (original_whisper.py:684-695): with
         # words present, text and tokens become views of the words (timestamp tokens drop out of ``tokens``)
@@ -340,4 +341,4 @@ def suppress_segment_silence(seg: dict, starts, ends, min_word_dur: float = 0.1,
             seg["tokens"] = [t for w in words for t in w["tokens"]]
     else:
         _snap(seg, starts, ends, min_word_dur, nonspeech_error, True)
-        seg["start"], seg["end"] = (round(seg["start"], 3) if seg["start"] else 0.0), (round(seg["end"], 3) if seg["end"] else 0.0)
+        seg["start"], seg["end"] = (round3(seg["start"]) if seg["start"] else 0.0), (round3(seg["end"]) if seg["end"] else 0.0)

@@ -239,3 +239,28 @@ def test_display_rounding_and_deprecations(ref):
     assert buf.getvalue() == "Result has no history.\n"
     r2 = copy.deepcopy(r)
     assert r2.segments[0] is not r.segments[0] and r2.text == r.text
+
+
+def test_round3_is_numpy_scalar_rounding_bit_for_bit():
+    """stable_ts_amd._num.round3 (the millisecond rounding of every stored timestamp) against the built-in round(x, 3) the
+    reference calls: for numpy.float64 inputs that is numpy's rint(x * 1000) / 1000, for Python floats the correctly rounded
+    decimal rounding -- same value, same type, same sign of zero, over random values, exact and one-ulp-off ties, already
+    rounded values, zeros, negatives, huge and non-finite values."""
+    import numpy as np
+    from stable_ts_amd._num import round3
+    rng = np.random.default_rng(123)
+    ties = (rng.integers(0, 4_000_000, size=60000) + 0.5) / 1000.0
+    vals = np.concatenate([rng.uniform(0, 4000, size=120000), ties, np.nextafter(ties, 1e9), np.nextafter(ties, -1e9),
+                           rng.integers(0, 4_000_000, size=60000) / 1000.0, rng.uniform(-100, 100, size=20000),
+                           np.array([0.0, -0.0, 1e-9, -1e-9, 1e15 + 0.3, 123456789.0005, 2.0 ** 52 + 0.5, 1e300, 1e12, 9.99e11,
+                                     np.inf, -np.inf])])
+    for v in vals:
+        x = np.float64(v)
+        a, b = round(x, 3), round3(x)
+        assert type(a) is type(b) and a.tobytes() == b.tobytes(), (repr(v), repr(a), repr(b))
+    assert np.isnan(round3(np.float64("nan")))
+    for v in (0.0, 1.0005, 2.675, 1234.5675, -3.14159, 7):
+        a, b = round(v, 3), round3(v)
+        assert type(a) is type(b) and a == b
+    f32 = np.float32(1.23456)
+    assert type(round3(f32)) is type(round(f32, 3)) and round3(f32) == round(f32, 3)
