@@ -35,7 +35,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_FUSE_SELF 16       // self-attention finishes q|k|v from the split-K slabs, appends K/V and attends in one launch
 #define SWX_FLAG_FUSE_CROSS_Q 64    // cross-attention finishes q from the split-K slabs (no finish launch for the query projection)
 #define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
-#define SWX_FLAG_DEC_V3 512        // decode step on the un-split "dec" GEMMs (swx_decstep.hip) when the batch has enough rows
+#define SWX_FLAG_DEC_V3 512        // decode step, small teacher-forced passes and the prefill on the un-split "dec" GEMMs (swx_decstep.hip)
 #define SWX_FLAG_NO_PACKED_XKV 2048 // decode cross-attention reads the row-layout K / V^T instead of the fragment-ordered copy (A/B)
 #define SWX_FLAG_FLASH_V1 4096      // MFMA flash attention: first-generation kernel (A/B)
 #define SWX_FLAG_SELECT_MEM 8192    // logit filters + token selection: the kernel that walks the row in memory (A/B and bit-identity reference)
