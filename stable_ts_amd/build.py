@@ -14,6 +14,29 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
+def build_variant(name: str, defines, verbose: bool = False) -> str:
+    """An experiment build of the whole library with extra -D switches, written to scripts/exp/libswx_<name>.so (git-ignored,
+    shipped to the GPU box); the A/B scripts copy it over stable_ts_amd/libswx.so on the box.  Never loaded by the product."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    outdir = os.path.join(os.path.dirname(HERE), "scripts", "exp")
+    objdir = os.path.join(outdir, "_build_" + name)
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for s in SOURCES:
+        o = os.path.join(objdir, s + ".o")
+        objs.append(o)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", *[f"-D{d}" for d in defines],
+               "-c", os.path.join(CSRC, s), "-o", o]
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
+    out = os.path.join(outdir, f"libswx_{name}.so")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + \

@@ -38,6 +38,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DEC_MAXMT = 3;
 
+// cache policy of the weight stream: every weight byte is read once per step by ONE XCD (the row groups of a panel share it
+// through that XCD's L2).  Built with -DSWX_DEC_NT the loads carry `nt` (MI355X_MICROARCH.md "nt-weights": -5..-10 % per layer
+// on a batch-1 decode layer); A/B on this step in profiles/r03_dec_nt_ab.txt.
+#ifdef SWX_DEC_NT
+#define SWX_DEC_W_POLICY " nt"
+#else
+#define SWX_DEC_W_POLICY ""
+#endif
+
 // NKS = K-slice depth / 32 and the epilogue EPI are fixed at compile time: every loop below unrolls without branches, and no
 // load sits under a run-time condition (a conditional load compiles to a branch whose join waits vmcnt(0), which would drain
 // the weight stream before the barrier -- seen in the ISA of the run-time-epilogue version)
@@ -95,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     f16x8 wf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
-        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(wf[ks]) : "v"(wp + (ks >> 2) * 2048), "n"((ks & 3) * 1024) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" SWX_DEC_W_POLICY : "=v"(wf[ks]) : "v"(wp + (ks >> 2) * 2048), "n"((ks & 3) * 1024) : "memory");
     // ---- epilogue operands (clamped addresses, never predicated): column constants and the residual rows
     constexpr int N_EPI = (E_SLAB ? 0 : 1) + (E_LN ? 1 : 0) + ((E_RES && !E_SLAB) ? MT : 0);   // loads younger than the weights
     const int n = panel * 64 + wave * 16 + lg * 4;

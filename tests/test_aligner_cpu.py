@@ -314,3 +314,31 @@ def test_align_words_on_standin_matches_reference(monkeypatch, as_dicts, opts):
                 fn(audio, given(cls), language="en", ignore_compatibility=True, max_word_dur=1.0)
             else:
                 fn(model, audio, given(cls), language="en", max_word_dur=1.0)
+
+
+def test_sharp_align_fixture_reproduced_by_host_code_on_standin(monkeypatch):
+    """tests/golden/reference_glue_sharp.json (the reference's align() / seam B2 on the oracle with SHARP weights; the GPU tests
+    hold the f32 AND the fp16 device path against it) is reproduced exactly by this package's host code on the CPU stand-in"""
+    import json
+    import warnings
+    import make_golden as G
+    import stable_ts_amd.alignment as A
+    from oracle.whisper.model import build_model
+    from oracle.whisper.tokenizer import get_tokenizer
+    from oracle_engine import CpuWhisper, install
+    install(monkeypatch)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_glue_sharp.json")) as f:
+        g = json.load(f)["align_base_en_sharp"]
+    c = g["case"]
+    mine = CpuWhisper(build_model(c["model"], **c["weights"]))
+    mine.manual_attention_encoder = True
+    audio = G.synth_audio(c["seconds"], c["seed"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = A.align(mine, audio, g["text"], language="en", regroup=False, suppress_silence=False)
+    words = got.all_words()
+    assert [(w.word, w.start, w.end, list(w.tokens)) for w in words] == [(w["word"], w["start"], w["end"], w["tokens"]) for w in g["words"]]
+    tok = get_tokenizer(False, num_languages=mine.num_languages)
+    func = A.make_alignment_func(mine, tok)
+    out = func(audio[:480000], [A.WordToken(tok.decode([i]), [i]) for i in g["ids"][:c["b2_words"]]])
+    assert [(w["word"], w["start"], w["end"]) for w in out] == [(w["word"], w["start"], w["end"]) for w in g["b2"]]

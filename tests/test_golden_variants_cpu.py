@@ -43,7 +43,7 @@ def test_variant_fixtures_match_host_code(fixtures, monkeypatch, name):
         assert [(w["word"], w["start"], w["end"], w["tokens"]) for w in a["words"]] == \
             [(w["word"], w["start"], w["end"], w["tokens"]) for w in b["words"]]
         for wa, wb in zip(a["words"], b["words"]):
-            assert abs(wa["probability"] - wb["probability"]) <= 1e-6 * abs(wb["probability"]) + 1e-12
+            assert abs(wa["probability"] - wb["probability"]) <= 1e-5 * abs(wb["probability"]) + 1e-12    # f32 oracle: the sum order depends on the host thread count
 
 
 def test_locate_fixtures_match_host_code(fixtures, monkeypatch):

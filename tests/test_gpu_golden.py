@@ -90,6 +90,41 @@ def test_alignment_func_matches_reference_seam_b2():
     assert res2.regroup_history.startswith("isp=1_cm=") and res2.language == "en"
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_alignment_sharp_weights_matches_reference_glue(dtype):
+    # tests/golden/reference_glue_sharp.json: the REFERENCE's get_whisper_alignment_func (seam B2, alignment.py:396-429) and
+    # model.align() on the CPU oracle with SHARP weights (logit gaps / attention maps like a trained model's), so that the
+    # fp16 device path -- what bench.py times -- is held to the same bar as the strict f32 path: identical words, every word
+    # start / end within +-20 ms (maximum deviation asserted and reported).
+    import stable_ts_amd as sw
+    from stable_ts_amd.alignment import WordToken, make_alignment_func
+    from stable_ts_amd.tokenizer import get_tokenizer
+    with open(os.path.join(HERE, "golden", "reference_glue_sharp.json")) as f:
+        g = json.load(f)["align_base_en_sharp"]
+    case = g["case"]
+    dims = sw.dims_for(case["model"])
+    model = sw.Whisper(dims, dtype=dtype, max_windows=1, max_rows=5)
+    model.load_state_dict(sw.random_state_dict(dims, **case["weights"]))
+    tok = get_tokenizer(False, num_languages=model.num_languages)
+    audio = _synth_audio(case["seconds"], case["seed"])
+    func = make_alignment_func(model, tok)
+    out = func(audio[:480000], [WordToken(tok.decode([i]), [i]) for i in g["ids"][:case["b2_words"]]])
+    assert [w["word"] for w in out] == [w["word"] for w in g["b2"]]
+    d_b2 = np.asarray([(abs(a["start"] - b["start"]), abs(a["end"] - b["end"])) for a, b in zip(out, g["b2"])])
+    res = model.align(audio, g["text"], language="en", regroup=False, suppress_silence=False)
+    words = res.all_words()
+    assert [w.word for w in words] == [w["word"] for w in g["words"]]
+    assert [list(w.tokens) for w in words] == [w["tokens"] for w in g["words"]]
+    d_al = np.asarray([(abs(w.start - r["start"]), abs(w.end - r["end"])) for w, r in zip(words, g["words"])])
+    rep = dict(dtype=dtype, b2_words=len(out), b2_within_20ms=float((d_b2 <= 0.0201).all(axis=1).mean()), b2_max_dt=float(d_b2.max()),
+               align_words=len(words), align_within_20ms=float((d_al <= 0.0201).all(axis=1).mean()), align_max_dt=float(d_al.max()))
+    os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(HERE), "gpurun_out", f"align_sharp_{dtype}.json"), "w") as f:
+        json.dump(rep, f)
+    assert rep["b2_within_20ms"] == 1.0 and rep["b2_max_dt"] <= 0.0201, rep
+    assert rep["align_within_20ms"] == 1.0 and rep["align_max_dt"] <= 0.0201, rep
+
+
 def test_transcribe_window_parallel_equals_per_clip():
     # batch_size mode == the sequential path run on each 30-s clip separately (SURVEY.md 8e oracle for the sharded mode)
     g = _golden()["tiny_en_t0_ss"]

@@ -223,7 +223,7 @@ def _report(name, payload):
 @pytest.mark.parametrize("beam", [None, 5])
 def test_lv3_dims_f16_decode_vs_f32_oracle(step, beam):
     # fp16 weights / activations (f32 accumulation, f32 LayerNorm statistics / softmax) against the f32 ORACLE on weights with
-    # a realistic logit gap.  Thresholds: tokens identical; |avg_logprob difference| < 2e-2; no_speech_prob within 5 %.
+    # a realistic logit gap.  Thresholds: tokens identical; |avg_logprob difference| <= 1e-3 (north star); no_speech_prob within 5 %.
     from stable_ts_amd import _lib
     lib = _lib.load()
     m, eng = _oracle(2, 9.0, 8.0), _engine("f16", 2, 9.0, 8.0)
@@ -252,17 +252,47 @@ def test_lv3_dims_f16_decode_vs_f32_oracle(step, beam):
     _report(f"decode[{step}][beam={beam}]", rep)
     for w in range(2):
         assert got[w][0] == refs[w].tokens, (w, got[w][0], refs[w].tokens)
-        assert abs(got[w][1] - refs[w].avg_logprob) < 2e-2
+        assert abs(got[w][1] - refs[w].avg_logprob) <= 1e-3       # north star (measured round 2: 1.8e-4)
         assert abs(got[w][2] - refs[w].no_speech_prob) < 1e-4 + 5e-2 * refs[w].no_speech_prob
 
 
+def _oracle_transcribe(audio, kw):
+    """the same transcribe() call with the f32 CPU oracle standing in for the device (tests/oracle_engine.py: the host code is
+    this package's, every number comes from the oracle) -- the oracle-side result the fp16 device run is held against"""
+    key = ("oracle_transcribe",)
+    if key not in _CACHE:
+        import pytest as _pt
+        from oracle_engine import CpuWhisper, install
+        mp = _pt.MonkeyPatch()
+        try:
+            install(mp)
+            _CACHE[key] = CpuWhisper(_oracle(2, 9.0, 8.0)).transcribe(audio.cpu(), **kw)
+        finally:
+            mp.undo()
+    return _CACHE[key]
+
+
+def _word_deltas(got, ref):
+    tok_same = [s.tokens == g.tokens for s, g in zip(got.segments, ref.segments)]
+    dw = []
+    if len(got.segments) == len(ref.segments) and all(tok_same):
+        for a, b in zip(got.all_words(), ref.all_words()):
+            dw.append((abs(a.start - b.start), abs(a.end - b.end), abs(a.probability - b.probability)))
+    dw = np.asarray(dw) if dw else np.zeros((0, 3))
+    return dict(segments=(len(got.segments), len(ref.segments)), token_identical_segments=int(sum(tok_same)),
+                words=len(ref.all_words()),
+                within_20ms=float(((dw[:, 0] <= 0.0201) & (dw[:, 1] <= 0.0201)).mean()) if len(dw) else None,
+                max_dt=float(dw[:, :2].max()) if len(dw) else None, max_dprob=float(dw[:, 2].max()) if len(dw) else None)
+
+
 @pytest.mark.parametrize("step", ["split-K step (gen 2)", "dec step (gen 3, forced)"])
-def test_lv3_dims_f16_transcribe_vs_f32_golden(step):
-    # transcribe() end to end in fp16 against the SAME call in the strict f32 mode (which is pinned to the oracle above and in
-    # test_gpu_model.py / test_gpu_golden.py): token agreement, word boundaries, probabilities.
-    # Thresholds: every window's tokens identical; >= 95 % of the words within +-20 ms at both ends (measured on MI355X:
-    # 40 of 41 words; the odd one sits on a flat stretch of the DTW cost surface where the f16 rounding of the attention
-    # scores moves the path by whole frames -- max deviation is reported, not bounded); word probabilities within 2e-2.
+def test_lv3_dims_f16_transcribe_vs_oracle(step):
+    # transcribe() end to end in fp16 (3 windows, beam 5, 40 tokens each, word timestamps) against (a) the SAME call with the
+    # f32 CPU ORACLE standing in for the device -- the parity bar proper -- and (b) the same call in this library's strict f32
+    # mode (pinned to the oracle in test_gpu_model.py / test_gpu_golden.py and above), kept as a second opinion.
+    # Bars: every window's tokens identical; on the default decode step (gen 3) EVERY word within +-20 ms at both ends with
+    # the maximum deviation asserted; on the superseded split-K step >= 95 % (measured round 2: 40 of 41).  Word
+    # probabilities saturate on these weights (p ~ 1): they are reported, the un-saturated comparison is the test below.
     import stable_ts_amd as sw
     from stable_ts_amd import _lib
     from bench import synth_audio
@@ -272,6 +302,7 @@ def test_lv3_dims_f16_transcribe_vs_f32_golden(step):
     kw = dict(language="de", temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
               beam_size=5, sample_len=40, min_tokens=40, word_timestamps=True, regroup=False, batch_size=3,
               max_instant_words=1.0, suppress_silence=False)
+    ref = _oracle_transcribe(audio, kw)
     gold = models["f32"].transcribe(audio, **kw)
     old = lib.swx_debug_flags(-1)
     lib.swx_debug_flags((old | 1024) if step.startswith("dec") else (old & ~(512 | 1024)))
@@ -279,18 +310,48 @@ def test_lv3_dims_f16_transcribe_vs_f32_golden(step):
         got = models["f16"].transcribe(audio, **kw)
     finally:
         lib.swx_debug_flags(old)
-    assert len(gold.segments) > 0 and len(gold.all_words()) >= 30
-    tok_same = [s.tokens == g.tokens for s, g in zip(got.segments, gold.segments)]
-    dw = []
-    if len(got.segments) == len(gold.segments) and all(tok_same):
-        for a, b in zip(got.all_words(), gold.all_words()):
-            dw.append((abs(a.start - b.start), abs(a.end - b.end), abs(a.probability - b.probability)))
-    dw = np.asarray(dw) if dw else np.zeros((0, 3))
-    rep = dict(segments=(len(got.segments), len(gold.segments)), token_identical_segments=int(sum(tok_same)),
-               words=len(gold.all_words()),
-               within_20ms=float(((dw[:, 0] <= 0.0201) & (dw[:, 1] <= 0.0201)).mean()) if len(dw) else None,
-               max_dt=float(dw[:, :2].max()) if len(dw) else None, max_dprob=float(dw[:, 2].max()) if len(dw) else None)
+    assert len(ref.segments) > 0 and len(ref.all_words()) >= 30
+    rep = dict(f16_vs_oracle=_word_deltas(got, ref), f16_vs_hip_f32=_word_deltas(got, gold), hip_f32_vs_oracle=_word_deltas(gold, ref))
     _report(f"transcribe[{step}]", rep)
-    assert len(got.segments) == len(gold.segments) and all(tok_same), rep
-    assert rep["within_20ms"] >= 0.95, rep
-    assert rep["max_dprob"] < 2e-2, rep
+    r = rep["f16_vs_oracle"]
+    assert r["segments"][0] == r["segments"][1] and r["token_identical_segments"] == r["segments"][1], rep
+    if step.startswith("dec"):
+        assert r["within_20ms"] == 1.0 and r["max_dt"] <= 0.0201, rep
+    else:
+        assert r["within_20ms"] >= 0.95, rep
+    assert rep["hip_f32_vs_oracle"]["within_20ms"] == 1.0, rep
+
+
+def test_lv3_dims_f16_score_probs_vs_oracle_unsaturated():
+    # token probabilities of the teacher-forced scoring pass where they are NOT saturated: random text tokens (p ~ 1e-7..1e-2)
+    # through swx_score in fp16 vs the f32 oracle's find_alignment (timing.py:41-67) -- |delta log p| and the DTW path.
+    m, eng = _oracle(2, 9.0, 8.0), _engine("f16", 2, 9.0, 8.0)
+    tok = get_tokenizer(True, num_languages=100, language="de", task="transcribe")
+    mels = _mel(61, B=2)
+    g = torch.Generator().manual_seed(5)
+    texts = [torch.randint(18, 50000, (n,), generator=g).tolist() for n in (100, 37)]
+    num_samples = [480000, 301234]
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    toks = [[*tok.sot_sequence, tok.no_timestamps, *t, tok.eot] for t in texts]
+    n_frames = [round(n / 320) for n in num_samples]
+    probs, neg, T = eng.score(xkv, toks, n_frames, n_sot=len(tok.sot_sequence), eot=tok.eot)
+    paths = eng.dtw(neg, [t + 1 for t in T], n_frames)
+    rep = []
+    for w in range(2):
+        _, cache = ost.find_alignment(m, tok, texts[w], mels[w], num_samples[w], return_cache=True)
+        p_ref = np.asarray(cache["text_token_probs"], dtype=np.float64)
+        p_got = np.asarray(probs[w], dtype=np.float64)[:len(p_ref)]
+        mid = (p_ref > 1e-7) & (p_ref < 0.99)
+        ri, rj = cache["dtw_path"]
+        ti, tj = paths[w]
+        jr = rj[np.pad(np.diff(ri), (1, 0), constant_values=1).astype(bool)]
+        jt = tj[np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)]
+        rep.append(dict(tokens=len(p_ref), unsaturated=int(mid.sum()), prob_range=(float(p_ref.min()), float(p_ref.max())),
+                        max_dlogp=float(np.abs(np.log(p_got[mid]) - np.log(p_ref[mid])).max()),
+                        dtw_path_identical=bool(ti.tolist() == ri.tolist() and tj.tolist() == rj.tolist()),
+                        max_jump_frame_diff=int(np.abs(jr - jt).max())))
+    _report("score_probs_unsaturated", rep)
+    for r in rep:
+        assert r["unsaturated"] >= r["tokens"] // 2, r
+        assert r["max_dlogp"] <= 2e-2, r             # 2 layers of fp16 storage: ~1e-3 relative per logit
+        assert r["max_jump_frame_diff"] <= 1, r      # token boundaries within one 20-ms frame of the oracle's
