@@ -201,8 +201,10 @@ int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_t *d_N, con
  *          4 cached self-attention 5 select/beam 6 mel 7 align-weights 8 dtw 9 layernorm
  * swx_prof_collect: out[cls*3+{0,1,2}] = {launches, total ms, total algorithmic work}; returns the class count */
 int swx_prof_enable(int on);
-/* run-time switches of the decode step (SWX_FLAG_* in csrc/swx_kernels.h; bit 0: run decode steps through the general
- * per-op path instead of the fused split-K step -- the A/B reference of the tests).  All switches are arithmetic-neutral.
+/* A/B switches for tests and scripts (SWX_FLAG_* in csrc/swx_kernels.h): 1 = decode steps and small passes through the general
+ * per-op path instead of the fused "dec" step (its reference), 2048 = decode cross-attention on the row-layout K / V^T
+ * (reference of the fragment-ordered copy), 8192 = memory-walking logit filters (reference of the register kernel),
+ * 16384 = decode loop without the captured step graph.  Default 0; nothing reads an environment variable.
  * flags < 0 only queries.  Returns the previous value. */
 int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);
@@ -210,13 +212,6 @@ int swx_prof_collect(double *out, int n_classes);
 /* ---- building blocks exported for the parity tests (same kernels the calls above launch) */
 int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
                   void *d_c, int64_t ldc, int M, int N, int K, int epilogue, int force_kernel, void *stream);
-/* the decode-step GEMM exactly as the fused step launches it (f16, M <= 128): split-K weight streaming into f32 slabs +
- * the finish kernel (bias / GELU / residual from d_res, optionally the LayerNorm of the finished row -> d_ln_out).
- * The slab scratch is allocated inside (test / micro-benchmark hook).  Mirrors `Linear` + the following `LayerNorm` of
- * upstream's ResidualAttentionBlock (whisper/model.py), i.e. one decoder projection of decode.py:33-65's step. */
-int swx_test_gemm_splitk(const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
-                         void *d_c, int64_t ldc, const float *d_ln_g, const float *d_ln_b, void *d_ln_out,
-                         int M, int N, int K, int epilogue, void *stream);
 /* decode-step "dec" GEMM (csrc/swx_decstep.hip), f16: epilogue bits 1 = LayerNorm fold (gamma / beta given, A = raw rows, K = full
  * row), 2 = GELU, 4 = residual update of d_x in place, 8 = QKV scatter (columns >= d go to the caches at pos0[m]), 16 = K-split
  * allowed.  d_scratch: >= N*K*2 + 8N + slab bytes + 1 KiB. */

@@ -1,10 +1,9 @@
 """Per-kernel micro-benchmarks at the bench workload's shapes (large-v3, 20 windows x beam 5) through libswx's test hooks.
 
-    python scripts/kernel_bench.py [--iters 200] [--only gemm|flash|cross|splitk]
+    python scripts/kernel_bench.py [--iters 200] [--only gemm|flash|cross|dec|dtw]
 
 One HIP-event pair brackets `iters` back-to-back launches of the same kernel, so the figure is the steady-state
 launch-to-launch time (kernel + one kernel boundary), which is what a dependent chain such as the decode step pays.
-Environment switches (SWX_FLAGS, SWX_PG_POLICY, SWX_PG_BLOCKS) apply as in the library.
 """
 import argparse
 import ctypes
@@ -45,7 +44,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--only", default="")
-    ap.add_argument("--gemm-kernel", type=int, default=1, help="force_kernel of the tiled GEMM: 1 register-staged, 5-7 direct-to-LDS variants, 8 / 9 = 64-column tiles always / never")
+    ap.add_argument("--gemm-kernel", type=int, default=7, help="force_kernel of the tiled GEMM: 1 register-staged, 7 direct-to-LDS (default dispatch), 8 / 9 = 64-column tiles always / never")
     args = ap.parse_args()
     from stable_ts_amd import _lib
     lib = _lib.load()
@@ -54,7 +53,7 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     rnd = lambda *s: (torch.randn(*s, device=dev) * 0.05).half()
-    print(f"SWX_FLAGS={lib.swx_debug_flags(-1)} SWX_PG_POLICY={os.environ.get('SWX_PG_POLICY')} SWX_PG_BLOCKS={os.environ.get('SWX_PG_BLOCKS')}")
+    print(f"debug flags = {lib.swx_debug_flags(-1)}")
 
     if args.only in ("", "gemm"):
         print(f"-- tiled MFMA GEMM (encoder / cross-KV / scoring shapes), f16, bias epilogue, force_kernel={args.gemm_kernel}")
@@ -85,7 +84,7 @@ def main():
         print(f"  {us:9.1f} us  {B * H * 64 * 2 * (2.0 * nk + 2.0 * nq) / us / 1e3:7.1f} GB/s algorithmic")
 
     if args.only in ("", "dec"):
-        print(f"-- decode-step GEMMs, third generation (un-split dec kernels), M=100  SWX_DEC_POLICY={os.environ.get('SWX_DEC_POLICY')}")
+        print("-- decode-step GEMMs (un-split dec kernels), M=100")
         M, d = 100, 1280
         tot = 0.0
         for name, N, K, epi in [("qkv (LN fold + scatter)", 3840, 1280, 1 | 8 | 32), ("attn-out (+x)", 1280, 1280, 4 | 32), ("cross-q (LN fold)", 1280, 1280, 1 | 32),
@@ -126,20 +125,6 @@ def main():
             us = timed(fn, 20)
             steps = Mc + (N + (N + 63) // 64 - 1) // ((N + 63) // 64) - 1
             print(f"  W={W:3d} N={N:4d} M={Mc}: {us:8.1f} us per launch   {1000.0 * us / (steps + N + Mc):7.1f} ns per dependent step (sweep {steps} + walk <= {N + Mc})")
-
-    if args.only in ("", "splitk"):
-        print("-- decode-step GEMMs (split-K weight streaming + finish), M=100")
-        M = 100
-        for name, N, K, epi, ln in [("qkv", 3840, 1280, EPI_BIAS, False), ("attn-out + LN", 1280, 1280, EPI_BIAS | EPI_RES, True),
-                                    ("cross-q", 1280, 1280, EPI_BIAS, False), ("mlp-1 (GELU)", 5120, 1280, EPI_BIAS | EPI_GELU, False),
-                                    ("mlp-2 + LN", 1280, 5120, EPI_BIAS | EPI_RES, True)]:
-            a, ws = rnd(M, K), weight_copies(rnd, N, K)
-            bias, lg, lb = torch.zeros(N, device=dev), torch.ones(N, device=dev), torch.zeros(N, device=dev)
-            c = torch.zeros(M, N, dtype=torch.half, device=dev)
-            h = torch.empty(M, N, dtype=torch.half, device=dev) if ln else None
-            us = timed(lambda i: lib.swx_test_gemm_splitk(p(a), K, p(ws[i % len(ws)]), p(bias), p(c) if epi & EPI_RES else None, p(c), N,
-                                                        p(lg) if ln else None, p(lb) if ln else None, p(h), M, N, K, epi, st), args.iters)
-            print(f"  {name:14s} N={N:5d} K={K:5d}: {us:7.2f} us per GEMM+finish  {2.0 * (N * K + M * K + M * N) / us / 1e3:7.1f} GB/s algorithmic")
 
 
 if __name__ == "__main__":

@@ -75,8 +75,6 @@ SYMBOLS = {
     "swx_prof_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
     "swx_test_gemm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                               c_int, c_int, c_int, c_void_p]),
-    "swx_test_gemm_splitk": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                     c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "swx_test_dec_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                   c_void_p]),

@@ -4,12 +4,10 @@
 // reached from stable_whisper/decode.py:40 (decoder steps), decode.py:27-30 (encoder) and timing.py:58-61 (the
 // teacher-forced pass whose cross-attention qk the word-timestamp code reads).
 //
-//   attn_flash_f16      MFMA flash attention, non-causal, for the MFMA-bound cases (encoder self-attention,
-//                       1500x1500 per head; cross-attention of the scoring pass).  One wave = 16 queries,
-//                       K tile [64 keys][64] and V^T tile [64][64 keys] staged in LDS per 4-wave workgroup.
-//                       S^T = K.Q^T is computed "swapped" so a lane's accumulator registers all belong to ONE query:
-//                       the online-softmax row statistics are lane-local + two shuffles, and the exponentiated tile is
-//                       already laid out as the B operand of O^T += V^T.P^T (no LDS round trip for P).
+//   attn_flash2_f16     MFMA flash attention, non-causal, for the MFMA-bound cases (encoder self-attention,
+//                       1500x1500 per head; cross-attention of the scoring pass).  One wave = 32 queries,
+//                       K tile [64 keys][64] and V^T tile [64][64 keys] double-buffered in LDS per 4-wave workgroup.
+//   attn_decode_cross   decode-step cross-attention: K / V^T streamed straight into MFMA operands (HBM-bound).
 //   attn_dense_rowwise  VALU kernel (any dtype): 8 queries that share one K/V (same window, same head) per workgroup;
 //                       K and V are streamed once per workgroup.  Used for the HBM-bound decode-step cross-attention
 //                       (the G beams of a window share the 246 MB/window cross-KV read) and for everything in the
@@ -22,8 +20,6 @@
 
 namespace {
 
-constexpr int SLAB_KMAX = 16;   // most split-K slabs a fused consumer (SlabRef) can finish; the launchers check ks2 <= SLAB_KMAX
-
 
 constexpr int DH = 64;
 
@@ -31,131 +27,10 @@ constexpr int DH = 64;
 constexpr int FL_KT = 64;            // keys per tile
 constexpr int FL_LD = 72;            // halfs per LDS row (144 B: keeps b128 / b64 fragment reads aligned)
 
-__global__ __launch_bounds__(256) void attn_flash_f16(AttnArgs a)
-{
-    __shared__ __attribute__((aligned(16))) f16 Ks[FL_KT][FL_LD];   // [key][d]
-    __shared__ __attribute__((aligned(16))) f16 Vt[DH][FL_LD];      // [d][key]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
-    const int qn = lane & 15, g = lane >> 4;
-    const f16 *Q = (const f16 *)a.q;
-    const f16 *K = (const f16 *)a.k;
-    const f16 *V = (const f16 *)a.v;
-
-    f16x8 qf[2];
-    {
-        const int qi = q0 + qn;
-        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qi < a.nq ? qi : 0)) * a.ldq + h * DH + g * 8;
-        qf[0] = (qi < a.nq) ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
-        qf[1] = (qi < a.nq) ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
-    }
-    f32x4 o[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -__builtin_inff(), l_run = 0.f;
-
-    for (int kt0 = 0; kt0 < a.nk; kt0 += FL_KT) {
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 256 * i, key = c >> 3, dc = (c & 7) * 8;
-            const int kg = kt0 + key;
-            // clamped addresses + select (no predicated loads: they become branches with early vmcnt(0) waits)
-            const int kgc = kg < a.nk ? kg : a.nk - 1;
-            f16x8 kv = *(const f16x8 *)(K + (size_t)b * a.k_bs + (size_t)kgc * a.ldkv + h * DH + dc), vv;
-            if (kg >= a.nk) kv = (f16x8)(f16)0;
-            *(f16x8 *)&Ks[key][dc] = kv;
-            if (a.vt_kp) {
-                // V already transposed in HBM ([H][64][kp], zero padded): chunk c -> d row c>>3, 8 keys at (c&7)*8
-                const int dr = c >> 3, kc = (c & 7) * 8;
-                vv = *(const f16x8 *)(V + (size_t)b * a.v_bs + ((size_t)h * DH + dr) * a.vt_kp + kt0 + kc);
-                *(f16x8 *)&Vt[dr][kc] = vv;
-            } else {
-                vv = *(const f16x8 *)(V + (size_t)b * a.v_bs + (size_t)kgc * a.ldkv + h * DH + dc);
-                if (kg >= a.nk) vv = (f16x8)(f16)0;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) Vt[dc + e][key] = vv[e];
-            }
-        }
-        __syncthreads();
-
-        // S^T tiles: s[t][r] = score(key = kt0 + t*16 + g*4 + r, query = q0 + qn)
-        f32x4 s[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const f16x8 kf = *(const f16x8 *)&Ks[t * 16 + qn][kk * 32 + g * 8];
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], s[t], 0, 0, 0);
-            }
-        }
-        float tmax = -__builtin_inff();
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt0 + t * 16 + g * 4 + r;
-                const float v = (key < a.nk) ? s[t][r] * 0.125f : -__builtin_inff();
-                s[t][r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);      // m_run = -inf on the first tile -> 0
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[t][r] - m_new);
-                s[t][r] = p;
-                psum += p;
-            }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { o[t][0] *= alpha; o[t][1] *= alpha; o[t][2] *= alpha; o[t][3] *= alpha; }
-
-        // O^T += V^T . P^T ; k-slot (g, j) of k-block c <-> key 32c + (j<4 ? g*4+j : 16 + g*4 + j-4)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            f16x8 pb;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { pb[r] = (f16)s[2 * c][r]; pb[4 + r] = (f16)s[2 * c + 1][r]; }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const f16x4 lo = *(const f16x4 *)&Vt[t * 16 + qn][32 * c + g * 4];
-                const f16x4 hi = *(const f16x4 *)&Vt[t * 16 + qn][32 * c + 16 + g * 4];
-                f16x8 va;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { va[e] = lo[e]; va[4 + e] = hi[e]; }
-                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb, o[t], 0, 0, 0);
-            }
-        }
-    }
-
-    const int qi = q0 + qn;
-    if (qi < a.nq) {
-        const float inv = 1.0f / l_run;
-        f16 *op = (f16 *)a.o + ((size_t)b * a.q_rows_per_batch + qi) * a.ldo + h * DH;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f16x4 ov;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[t][r] * inv);
-            *(f16x4 *)(op + t * 16 + g * 4) = ov;
-        }
-    }
-}
-
-// ================================================================================================ flash f16, gen 2
-// Same mathematics and MFMA operand arrangement as attn_flash_f16 above (swapped QK^T, lane-local softmax statistics, P feeds
-// PV from registers); what changes is the data movement, which bounded the first kernel at 0.10 of the MFMA peak:
+// ================================================================================================ flash f16 (generation 2)
+// Swapped QK^T (S^T = K.Q^T), so a lane's accumulator registers all belong to ONE query: the online-softmax row statistics are
+// lane-local + two shuffles and the exponentiated tile is already laid out as the B operand of O^T += V^T.P^T (no LDS round
+// trip for P).  Against the first kernel (16 queries per wave, single-buffered tiles: 0.10 of the MFMA peak, deleted in round 3):
 //   * a wave owns 32 queries (two 16-query blocks): every K / V^T fragment read from LDS feeds two MFMAs, and a workgroup
 //     covers 128 queries per barrier instead of 64;
 //   * K / V^T tiles are double-buffered in LDS, the global loads of tile t+1 are issued into registers BEFORE the MFMAs of
@@ -359,7 +234,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const f16 *__restrict_
 // PACKED: K and V^T come from the fragment-ordered copy (swx_xkv_pack): every MFMA operand fragment of a 32-key block is one
 // contiguous 1 KB piece, so a wave instruction reads 8 full 128-byte lines instead of 16 separate 64-byte row pieces (the
 // per-CU address path, not HBM, bounds the row-layout variant at ~4.2 TB/s: same finding as for the decode GEMM weights).
-template <bool QSLAB, bool PIPE, bool PACKED = false>
+template <bool PACKED>
 __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 {
     __shared__ float sm_m[4][16], sm_l[4][16];
@@ -383,9 +258,6 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     // A-row i of S^T tile t  <->  key k0 + (i>>2)*8 + (i&3) + 4t, so that lane (q, g) owns keys k0 + g*8 + 0..7
     const int krow = (qn >> 2) * 8 + (qn & 3);
 
-    // Key blocks are double-buffered in registers by hand: the K / V^T fragments of this wave's NEXT block are requested
-    // before the current block's MFMAs and softmax, so 16 KB per wave stay in flight and the loop never drains to
-    // vmcnt(0) (the plain loop compiled to load -> wait -> compute per block: two exposed round trips per 32 keys).
     const int64_t per_head = swx_xkv_packed_elems_per_head(a.nk);
     const f16 *Kpk = PACKED ? (const f16 *)a.kv_packed + (size_t)b * a.k_bs + (size_t)h * per_head + lane * 8 : nullptr;
     const f16 *Vpk = PACKED ? Kpk + per_head / 2 : nullptr;
@@ -414,35 +286,7 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     load_blk(wave, kA, vA);
 
     f16x8 qf[2];
-    if constexpr (QSLAB) {
-        // q of this (window, head) is finished here from the split-K partials of the query projection: wave 0 sums the
-        // slabs (same summation order and f16 rounding as splitk_finish_f16 -> bit-identical to the separate finish
-        // launch), parks the 16 x 64 tile in LDS, and every wave picks its MFMA fragments from there.
-        __shared__ __attribute__((aligned(16))) f16 qsh[16][DH + 8];
-        {
-            const SlabRef sr = a.qs;
-            const int row = tid >> 4, c0 = (tid & 15) * 4;          // 16 rows x 16 float4 columns = the 256 lanes
-            const bool rok = q_base + row < a.nq;
-            const float *sp = sr.slabs + ((size_t)b * a.q_rows_per_batch + (rok ? q_base + row : 0)) * sr.N + h * DH + c0;
-            // every slab load is issued before the first add (a rolled loop compiles to one round trip PER slab);
-            // slots past ks2 re-read the last slab (clamped, never predicated) and are skipped in the sum
-            f32x4 part[SLAB_KMAX];
-#pragma unroll
-            for (int k = 0; k < SLAB_KMAX; ++k) part[k] = *(const f32x4 *)(sp + (size_t)(k < sr.ks2 ? k : sr.ks2 - 1) * sr.stride);
-            const f32x4 bias = *(const f32x4 *)(sr.bias + h * DH + c0);
-            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int k = 0; k < SLAB_KMAX; ++k) if (k < sr.ks2) acc += part[k];
-            acc += bias;
-            f16x4 q4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) q4[e] = rok ? (f16)acc[e] : (f16)0;
-            *(f16x4 *)&qsh[row][c0] = q4;
-        }
-        __syncthreads();
-        qf[0] = *(const f16x8 *)&qsh[qn][g * 8];
-        qf[1] = *(const f16x8 *)&qsh[qn][32 + g * 8];
-    } else {
+    {
         const bool qok = q_base + qn < a.nq;
         const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qok ? q_base + qn : 0)) * a.ldq + h * DH + g * 8;
         qf[0] = qok ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
@@ -492,20 +336,7 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
             o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t], pb, o[t], 0, 0, 0);
         }
     };
-    if constexpr (PIPE) {
-        // straight-line pair body (no exit between the two halves, or the optimizer sinks the prefetch below the first
-        // compute).  The second block of the last pair may lie past nblk: its keys are all masked, which leaves
-        // (m_run, l_run, o) unchanged exactly (alpha = 1, p = 0), so the result is bit-identical to the plain loop.
-        f16x8 kB[4], vB[4];
-        for (int cb = wave; cb < nblk; cb += 8) {           // nblk >= 4: every wave owns at least one block
-            load_blk(cb + 4, kB, vB);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_blk(cb, kA, vA);
-            load_blk(cb + 8, kA, vA);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_blk(cb + 4, kB, vB);
-        }
-    } else {
+    {
         compute_blk(wave, kA, vA);                           // nblk >= 4: every wave owns at least one block
 #pragma unroll 2
         for (int cb = wave + 4; cb < nblk; cb += 4) {
@@ -711,21 +542,18 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
     }
 }
 
-// ------------------------------------------------------------------------------------------ fused decode step
-// One wave per (row, head) of a single-token decode step, f16.  Replaces THREE launches of the generic path (split-K
-// finish of the QKV projection, kv_append, self_attn_cached): the wave finishes its own 3 x 64 columns from the f32
-// partial slabs (same summation order / f16 rounding as splitk_finish_f16), appends the new K/V to the cache, and attends.
-// The dependent-load chain is 3 round trips instead of 5: {pos0} -> {ancestor ids, slabs} -> {K rows, V fragments} ->
-// math; the V fragments of the first 128 positions are requested together with the K rows (ancestor ids travel between
-// lanes by ds_bpermute).  Arithmetic order is the generic kernel's, so both paths agree bit for bit.
-// SLABS = true : q | k | v of the new token are finished here from the split-K partials (second-generation decode step)
-// SLABS = false: q is read from a.qkv (f16, row stride ldqkv) and the new token's K / V are ALREADY in the cache at position
-//                pos0[r] of row r (the QKV projection of the third-generation step scatters them in its epilogue)
-template <bool SLABS>
-__global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
+// ------------------------------------------------------------------------------------------ decode-step self-attention
+// One wave per (row, head) of a single-token decode step, f16: q comes from the QKV projection's output (a.qkv, row stride
+// ldqkv), the new token's K / V are ALREADY in the cache at position pos0[r] of row r (the projection's epilogue scattered
+// them).  The dependent-load chain is 3 round trips: {pos0} -> {ancestor ids} -> {K rows, V fragments} -> math; the V
+// fragments of the first 128 positions are requested together with the K rows (ancestor ids travel between lanes by
+// shuffles).  Arithmetic order is self_attn_cached's, so both paths agree bit for bit.
+// HBM traffic: K and V of every cached position of every row once = R * (pos + 1) * d * 2 * 2 bytes per launch (57 MB at
+// position 111 for 100 rows of large-v3: at the end of a window's decode this kernel is bandwidth-, not latency-bound).
+__global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
 {
     constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
-    __shared__ float qs[DH], kn[DH], vn[DH];
+    __shared__ float qs[DH];
     __shared__ float ps[512];
     const int lane = threadIdx.x, h = blockIdx.x, r = blockIdx.y;
     const int d = a.d;
@@ -733,44 +561,20 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     const int32_t *anc = a.anc ? a.anc + (size_t)r * a.n_ctx : nullptr;
     const f16 *kc = (const f16 *)a.kcache, *vc = (const f16 *)a.vcache;
     const int j0 = lane, j1 = lane + 64;
-    // positions that live in the cache: strictly older ones, plus the new one itself when the projection already put it there
-    const bool has0 = SLABS ? j0 < pos : j0 <= pos, has1 = SLABS ? j1 < pos : j1 <= pos;
+    const bool has0 = j0 <= pos, has1 = j1 <= pos;         // positions that live in the cache (the new one included)
     // ancestor ids: clamped unconditional loads + select (a predicated load would cost its own round trip)
     const int32_t *ap = anc ? anc : a.pos0;
     const bool old0 = j0 < pos, old1 = j1 < pos;           // the ancestor table covers the older positions; the new one is row r's own
     const int t0 = ap[(anc && old0) ? j0 : 0], t1 = ap[(anc && old1) ? j1 : 0];
     const int pr0 = (anc && old0) ? t0 : r, pr1 = (anc && old1) ? t1 : r;
-    // ---- finish q | k | v of this head from the split-K partials
-    if constexpr (!SLABS) {
-        qs[lane] = (float)((const f16 *)a.qkv)[(size_t)r * a.ldqkv + h * DH + lane];
-    } else {
-        const SlabRef sr = a.qkvs;
-        const float *sp = sr.slabs + (size_t)r * sr.N + h * DH + lane;
-        // all 3 x ks2 partial loads in flight before the first add (see attn_decode_cross_f16)
-        float pq[SLAB_KMAX], pk[SLAB_KMAX], pv[SLAB_KMAX];
-#pragma unroll
-        for (int s = 0; s < SLAB_KMAX; ++s) {
-            const float *p = sp + (size_t)(s < sr.ks2 ? s : sr.ks2 - 1) * sr.stride;
-            pq[s] = p[0]; pk[s] = p[d]; pv[s] = p[2 * d];
-        }
-        const float bq = sr.bias[h * DH + lane], bk = sr.bias[d + h * DH + lane], bv = sr.bias[2 * d + h * DH + lane];
-        float q = 0.f, k = 0.f, v = 0.f;
-#pragma unroll
-        for (int s = 0; s < SLAB_KMAX; ++s) if (s < sr.ks2) { q += pq[s]; k += pk[s]; v += pv[s]; }
-        q += bq; k += bk; v += bv;
-        const f16 qh = (f16)q, kh = (f16)k, vh = (f16)v;
-        const size_t at = ((size_t)r * a.n_ctx + pos) * d + h * DH + lane;
-        ((f16 *)a.kcache)[at] = kh;
-        ((f16 *)a.vcache)[at] = vh;
-        qs[lane] = (float)qh; kn[lane] = (float)kh; vn[lane] = (float)vh;
-    }
+    qs[lane] = (float)((const f16 *)a.qkv)[(size_t)r * a.ldqkv + h * DH + lane];
     // ---- K rows of positions lane, lane + 64 and the V fragments of positions < 128: one batch of loads
     f16x8 k0[8], k1[8];
     {
         const f16 *kr0 = kc + ((size_t)(has0 ? pr0 : r) * a.n_ctx + (has0 ? j0 : 0)) * d + h * DH;   // clamped, never predicated
 #pragma unroll
         for (int e = 0; e < 8; ++e) k0[e] = *(const f16x8 *)(kr0 + 8 * e);
-        if (SLABS ? pos > 64 : pos >= 64) {
+        if (pos >= 64) {
             const f16 *kr1 = kc + ((size_t)(has1 ? pr1 : r) * a.n_ctx + (has1 ? j1 : 0)) * d + h * DH;
 #pragma unroll
             for (int e = 0; e < 8; ++e) k1[e] = *(const f16x8 *)(kr1 + 8 * e);
@@ -780,17 +584,17 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     f16x8 vpre[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
-        if (SLABS ? i * 8 < pos : i * 8 <= pos) {           // uniform: some key of this group of 8 is in the cache
+        if (i * 8 <= pos) {                                  // uniform: some key of this group of 8 is in the cache
             const int j = kg + 8 * i;
             const int src = j & 63;
             const int pa = __shfl(pr0, src, 64), pb = __shfl(pr1, src, 64);
             const int prj = j < 64 ? pa : pb;                       // (pr0 / pr1 are r for the new position)
-            const bool ok = SLABS ? j < pos : j <= pos;
+            const bool ok = j <= pos;
             vpre[i] = *(const f16x8 *)(vc + ((size_t)(ok ? prj : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
         }
     }
-    __syncthreads();                                        // qs / kn / vn visible
-    // ---- scores (each lane owns whole keys; the new key comes from LDS)
+    __syncthreads();                                        // qs visible
+    // ---- scores (each lane owns whole keys)
     auto dot_regs = [&](const f16x8 *kk) {
         float acc = 0.f;
 #pragma unroll
@@ -799,35 +603,25 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
             for (int e = 0; e < 8; ++e) acc = fmaf(qs[c * 8 + e], (float)kk[c][e], acc);
         return acc;
     };
-    auto dot_new = [&]() {
-        float acc = 0.f;
-        for (int e = 0; e < DH; ++e) acc = fmaf(qs[e], kn[e], acc);
-        return acc;
-    };
     float mx = -__builtin_inff();
     if (j0 <= pos) {
-        const float sc = (has0 ? dot_regs(k0) : dot_new()) * 0.125f;
+        const float sc = dot_regs(k0) * 0.125f;
         ps[j0] = sc; mx = fmaxf(mx, sc);
     }
     if (pos >= 64 && j1 <= pos) {
-        const float sc = (has1 ? dot_regs(k1) : dot_new()) * 0.125f;
+        const float sc = dot_regs(k1) * 0.125f;
         ps[j1] = sc; mx = fmaxf(mx, sc);
     }
     for (int j = lane + 128; j <= pos; j += 64) {
-        float acc;
-        if (!SLABS || j < pos) {
-            const int pr = (anc && j < pos) ? anc[j] : r;
-            const f16 *kr = kc + ((size_t)pr * a.n_ctx + j) * d + h * DH;
-            acc = 0.f;
+        const int pr = (anc && j < pos) ? anc[j] : r;
+        const f16 *kr = kc + ((size_t)pr * a.n_ctx + j) * d + h * DH;
+        float acc = 0.f;
 #pragma unroll 2
-            for (int d0 = 0; d0 < DH; d0 += 8) {
-                float kv[8];
-                load8<f16>(kr + d0, kv);
+        for (int d0 = 0; d0 < DH; d0 += 8) {
+            float kv[8];
+            load8<f16>(kr + d0, kv);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(qs[d0 + e], kv[e], acc);
-            }
-        } else {
-            acc = dot_new();
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[d0 + e], kv[e], acc);
         }
         acc *= 0.125f;
         ps[j] = acc; mx = fmaxf(mx, acc);
@@ -846,28 +640,15 @@ __global__ __launch_bounds__(64) void self_attn_fused_f16(SelfAttnArgs a)
     for (int i = 0; i < PF; ++i) {
         const int j = kg + 8 * i;
         if (i * 8 <= pos && j <= pos) {
-            float vv[8];
-            if (!SLABS || j < pos) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] = (float)vpre[i][e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vv[e] = vn[dc + e];
-            }
             const float pj = ps[j] * inv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vv[e], acc[e]);
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vpre[i][e], acc[e]);
         }
     }
     for (int j = kg + 8 * PF; j <= pos; j += 8) {
         float vv[8];
-        if (!SLABS || j < pos) {
-            const int pr = (anc && j < pos) ? anc[j] : r;
-            load8<f16>(vc + ((size_t)pr * a.n_ctx + j) * d + h * DH + dc, vv);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) vv[e] = vn[dc + e];
-        }
+        const int pr = (anc && j < pos) ? anc[j] : r;
+        load8<f16>(vc + ((size_t)pr * a.n_ctx + j) * d + h * DH + dc, vv);
         const float pj = ps[j] * inv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vv[e], acc[e]);
@@ -962,33 +743,23 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     // the decode kernel also takes a SMALL multi-row pass (align(): one window of ~100 rows) as groups of 16 rows, when the
     // fragment-ordered K / V^T copy exists and the flash grid would be tiny
     const int ngrp = cdiv(a.nq, 16);
-    const bool small_pass = a.nq > 16 && a.nq <= 160 && a.kv_packed && !a.qs.slabs && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV) &&
+    const bool small_pass = a.nq > 16 && a.nq <= 160 && a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV) &&
                             (int64_t)a.B * a.H * ngrp <= 1024 && force_kernel == 0;
     const bool dec = (dtype == SWX_F16) && a.vt_kp > 0 && (a.nq <= 16 || small_pass) && a.nk >= 128 && (force_kernel == 3 || force_kernel == 0);
     if (force_kernel == 3 && !dec) return -5;
-    if (a.qs.slabs && !dec) return -5;         // only the decode kernel finishes q from slabs
     if (dec) {
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
-        const bool qsl = a.qs.slabs != nullptr, pipe = (swx_flags() & SWX_FLAG_XATTN_PIPE) != 0;
-        if (qsl && (a.qs.N % 4 != 0 || !a.qs.bias || a.qs.ks2 < 1 || a.qs.ks2 > SLAB_KMAX)) return -5;
         dim3 gd(a.H, a.B, a.nq <= 16 ? 1 : ngrp);
-#define SWX_XA(QS_, PP_) hipLaunchKernelGGL((attn_decode_cross_f16<QS_, PP_>), gd, dim3(256), 0, s, a)
-        if (a.kv_packed && !qsl && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV))
-            hipLaunchKernelGGL((attn_decode_cross_f16<false, false, true>), gd, dim3(256), 0, s, a);
-        else if (pipe) { if (qsl) SWX_XA(true, true); else SWX_XA(false, true); }
-        else { if (qsl) SWX_XA(true, false); else SWX_XA(false, false); }
-#undef SWX_XA
+        if (a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV))
+            hipLaunchKernelGGL(attn_decode_cross_f16<true>, gd, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(attn_decode_cross_f16<false>, gd, dim3(256), 0, s, a);      // row-layout K / V^T: the reference
     } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
-        if (swx_flags() & SWX_FLAG_FLASH_V1) {
-            dim3 g(cdiv(a.nq, 64), a.H, a.B);
-            hipLaunchKernelGGL(attn_flash_f16, g, dim3(256), 0, s, a);
-        } else {
-            dim3 g(cdiv(a.nq, 128), a.H, a.B);
-            if (a.vt_kp) hipLaunchKernelGGL(attn_flash2_f16<true>, g, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(attn_flash2_f16<false>, g, dim3(256), 0, s, a);
-        }
+        dim3 g(cdiv(a.nq, 128), a.H, a.B);
+        if (a.vt_kp) hipLaunchKernelGGL(attn_flash2_f16<true>, g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(attn_flash2_f16<false>, g, dim3(256), 0, s, a);
     } else {
         // algorithmic bytes: K and V of every (window, head) once + q in + o out
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
@@ -1041,17 +812,13 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
 {
     if (a.R <= 0 || a.n_new <= 0) return 0;
     if (a.n_ctx > 512) return -5;
-    SwxProfScope prof(PC_SELF_ATTN, 0.0, s);
-    if (a.qkvs.slabs) {
-        if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.qkvs.bias || a.qkvs.N != 3 * a.d || a.qkvs.ks2 < 1 ||
-            a.qkvs.ks2 > SLAB_KMAX) return -5;
-        hipLaunchKernelGGL(self_attn_fused_f16<true>, dim3(a.H, a.R), dim3(64), 0, s, a);
-        SWX_CHECK_LAUNCH();
-        return 0;
-    }
+    // algorithmic bytes: K and V of every cached position of every row once (+ q in, o out); the positions are device state --
+    // the decode loop passes the one it knows (step_pos), multi-token passes attend to n_new positions on average n_new / 2 + 1
+    const double npos = a.step_pos > 0 ? a.step_pos + 1 : (a.n_new + 1) * 0.5;
+    SwxProfScope prof(PC_SELF_ATTN, (double)a.R * a.n_new * a.d * (dtype == SWX_F16 ? 2 : 4) * (2.0 * npos + 2.0), s);
     if (a.step_cached) {       // single-token step, q in a.qkv, the new K / V already in the cache
         if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.skip_append) return -5;
-        hipLaunchKernelGGL(self_attn_fused_f16<false>, dim3(a.H, a.R), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(self_attn_step_f16, dim3(a.H, a.R), dim3(64), 0, s, a);
         SWX_CHECK_LAUNCH();
         return 0;
     }

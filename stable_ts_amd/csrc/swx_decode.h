@@ -15,6 +15,8 @@ struct DecodeBufs {
     int32_t *row_done;         // [M]
     int32_t *win_done, *win_done_prev;   // [W]
     int32_t *n_done;           // [1]
+    int32_t *step_dev;         // [1] number of tokens sampled so far: read by the selection kernels, advanced by the step-finish
+                               //     kernel -- the step index is device state so that a captured step graph can be replayed
     int32_t *fin_tokens;       // [W][fin_cap][TS]
     float *fin_score;          // [W][fin_cap]
     int32_t *fin_len;          // [W][fin_cap]
@@ -29,6 +31,6 @@ struct DecodeBufs {
 
 int swx_decode_init(const DecodeBufs &b, const int32_t *init_tokens, hipStream_t s);
 int swx_decode_after_prefill(const DecodeBufs &b, const float *lg2, float *nospeech, hipStream_t s);
-int swx_decode_select(const DecodeBufs &b, int step, int cur, hipStream_t s);
+int swx_decode_select(const DecodeBufs &b, int cur, hipStream_t s);
 int swx_decode_finalize(const DecodeBufs &b, int cur, int n_steps, int32_t *tokens_out, int32_t *lens_out,
                         float *sumlp_out, int G_out, hipStream_t s);

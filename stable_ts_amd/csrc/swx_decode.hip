@@ -101,7 +101,7 @@ __global__ void decode_init_kernel(DecodeBufs b, const int32_t *__restrict__ ini
         b.sum_lp[r] = 0.f;
         b.row_done[r] = 0;
         if (r % b.G == 0) { b.win_done[w] = 0; b.fin_count[w] = 0; }
-        if (r == 0) *b.n_done = 0;
+        if (r == 0) { *b.n_done = 0; *b.step_dev = 0; }
     }
 }
 
@@ -144,8 +144,9 @@ __global__ __launch_bounds__(SEL_T) void decode_prefill_logits_kernel(DecodeBufs
 
 // -------------------------------------------------------------------------------------------- filter + select
 // grid (M).  step = number of tokens sampled so far (== tokens.shape[1] - sample_begin upstream).
-__global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int step, int cur)
+__global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int cur)
 {
+    const int step = *b.step_dev;
     __shared__ float shf[SEL_T / 64];
     __shared__ ArgMax sha[SEL_T / 64];
     __shared__ int sh_last_ts;
@@ -275,8 +276,9 @@ __global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int 
 // register array cannot be indexed by a run-time token id; nothing reads the row after this kernel (the next step's logits
 // GEMM rewrites it), so the filtered values are not written back.
 template <int NV>
-__global__ __launch_bounds__(SEL_T) void decode_select_reg_kernel(DecodeBufs b, int step, int cur)
+__global__ __launch_bounds__(SEL_T) void decode_select_reg_kernel(DecodeBufs b, int cur)
 {
+    const int step = *b.step_dev;
     __shared__ float shf[SEL_T / 64];
     __shared__ ArgMax sha[SEL_T / 64];
     __shared__ float sh_rot[SEL_T];
@@ -426,8 +428,9 @@ __global__ __launch_bounds__(SEL_T) void decode_select_reg_kernel(DecodeBufs b, 
 
 // ---------------------------------------------------------------------------------------------- beam update
 // grid (W), 256 threads.  cur = token/ancestor buffer holding the current beams; the new beams go to cur^1.
-__global__ __launch_bounds__(256) void decode_beam_update_kernel(DecodeBufs b, int step, int cur)
+__global__ __launch_bounds__(256) void decode_beam_update_kernel(DecodeBufs b, int cur)
 {
+    const int step = *b.step_dev;
     constexpr int MAXC = 17 * 16;
     __shared__ float sc[MAXC];
     __shared__ short src[MAXC];
@@ -527,6 +530,7 @@ __global__ void decode_step_finish_kernel(DecodeBufs b)
         nd += b.win_done[w] ? 1 : 0;
     }
     *b.n_done = nd;
+    *b.step_dev += 1;
 }
 
 // ------------------------------------------------------------------------------------------------ finalize
@@ -613,16 +617,16 @@ int swx_decode_after_prefill(const DecodeBufs &b, const float *lg2, float *nospe
     SWX_CHECK_LAUNCH();
     return 0;
 }
-int swx_decode_select(const DecodeBufs &b, int step, int cur, hipStream_t s)
+int swx_decode_select(const DecodeBufs &b, int cur, hipStream_t s)
 {
     SwxProfScope prof(PC_SELECT, (double)b.M * b.V * 4.0, s);
     const bool mem_kernel = swx_flags() & SWX_FLAG_SELECT_MEM;       // A/B and bit-identity reference of the register kernel
     if (!mem_kernel && b.V <= 51 * SEL_T)
-        hipLaunchKernelGGL(decode_select_reg_kernel<51>, dim3(b.M), dim3(SEL_T), 0, s, b, step, cur);
+        hipLaunchKernelGGL(decode_select_reg_kernel<51>, dim3(b.M), dim3(SEL_T), 0, s, b, cur);
     else
-        hipLaunchKernelGGL(decode_select_kernel, dim3(b.M), dim3(SEL_T), 0, s, b, step, cur);
+        hipLaunchKernelGGL(decode_select_kernel, dim3(b.M), dim3(SEL_T), 0, s, b, cur);
     if (b.cfg.beam) {
-        hipLaunchKernelGGL(decode_beam_update_kernel, dim3(b.W), dim3(256), 0, s, b, step, cur);
+        hipLaunchKernelGGL(decode_beam_update_kernel, dim3(b.W), dim3(256), 0, s, b, cur);
         hipLaunchKernelGGL(decode_beam_commit_kernel, dim3(cdiv(b.M, 256)), dim3(256), 0, s, b);
     }
     hipLaunchKernelGGL(decode_step_finish_kernel, dim3(1), dim3(64), 0, s, b);

@@ -61,8 +61,7 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     // ---- block id -> (column panel, K slice, row group): all row groups of one (panel, slice) unit share an XCD
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    int unit = (slot / g.n_rg) * 8 + xcd, rg = slot % g.n_rg;
-    if (g.abl & 32) { unit = b / g.n_rg; rg = b % g.n_rg; }        // experiment: row groups of a panel spread over the XCDs
+    const int unit = (slot / g.n_rg) * 8 + xcd, rg = slot % g.n_rg;
     const int panels = (g.N + 63) >> 6;
     if (unit >= panels * g.ks2) return;
     const int panel = unit / g.ks2, ks_id = unit - panel * g.ks2;
@@ -292,22 +291,6 @@ __global__ __launch_bounds__(256) void fold_pack_kernel(const f16 *__restrict__ 
     }
 }
 
-// SWX_DEC_POLICY="NxK=MT:ks2,NxK=MT:ks2,..." pins the tiling of given shapes (experiments)
-bool dec_policy(int N, int K, int *mt, int *ks2)
-{
-    static const char *env = getenv("SWX_DEC_POLICY");
-    const char *e = env;
-    while (e && *e) {
-        int n = 0, k = 0, a = 0, c = 0, used = 0;
-        if (sscanf(e, "%dx%d=%d:%d%n", &n, &k, &a, &c, &used) == 4 && used > 0) {
-            if (n == N && k == K) { *mt = a; *ks2 = c; return true; }
-            e += used;
-        } else break;
-        if (*e == ',') ++e;
-    }
-    return false;
-}
-
 }  // namespace
 
 int swx_dec_plan(int M, int N, int K, int epi, int *mt_out, int *ks2_out)
@@ -324,9 +307,6 @@ int swx_dec_plan(int M, int N, int K, int epi, int *mt_out, int *ks2_out)
     // rows per workgroup: the smallest MT whose grid fits one round of 256 workgroups, within 120 KB of LDS
     int mt = 1;
     while (mt < DEC_MAXMT && (int64_t)(mt + 1) * 16 * kslice * 2 <= 122880 && panels * ks2 * cdiv(M, mt * 16) > 256) ++mt;
-    int pm = 0, pk = 0;
-    if (dec_policy(N, K, &pm, &pk) && pm >= 1 && pm <= DEC_MAXMT && pk >= 1 && K % pk == 0 && depth_ok(K / pk) &&
-        (int64_t)pm * 16 * (K / pk) * 2 <= 122880 && (pk == 1 || (epi & DEC_SLAB))) { mt = pm; ks2 = pk; }
     *mt_out = mt; *ks2_out = ks2;
     return 0;
 }
@@ -348,8 +328,6 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     if (ks2 == 1 && (g.epi & DEC_SLAB)) g.epi &= ~DEC_SLAB;      // un-split after all: the kernel finishes the output itself
     g.ks2 = ks2; g.kslice = g.K / ks2; g.n_rg = cdiv(g.M, mt * 16);
     g.slab_stride = (int64_t)g.M * g.N;
-    static const int abl = [] { const char *e = getenv("SWX_DEC_ABL"); return e ? atoi(e) : 0; }();
-    g.abl = abl;
     const int nks = g.kslice / 32;
     const int units = (g.N / 64) * ks2;
     const int grid = cdiv(units, 8) * g.n_rg * 8;

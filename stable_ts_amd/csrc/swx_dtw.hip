@@ -6,21 +6,12 @@
 // to a correctly rounded f32 add for every pair of f32 inputs (the f64 sum is exact when the exponents
 // are within 29 bits, and otherwise both roundings return the larger operand), so the kernel adds in f32.
 //
-// The problem is bound by its serial depth (M + ceil(N/R) - 1 dependent steps), not by bandwidth:
-// the cost matrix is <= 2.7 MB.  What round 1's kernel paid per step was memory latency -- a global load of x per lane with
-// nothing prefetched (the skewed front touches 64 different cache lines per step) and a global trace store: 0.83 us per
-// step.  This generation is the LDS wavefront scan the north star names:
-//   * one workgroup (4 waves) per window.  Wave 0 sweeps the skewed anti-diagonal front: lane l owns R consecutive token
-//     rows and computes column j = t - l at step t; the only cross-lane traffic is one shuffle per step (the bottom cell of
-//     the lane above).
-//   * waves 1-3 stream x from HBM/L2 in 16-step chunks with coalesced row segments (64 contiguous bytes per row and chunk)
-//     and park it in an LDS ring ALREADY SKEWED: slot s of lane l holds x[l*R .. l*R+R-1][s - l], so the sweep reads one
-//     aligned R-float record per step at a lane stride chosen to be bank-conflict free, one step ahead of its use.
-//     Loads for chunk k+2 are in flight while the sweep runs chunk k; one workgroup barrier per 16 steps.
-//   * the 2-bit moves of a lane's R rows for one column are packed into one byte (R <= 4, i.e. N <= 256 tokens -- every
-//     transcribe() / align() window) and kept in LDS, lane-major ([lane][column]); the backtrace walks it from LDS in
-//     8-column words (one LDS read per 8 columns or lane change instead of one dependent memory load per path step).
-//     Longer token axes (R = 5..7, N <= 448) keep the trace in global memory in the same lane-major layout.
+// The problem is bound by its serial depth (M + N - 1 dependent anti-diagonal steps), not by bandwidth:
+// the cost matrix is <= 2.7 MB.  Round 1's kernel paid memory latency per step (0.83 us: a global x load per lane, a global
+// trace store); round 2's first LDS wavefront scan (one sweeping wave + three loader waves, x skewed into an LDS ring,
+// trace in LDS: 607 us at 226 x 1500) was bounded by ONE wave executing the whole front -- ~75 VALU operations per step for
+// 4 rows per lane -- and by a backtrace of one scalar iteration per path element.  Both were deleted in round 3; what
+// remains is the third generation below (264 us).
 #include <type_traits>
 #include <cstdlib>
 #include "swx_common.h"
@@ -28,187 +19,12 @@
 
 namespace {
 
-// DTW_CH steps per chunk (one barrier per chunk); ring slots = 2 chunks: the chunk being swept + the chunk being written
-__host__ __device__ constexpr int dtw_lane_stride(int R, int RING)      // dwords between two lanes' rings; see the bank notes above
-{
-    return RING * R + (R == 4 ? 4 : (R == 2 ? 2 : 1));
-}
-
-template <int R, bool TLDS, int DTW_CH>
-__global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ x_all, int ld_n, int ld_m,
-                                                      const int *__restrict__ Nw, const int *__restrict__ Mw,
-                                                      int *__restrict__ text_idx, int *__restrict__ time_idx,
-                                                      int *__restrict__ out_len, unsigned char *__restrict__ ws_all,
-                                                      size_t ws_stride, int TP, int abl)
-{
-    constexpr int DTW_RING = 2 * DTW_CH;
-    typedef typename std::conditional<(R <= 4), unsigned char, unsigned short>::type TT;    // one column's moves of a lane
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int LS = dtw_lane_stride(R, DTW_RING);
-    float *xs = (float *)smem;                                   // [64][LS]: slot s of lane l at l*LS + (s % RING)*R + r
-    TT *tr_lds = (TT *)(smem + (size_t)64 * LS * 4);             // [64][TP] (TLDS only)
-    const int w = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = Nw[w], M = Mw[w];
-    const int cap = ld_n + ld_m;
-    const float *__restrict__ x = x_all + (size_t)w * ld_n * ld_m;
-    unsigned char *wsw = ws_all + (size_t)w * ws_stride;
-    TT *tr = TLDS ? tr_lds : (TT *)wsw;                          // trace plane, lane-major, pitch TP
-    int *o_t = text_idx + (size_t)w * cap;
-    int *o_f = time_idx + (size_t)w * cap;
-
-    if (N <= 0 || M <= 0) {  // degenerate: path of the border only
-        if (tid == 0) out_len[w] = 0;
-        return;
-    }
-    const int nl = (N + R - 1) / R;                    // active lanes
-    const int steps = M + nl - 1;
-    const int nchunks = (steps + DTW_CH - 1) / DTW_CH;
-    const float INF = __builtin_inff();
-
-    // ---- loader side (waves 1-3): element e of a chunk = (row e / 16, step t0 + e % 16) -> column step - row / R
-    constexpr int NLD = (64 * R * DTW_CH + 191) / 192;
-    float lreg[NLD];
-    auto issue_loads = [&](int k) {
-        const int t0 = k * DTW_CH;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = (tid - 64) + 192 * i;
-            const int row = e / DTW_CH, s = t0 + (e % DTW_CH);
-            const int j = s - row / R;
-            const bool ok = row < N && j >= 0 && j < M;
-            // clamped address + select: a predicated load would be a branch with its own wait
-            const float v = (abl & 2) ? 0.5f : x[(size_t)(row < N ? row : N - 1) * ld_m + (j < 0 ? 0 : (j < M ? j : M - 1))];
-            lreg[i] = ok ? v : 0.f;
-        }
-    };
-    auto store_lds = [&](int k) {
-        const int t0 = k * DTW_CH;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int e = (tid - 64) + 192 * i;
-            const int row = e / DTW_CH, s = t0 + (e % DTW_CH);
-            if (row < 64 * R) xs[(row / R) * LS + (s % DTW_RING) * R + (row % R)] = lreg[i];
-        }
-    };
-
-    // ---- sweep state (wave 0)
-    float prev[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) prev[r] = INF;         // cost[i][0] = inf for i >= 1
-    float diag_in = (lane == 0) ? 0.0f : INF;          // cost[i0-1][0]; cost[0][0] = 0
-    float bottom = INF;
-    const int i0 = lane * R;                           // 0-based first row of this lane
-    const float *xl = xs + lane * LS;
-
-    if (wave > 0) { issue_loads(0); store_lds(0); if (nchunks > 1) issue_loads(1); }
-    __syncthreads();
-    for (int k = 0; k < nchunks; ++k) {
-        if (wave == 0 && !(abl & 4)) {
-            const int t_end = (k + 1) * DTW_CH < steps ? (k + 1) * DTW_CH : steps;
-            int t = k * DTW_CH;
-            float xv[R], xn[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) xv[r] = xl[(t % DTW_RING) * R + r];
-            for (; t < t_end; ++t) {
-                if (t + 1 < t_end) {                   // next step's record: in flight while this step's chain runs
-#pragma unroll
-                    for (int r = 0; r < R; ++r) xn[r] = xl[((t + 1) % DTW_RING) * R + r];
-                }
-                // bottom cell of the lane above: one DPP move (wave_shr:1; lane 0 keeps `old` = inf = cost[0][j], j >= 1)
-                const float up = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(INF), __float_as_int(bottom), 0x138, 0xf, 0xf, false));
-                const int j = t - lane;                // 0-based column
-                const bool valid = lane < nl && j >= 0 && j < M;
-                // straight-line body for all R rows (no branches on the dependent chain): rows past N of the last active
-                // lane compute on zeros -- their results feed only rows further down, which are past N as well -- and a
-                // lane outside its column range keeps its state through the selects below
-                float c0 = diag_in, c1 = up;
-                unsigned trb = 0;
-                float nvs[R];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const float c2 = prev[r];
-                    const bool s0 = (c0 < c1) & (c0 < c2);
-                    const bool s1 = (c1 < c0) & (c1 < c2);
-                    const float c = s0 ? c0 : (s1 ? c1 : c2);
-                    trb |= (s0 ? 0u : (s1 ? 1u : 2u)) << (2 * r);
-                    const float nv = __fadd_rn(xv[r], c);
-                    nvs[r] = nv;
-                    c0 = c2;       // cost[i][j-1] is the diagonal of the row below
-                    c1 = nv;       // cost[i][j]   is "up" of the row below
-                }
-#pragma unroll
-                for (int r = 0; r < R; ++r) prev[r] = valid ? nvs[r] : prev[r];
-                bottom = valid ? c1 : bottom;
-                diag_in = valid ? up : diag_in;
-                if (valid) tr[(size_t)lane * TP + j] = (TT)trb;
-#pragma unroll
-                for (int r = 0; r < R; ++r) xv[r] = xn[r];
-            }
-        } else if (k + 1 < nchunks) {
-            store_lds(k + 1);                           // loads issued one chunk ago; its slots held chunk k-1
-            if (k + 2 < nchunks) issue_loads(k + 2);
-        }
-        __syncthreads();
-    }
-    if (wave > 0) return;
-    if (abl & 1) { if (lane == 0) out_len[w] = 0; return; }      // experiment: no backtrace
-
-    // the trace plane must be visible to the walk (LDS: the barrier above; global: same wave, program order + fence)
-    if (!TLDS) __threadfence_block();
-
-    // ---- backtrace: every lane of wave 0 walks the same path (uniform control flow, broadcast reads); lane 0 records it.
-    //      The moves of 8 (byte trace) or 4 (short trace) consecutive columns of one lane travel in one 64-bit word.
-    constexpr int WCOLS = 8 / (int)sizeof(TT);
-    //      The path is collected in LDS (the x ring is free once the sweep is over; N + M <= 1948 packed entries fit the
-    //      smallest ring) and written out in forward order by all lanes at the end.
-    unsigned *path = (unsigned *)smem;
-    int i = N, j = M, n = 0;
-    int cur_lane = -1, cur_blk = -1;
-    unsigned w_lo = 0, w_hi = 0;          // the current 64-bit trace word, held in SCALAR registers
-    while (i > 0 || j > 0) {
-        if (lane == 0) path[n] = (unsigned)(i - 1) | ((unsigned)(j - 1) << 16);       // (-1 wraps to 0xFFFF: decoded below)
-        ++n;
-        unsigned mv;
-        if (i == 0) mv = 2u;
-        else if (j == 0) mv = 1u;
-        else {
-            const int tl = (i - 1) / R, rr = (i - 1) - tl * R, col = j - 1;
-            const int blk = col / WCOLS;
-            if (tl != cur_lane || blk != cur_blk) {
-                const unsigned long long word = *(const unsigned long long *)(tr + (size_t)tl * TP + blk * WCOLS);     // TP % 8 == 0
-                // the walk is wave-uniform: handing the word to the scalar unit keeps (i, j), the move extraction and every
-                // branch of the loop off the vector pipe (one VALU -> SALU transfer per 8 columns instead of one per step)
-                w_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)word);
-                w_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(word >> 32));
-                cur_lane = tl; cur_blk = blk;
-            }
-            const int sh = (col - blk * WCOLS) * 8 * (int)sizeof(TT);
-            const unsigned wd = (sh < 32 ? (w_lo >> sh) : (w_hi >> (sh - 32))) & (sizeof(TT) == 1 ? 0xFFu : 0xFFFFu);
-            mv = (wd >> (2 * rr)) & 3u;
-        }
-        if (mv == 0u) { --i; --j; }
-        else if (mv == 1u) { --i; }
-        else { --j; }
-    }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): lane 0's LDS stores before the other lanes read them (one wave)
-    for (int p = lane; p < n; p += 64) {
-        const unsigned e = path[n - 1 - p];
-        const int a = (int)(e & 0xFFFFu), b = (int)(e >> 16);
-        o_t[p] = a == 0xFFFF ? -1 : a;
-        o_f[p] = b == 0xFFFF ? -1 : b;
-    }
-    if (lane == 0) out_len[w] = n;
-}
-
-// ------------------------------------------------------------------------------------------ generation 3: four sweeping waves
-// What bounded the kernel above (profiles/r02_dtw_ablation.txt): ONE wave executes the whole front -- ~75 VALU operations per
-// anti-diagonal step for 4 rows per lane, 4 cycles each, whatever their dependencies: 203 ns per step x 1724 steps; and a
-// backtrace of one scalar iteration per path element (295 us for 1725 elements).  Here:
+// ------------------------------------------------------------------------------------------ four sweeping waves
+// One workgroup (4 waves) per window -- the LDS wavefront scan the north star names:
 //   * all four waves of the workgroup sweep: lane L (0..255) owns R consecutive token rows (R = 1 up to 256 tokens, 2 up to
 //     512), so a step costs ~19 VALU operations per wave.  Wave w runs one 16-step chunk behind wave w-1 and takes the
 //     bottom row of the wave above from a small LDS ring (one workgroup barrier per chunk); inside a wave the neighbour is
-//     one DPP move as before.
+//     one DPP move (wave_shr:1).
 //   * no LDS staging of x and no loader waves: a lane needs 16 CONSECUTIVE floats of its row per chunk; they are requested
 //     three chunks ahead (index clamped into the window; columns outside [0, M) are loaded but never used) and wait in
 //     registers.
@@ -217,7 +33,7 @@ __global__ __launch_bounds__(256) void swx_dtw_kernel(const float *__restrict__ 
 //   * backtrace on the scalar unit over RUNS: consecutive "left" moves (the bulk of a path: 1500 frames vs ~226 tokens) are
 //     counted with one count-leading-zeros on the trace word, so the walk takes one iteration per run (~N + M/16) instead
 //     of one per path element; the runs are expanded to the two index arrays by all 256 threads at the end.
-// Same recurrence, same tie-break, same f32 adds as above: bit-identical paths (tests/test_gpu_kernels.py DTW tests).
+// Same recurrence, same tie-break, same f32 adds as the CPU rule: bit-identical paths (tests/test_gpu_kernels.py DTW tests).
 constexpr int D4_CH = 16, D4_BR = 64;
 
 template <int R, bool TLDS>
@@ -225,7 +41,7 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
                                                        const int *__restrict__ Nw, const int *__restrict__ Mw,
                                                        int *__restrict__ text_idx, int *__restrict__ time_idx,
                                                        int *__restrict__ out_len, unsigned char *__restrict__ ws_all,
-                                                       size_t ws_stride, int PITCH, int abl)
+                                                       size_t ws_stride, int PITCH)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *bnd = (float *)smem;                                   // [3][D4_BR]: bottom row of waves 0..2, ring over steps
@@ -262,10 +78,7 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const unsigned e0 = (unsigned)((L * R + r) * ld_m + (c * D4_CH - L));
-            if (abl & 2) {                 // experiment: no x loads
-#pragma unroll
-                for (int q = 0; q < D4_CH; ++q) dst[r][q] = 0.5f;
-            } else if (e0 + (D4_CH - 1) <= last_e) {
+            if (e0 + (D4_CH - 1) <= last_e) {
 #pragma unroll
                 for (int g = 0; g < D4_CH / 4; ++g) {
                     const f4u v = *(const f4u *)(xw + e0 + 4 * g);
@@ -348,7 +161,6 @@ __global__ __launch_bounds__(256) void swx_dtw4_kernel(const float *__restrict__
     }
     if (!TLDS) { __threadfence_block(); __syncthreads(); }
 
-    if (abl & 1) { if (tid == 0) out_len[w] = 0; return; }      // experiment: no backtrace
     // ---- backtrace over runs (wave 0, scalar), then expansion by all threads
     if (wave == 0) {
         int i = N, j = M, n = 0, k = 0;
@@ -401,16 +213,12 @@ inline int dtw4_pitch(int ld_n, int ld_m)
     return (((ld_m + lanes - 1) + D4_CH - 1) / D4_CH + 3) | 1;
 }
 
-inline int dtw_tp(int ld_m) { return (ld_m + 15) / 16 * 16; }
-
 }  // namespace
 
 extern "C" size_t swx_dtw_workspace_bytes(int W, int ld_n, int ld_m)
 {
-    // per window: the lane-major trace plane as shorts (used by the long-token-axis variant only) + the path scratch
-    size_t per = (size_t)64 * dtw_tp(ld_m) * sizeof(unsigned short) + 2 * (size_t)(ld_n + ld_m) * sizeof(int);
-    const size_t per4 = (size_t)256 * dtw4_pitch(ld_n, ld_m) * 2 * sizeof(unsigned);       // generation 3, R = 2, trace in memory
-    if (per4 > per) per = per4;
+    // per window: the trace words of the long-token-axis variant (R = 2, trace in memory)
+    size_t per = (size_t)256 * dtw4_pitch(ld_n, ld_m) * 2 * sizeof(unsigned);
     per = (per + 255) & ~(size_t)255;
     return per * (size_t)(W > 0 ? W : 1);
 }
@@ -423,11 +231,8 @@ extern "C" int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_
     hipStream_t s = (hipStream_t)stream;
     SwxProfScope prof(PC_DTW, (double)W * ld_n * ld_m * 5.0, s);
     const size_t per = swx_dtw_workspace_bytes(1, ld_n, ld_m);
-    const int R = (ld_n + 63) / 64;
-    const int TP = dtw_tp(ld_m);
-    static const int abl = [] { const char *e = getenv("SWX_DTW_ABL"); return e ? atoi(e) : 0; }();
-    static const bool gen2 = [] { const char *e = getenv("SWX_DTW_GEN2"); return e && atoi(e) != 0; }();     // A/B: the one-wave sweep
-    if (!gen2 && ld_n <= 512 && ld_n + ld_m < 65535 && ld_m < 32768) {
+    if (ld_n + ld_m >= 65535 || ld_m >= 32768) return -2;      // run records pack (offset, length) into 32 bits
+    {
         const int PITCH = dtw4_pitch(ld_n, ld_m);
         const size_t base = 3 * D4_BR * 4 + 2 * (size_t)(ld_n + ld_m) * 4;
 #define SWX_DTW4(RR, TL) do { \
@@ -439,38 +244,12 @@ extern "C" int swx_dtw(const float *d_x, int W, int ld_n, int ld_m, const int32_
                 attr_done4 = true; \
             } \
             hipLaunchKernelGGL((swx_dtw4_kernel<RR, TL>), dim3(W), dim3(256), lds, s, d_x, ld_n, ld_m, d_N, d_M, d_text_idx, d_time_idx, \
-                               d_len, (unsigned char *)d_trace_ws, per, PITCH, abl); } while (0)
+                               d_len, (unsigned char *)d_trace_ws, per, PITCH); } while (0)
         const bool fits = base + (size_t)256 * PITCH * 4 <= 160 * 1024 - 1024 - 64;
         if (ld_n <= 256) { if (fits) SWX_DTW4(1, true); else SWX_DTW4(1, false); }
         else SWX_DTW4(2, false);
 #undef SWX_DTW4
-        SWX_CHECK_LAUNCH();
-        return 0;
     }
-    static const int ch = [] { const char *e = getenv("SWX_DTW_CH"); return e ? atoi(e) : 16; }();
-#define SWX_DTW_LAUNCH2(RR, TL, CH_) do { \
-        const size_t lds = (size_t)64 * dtw_lane_stride(RR, 2 * CH_) * 4 + ((TL) ? (size_t)64 * TP * (RR <= 4 ? 1 : 2) : 0); \
-        static bool attr_done = false; \
-        if (!attr_done) { \
-            hipError_t e_ = hipFuncSetAttribute((const void *)swx_dtw_kernel<RR, TL, CH_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
-            if (e_ != hipSuccess) return -100 - (int)e_; \
-            attr_done = true; \
-        } \
-        if (lds > 160 * 1024 - 1024) return -2; \
-        hipLaunchKernelGGL((swx_dtw_kernel<RR, TL, CH_>), dim3(W), dim3(256), lds, s, d_x, ld_n, ld_m, d_N, d_M, d_text_idx, d_time_idx, \
-                           d_len, (unsigned char *)d_trace_ws, per, TP, abl); } while (0)
-#define SWX_DTW_LAUNCH(RR, TL) do { if (ch == 32 && RR <= 4) SWX_DTW_LAUNCH2(RR, TL, 32); else SWX_DTW_LAUNCH2(RR, TL, 16); } while (0)
-    switch (R) {
-        case 1: SWX_DTW_LAUNCH(1, true); break;
-        case 2: SWX_DTW_LAUNCH(2, true); break;
-        case 3: SWX_DTW_LAUNCH(3, true); break;
-        case 4: SWX_DTW_LAUNCH(4, true); break;
-        case 5: SWX_DTW_LAUNCH(5, false); break;
-        case 6: SWX_DTW_LAUNCH(6, false); break;
-        default: SWX_DTW_LAUNCH(7, false); break;
-    }
-#undef SWX_DTW_LAUNCH
-#undef SWX_DTW_LAUNCH2
     SWX_CHECK_LAUNCH();
     return 0;
 }

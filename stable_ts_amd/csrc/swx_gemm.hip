@@ -262,21 +262,21 @@ __global__ __launch_bounds__(256) void gemm_f16_tiled(GemmArgs g)
 // per K step, 67.6 KB of f32 epilogue staging -> two workgroups per CU; profiles/r02_kb_gemm_glds.txt): time = 103 us per
 // 1280 of K + 79 us that do not depend on K -- at M = 30000, N = 1280 the fixed part was 43 % of the launch: the epilogue's
 // dependent bias / residual loads (see tile_epilogue_f16), with only one other workgroup on the CU to hide them.
-// SINGLE = one operand buffer, two barriers per K step, 33.8 KB of LDS -> three to four workgroups per CU: the occupancy, not
-// a software pipeline, overlaps one workgroup's loads and epilogue with its neighbours' MFMAs.  Measured at M = 30000
-// (profiles/r02_kb_gemm_gen2.txt, TFLOP/s, first kernel -> <false,2> -> <true,4> -> <true,3>): N = K = 1280: 522 -> 737 -> 783
-// -> 768; N = 3840: 536 -> 704 -> 754 -> 737; N = 5120: 523 -> 748 -> 809 -> 788; K = 5120: 715 -> 783 -> 816 -> 854.  All
-// variants produce bit-identical results (same MFMA order per accumulator, same f32 epilogue arithmetic;
-// tests/hw_checks/gemm_glds_check.py).  Default: <true, 3>.
+// Now: one operand buffer, two barriers per K step, 33.8 KB of LDS -> three workgroups per CU: the occupancy, not a software
+// pipeline, overlaps one workgroup's loads and epilogue with its neighbours' MFMAs.  Measured at M = 30000
+// (profiles/r02_kb_gemm_gen2.txt, TFLOP/s, first kernel -> double buffer, 2 per CU -> single buffer, 4 per CU -> single buffer,
+// 3 per CU = this kernel): N = K = 1280: 522 -> 737 -> 783 -> 768; N = 3840: 536 -> 704 -> 754 -> 737; N = 5120: 523 -> 748 ->
+// 809 -> 788; K = 5120: 715 -> 783 -> 816 -> 854.  The variants that lost were deleted in round 3.  Bit-identical to the
+// register-staged kernel (same MFMA order per accumulator, same f32 epilogue arithmetic; tests/hw_checks/gemm_glds_check.py).
 constexpr int GL_TILE = 128 * 128;          // bytes of one operand tile: 128 rows x 64 halfs
 
-template <bool SINGLE, int BNT>     // BNT = tile width: 128, or 64 for shapes whose 128-wide tiles would not fill the chip
+template <int BNT>     // BNT = tile width: 128, or 64 for shapes whose 128-wide tiles would not fill the chip
 __device__ __forceinline__ void gemm_f16_glds_body(const GemmArgs &g)
 {
     constexpr int NJ = BNT / 32;                       // 16-column fragments per wave (2 x 2 waves: 64 rows x BNT / 2 columns each)
     constexpr int TB = BNT * 128;                      // bytes of the B operand tile (BNT rows x 64 halfs)
     constexpr int STAGE = GL_TILE + TB;
-    constexpr int MAIN = (SINGLE ? 1 : 2) * STAGE;
+    constexpr int MAIN = STAGE;
     constexpr int EPI_ = 64 * (BNT + 4) * 4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[MAIN > EPI_ ? MAIN : EPI_];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -348,31 +348,18 @@ __device__ __forceinline__ void gemm_f16_glds_body(const GemmArgs &g)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
-    if (SINGLE) {
-        for (int kt = 0; kt < KT; ++kt) {
-            stage(kt, 0);
-            __syncthreads();
-            compute(0);
-            __syncthreads();
-        }
-    } else {
-        stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {       // one operand buffer, two barriers per K step: three workgroups per CU overlap each other
+        stage(kt, 0);
         __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < KT) stage(kt + 1, cur ^ 1);
-            compute(cur);
-            __syncthreads();
-        }
+        compute(0);
+        __syncthreads();
     }
     tile_epilogue_f16<NJ>(g, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // the instantiations in use (second launch bound = workgroups per CU the register allocation must allow)
-__global__ __launch_bounds__(256, 2) void gemm_f16_glds_d2_128(GemmArgs g) { gemm_f16_glds_body<false, 128>(g); }
-__global__ __launch_bounds__(256, 4) void gemm_f16_glds_s4_128(GemmArgs g) { gemm_f16_glds_body<true, 128>(g); }
-__global__ __launch_bounds__(256, 3) void gemm_f16_glds_s3_128(GemmArgs g) { gemm_f16_glds_body<true, 128>(g); }
-__global__ __launch_bounds__(256, 3) void gemm_f16_glds_s3_64(GemmArgs g) { gemm_f16_glds_body<true, 64>(g); }
+__global__ __launch_bounds__(256, 3) void gemm_f16_glds_128(GemmArgs g) { gemm_f16_glds_body<128>(g); }
+__global__ __launch_bounds__(256, 3) void gemm_f16_glds_64(GemmArgs g) { gemm_f16_glds_body<64>(g); }
 
 // ------------------------------------------------------------------------------------------------ tiled f32
 constexpr int BK32 = 16, LD32 = BK32 + 1;
@@ -454,24 +441,19 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
 // while the MFMAs of chunk c issue -- without it each k-step exposes a full memory round trip (measured 40 us per
 // launch at M=100 before, rocprof r01 v0).
 template <int MT>
-__global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs, int64_t slab_stride, int ks2)
+__global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
 {
-    constexpr int NKS_MAX = 10;      // k-steps (of 32) per wave: the launcher keeps K / (128 * ks2) <= 10
+    constexpr int NKS_MAX = 10;      // k-steps (of 32) per wave: the launcher keeps K / 128 <= 10
     __shared__ f32x4 red[3][MT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const f16 *A = (const f16 *)g.A;
     const f16 *W = (const f16 *)g.W;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    // K is split over blockIdx.y (ks2 slices, partial sums go to f32 slabs) and then over the 4 waves
-    const int kslice = g.K / (4 * ks2);
+    // K is split over the 4 waves
+    const int kslice = g.K / 4;
     const int nks = kslice / 32;
-    const int kb = (blockIdx.y * 4 + wave) * kslice;
-    if (ks2 > 1 || slabs) {
-        g.C = slabs + (size_t)blockIdx.y * slab_stride;
-        g.ldc = g.N;
-        g.epi = EPI_OUT_F32;
-    }
+    const int kb = wave * kslice;
     const int n = n0 + fr;
     const bool nok = n < g.N;
     const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
@@ -535,349 +517,7 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g, float *slabs,
     }
 }
 
-// ------------------------------------------------------------------------------------------- panel-group f16
-// Decode-step GEMM, second generation.  Profile r01 v3 showed the 16-column-panel kernel above bound by L2->CU
-// ACTIVATION traffic (every panel re-reads the whole [M][K] activation: 3242 panels x 256 KB for the logits), not by
-// HBM.  Here a workgroup owns 64 output columns (one 16-column panel per wave) x one K slice (blockIdx.y); the
-// activation chunk [MT*16][64] of each step is staged ONCE per workgroup in LDS with coalesced full-line loads and
-// shared by the four waves (4x fewer, 2x wider L2 requests), while every wave streams its own weight fragments of the
-// whole slice from HBM up front.  Partial sums go to f32 slabs (deterministic split-K), finished by splitk_finish_f16.
-constexpr int PG_LD = 72;        // halfs per LDS row
-constexpr int PG_MAXIT = 20;     // 64-wide K chunks per workgroup slice, upper bound (launcher picks the <= 5, <= 10 or <= 20 build)
-template <int MT, int MAXIT, bool DIRECT>
-__global__ __launch_bounds__(256) void gemm_f16_pg(GemmArgs g, float *slabs, int64_t slab_stride, int ks2, int flags)
-{
-    __shared__ __attribute__((aligned(16))) f16 As[2][MT * 16][PG_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, fk = (lane >> 4) * 8;
-    const f16 *A = (const f16 *)g.A;
-    const f16 *W = (const f16 *)g.W;
-    const int kslice = g.K / ks2;
-    const int nit = kslice / 64;
-    const int kb = blockIdx.y * kslice;
-    const int n = blockIdx.x * 64 + wave * 16 + fr;
-    const bool nok = n < g.N;
-    const f16 *wp = W + (size_t)(nok ? n : 0) * g.ldw + kb + fk;
-    const f16x8 zero8 = (f16x8)(f16)0;
-
-    f16x8 wf[2 * MAXIT];
-#pragma unroll
-    for (int ks = 0; ks < 2 * MAXIT; ++ks) wf[ks] = (nok && ks < 2 * nit) ? *(const f16x8 *)(wp + ks * 32) : zero8;
-
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    constexpr int NCH = (MT * 16 * 8 + 255) / 256;      // 16-byte chunks of the activation tile per thread
-    f16x8 ra[NCH];
-    auto load_a = [&](int it) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 3, c8 = (idx & 7) * 8;
-            ra[j] = (row < g.M) ? *(const f16x8 *)(A + (size_t)row * g.lda + kb + it * 64 + c8) : zero8;
-        }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int idx = tid + 256 * j, row = idx >> 3, c8 = (idx & 7) * 8;
-            if (row < MT * 16) *(f16x8 *)&As[buf][row][c8] = ra[j];
-        }
-    };
-    load_a(0);
-    store_a(0);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-        if (it < nit) {
-            const int cur = it & 1;
-            if (it + 1 < nit) load_a(it + 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const f16x8 a = *(const f16x8 *)&As[cur][t * 16 + fr][kk * 32 + fk];
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wf[it * 2 + kk], acc[t], 0, 0, 0);
-                }
-            if (it + 1 < nit) store_a(cur ^ 1);
-            __syncthreads();
-        }
-    }
-    const int col = blockIdx.x * 64 + wave * 16 + (lane & 15), row_l = (lane >> 4) * 4;
-    if constexpr (DIRECT) {
-        // un-split K (ks2 == 1): the workgroup owns the finished sums, so bias / GELU are applied here and the compute
-        // dtype is stored directly -- no slab, no finish launch.  Same arithmetic as splitk_finish_f16 on one slab.
-        if (col < g.N) {
-            const float bias = (g.epi & EPI_BIAS) ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = t * 16 + row_l + r;
-                    float a = 0.f + acc[t][r];
-                    if (g.epi & EPI_BIAS) a += bias;
-                    if (g.epi & EPI_GELU) a = gelu_erf(a);
-                    if (row < g.M) ((f16 *)g.C)[(size_t)row * g.ldc + col] = (f16)a;
-                }
-        }
-        return;
-    }
-    // each wave owns its 16 columns for this K slice: plain f32 partials, no cross-wave reduction
-    float *out = slabs + (size_t)blockIdx.y * slab_stride;
-    if (col < g.N) {
-        if (flags & SWX_FLAG_SC1_SLABS) {
-            // write-through: the partials reach memory while the kernel runs instead of as one dirty-L2 write-back at
-            // the kernel boundary (MI355X_MICROARCH.md "boundary" / "publish-large" rows)
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = t * 16 + row_l + r;
-                    if (row < g.M) __hip_atomic_store(&out[(size_t)row * g.N + col], acc[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-        } else {
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = t * 16 + row_l + r;
-                    if (row < g.M) out[(size_t)row * g.N + col] = acc[t][r];
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------- split-K finish
-// One workgroup per output row: v = sum_k slab[k][row][:] (+bias, GELU, +residual) -> C ; optionally the LayerNorm
-// of the finished row -> ln_out (saves the separate LN launch and its extra pass), and for the fused QKV projection
-// the new K / V rows go straight into the self-attention cache at the row's current position.
-constexpr int FIN_MAXC = 20;   // columns per thread: N <= 256 * 20
-// KS2 > 0: slab count known at compile time (every slab load of a thread is independent and in flight at once);
-// KS2 == 0: generic run-time count
-template <int KS2, int NC>
-__global__ __launch_bounds__(256) void splitk_finish_f16(const float *__restrict__ slabs, int ks2, int64_t slab_stride, int N,
-                                                         FinishArgs f)
-{
-    __shared__ float sh[4];
-    const int row = blockIdx.x, tid = threadIdx.x + blockIdx.y * (256 * NC);   // blockIdx.y > 0 only without fused LN
-    float v[NC];
-    const float *base = slabs + (size_t)row * N;
-    if constexpr (KS2 > 0) {
-        float part[NC][KS2];
-#pragma unroll
-        for (int i = 0; i < NC; ++i)
-#pragma unroll
-            for (int k = 0; k < KS2; ++k) {
-                const int col = tid + 256 * i;
-                part[i][k] = base[(size_t)k * slab_stride + (col < N ? col : N - 1)];   // clamped, never predicated: a
-                // predicated load becomes a branch + s_waitcnt vmcnt(0) per column group (serialised round trips)
-            }
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            float a = 0.f;
-#pragma unroll
-            for (int k = 0; k < KS2; ++k) a += part[i][k];
-            v[i] = a;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            const int col = tid + 256 * i;
-            float a = 0.f;
-            if (col < N) for (int k = 0; k < ks2; ++k) a += base[(size_t)k * slab_stride + col];
-            v[i] = a;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int col = tid + 256 * i;
-        float a = v[i];
-        if (col < N) {
-            if (f.epi & EPI_BIAS) a += f.bias[col];
-            if (f.epi & EPI_GELU) a = gelu_erf(a);
-            if (f.epi & EPI_RES) a += (float)((const f16 *)f.R)[(size_t)row * f.ldr + col];
-            const f16 h = (f16)a;
-            if (f.kcache && col >= f.d) {
-                const int pos = f.pos0[row];
-                if (col < 2 * f.d) ((f16 *)f.kcache)[((size_t)row * f.n_ctx + pos) * f.d + (col - f.d)] = h;
-                else ((f16 *)f.vcache)[((size_t)row * f.n_ctx + pos) * f.d + (col - 2 * f.d)] = h;
-            } else {
-                ((f16 *)f.C)[(size_t)row * f.ldc + col] = h;
-            }
-            a = (float)h;      // the LayerNorm below sees the stored (rounded) activation, like a separate LN launch would
-        }
-        v[i] = a;
-    }
-    if (!f.ln_out) return;
-    const int wid = threadIdx.x >> 6;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) if (tid + 256 * i < N) s += v[i];
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) sh[wid] = s;
-    __syncthreads();
-    const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)N;
-    __syncthreads();
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) if (tid + 256 * i < N) { const float t = v[i] - mean; q += t * t; }
-    q = wave_sum(q);
-    if ((threadIdx.x & 63) == 0) sh[wid] = q;
-    __syncthreads();
-    const float rstd = 1.0f / sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)N + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int col = tid + 256 * i;
-        if (col < N) ((f16 *)f.ln_out)[(size_t)row * f.ld_ln + col] = (f16)((v[i] - mean) * rstd * f.ln_g[col] + f.ln_b[col]);
-    }
-}
-
-// Experiment hook: SWX_PG_POLICY="NxK=ks2,NxK=ks2,..." pins the K split of given GEMM shapes (e.g. "5120x1280=1" runs the
-// first MLP projection un-split on 80 fat workgroups, which lets the kernel finish bias + GELU itself).
-int pg_policy(int N, int K)
-{
-    static const std::vector<std::array<int, 3>> table = [] {
-        std::vector<std::array<int, 3>> t;
-        const char *e = getenv("SWX_PG_POLICY");
-        while (e && *e) {
-            int n = 0, k = 0, c = 0, used = 0;
-            if (sscanf(e, "%dx%d=%d%n", &n, &k, &c, &used) == 3 && used > 0) { t.push_back({n, k, c}); e += used; }
-            else break;
-            if (*e == ',') ++e;
-        }
-        return t;
-    }();
-    for (auto &r : table) if (r[0] == N && r[1] == K) return r[2];
-    return 0;
-}
-
-int pg_ks2(int N, int K)
-{
-    const int units = K / 64;
-    const int panels = (N + 63) / 64;
-    const int pinned = pg_policy(N, K);
-    if (pinned > 0 && units % pinned == 0 && units / pinned <= PG_MAXIT) return pinned;
-    static const int target = [] { const char *e = getenv("SWX_PG_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 320; }();
-    int want = (target + panels - 1) / panels;     // workgroups wanted per launch (tunable for experiments)
-    int ks2 = 0;
-    for (int c = 1; c <= units; ++c)
-        if (units % c == 0 && units / c <= 10 && (ks2 == 0 || c <= want)) ks2 = c;
-    return ks2;
-}
-
-int skinny_ks2(int N, int K)
-{
-    const int units = K / 128;                       // a wave's K slice must stay a multiple of 32
-    const int panels = (N + 15) / 16;
-    int want = 640 / panels;
-    if (want < 1) want = 1;
-    int ks2 = 0;
-    for (int c = 1; c <= units; ++c)
-        if (units % c == 0 && units / c <= 10 && (ks2 == 0 || c <= want)) ks2 = c;    // smallest legal c, grown up to `want`
-    return ks2 ? ks2 : units;
-}
-
 }  // namespace
-
-size_t swx_skinny_slab_floats(int M, int N, int K)
-{
-    if (M <= 0 || M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC) return 0;
-    const int a = skinny_ks2(N, K), b = pg_ks2(N, K);
-    return (size_t)(a > b ? a : b) * M * N;
-}
-
-int swx_pg_splits(int N, int K) { return (K % 128 != 0 || N <= 0) ? 0 : pg_ks2(N, K); }
-
-namespace {
-int pg_launch(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
-              const FinishArgs *direct, hipStream_t s);
-}
-
-int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
-                hipStream_t s)
-{
-    return pg_launch(A, lda, W, ldw, M, N, K, slabs, ref, nullptr, s);
-}
-
-namespace {
-// direct != null (only legal when the shape runs un-split): bias / GELU in the kernel's own epilogue, compute dtype out
-int pg_launch(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
-              const FinishArgs *direct, hipStream_t s)
-{
-    if (M <= 0 || N <= 0) return -4;
-    if (M > 128 || K % 128 != 0 || N > 256 * FIN_MAXC || lda % 8 != 0 || ldw % 8 != 0) return -4;
-    const int ks2 = pg_ks2(N, K);
-    if (ks2 <= 0) return -4;
-    GemmArgs g{};
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = EPI_OUT_F32; g.res_mod = 1;
-    if (direct) {
-        if (ks2 != 1) return -4;
-        g.epi = direct->epi & (EPI_BIAS | EPI_GELU); g.bias = direct->bias; g.C = direct->C; g.ldc = direct->ldc;
-    }
-    const int64_t stride = (int64_t)M * N;
-    const int flags = swx_flags();
-    dim3 grid(cdiv(N, 64), ks2);
-    SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)N * K + (double)M * K) + (double)M * N * 2, s);
-    const int nit = K / (64 * ks2);           // K slice per workgroup in 64-wide chunks: <= 5 (default tuning), <= 10 or <= 20
-#define SWX_PG2(MT, DIR) do { if (nit > 10) hipLaunchKernelGGL((gemm_f16_pg<MT, 20, DIR>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
-                              else if (nit > 5) hipLaunchKernelGGL((gemm_f16_pg<MT, 10, DIR>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); \
-                              else hipLaunchKernelGGL((gemm_f16_pg<MT, 5, DIR>), grid, dim3(256), 0, s, g, slabs, stride, ks2, flags); } while (0)
-#define SWX_PG(MT) do { if (direct) SWX_PG2(MT, true); else SWX_PG2(MT, false); } while (0)
-    switch (cdiv(M, 16)) {
-        case 1: SWX_PG(1); break;
-        case 2: SWX_PG(2); break;
-        case 3: SWX_PG(3); break;
-        case 4: SWX_PG(4); break;
-        case 5: SWX_PG(5); break;
-        case 6: SWX_PG(6); break;
-        case 7: SWX_PG(7); break;
-        default: SWX_PG(8); break;
-    }
-#undef SWX_PG
-#undef SWX_PG2
-    if (ref) { ref->slabs = slabs; ref->ks2 = ks2; ref->stride = stride; ref->N = N; ref->bias = nullptr; }
-    return 0;
-}
-}  // namespace
-
-int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
-                           const FinishArgs &f, hipStream_t s)
-{
-    if (M <= 0 || N <= 0) return 0;
-    SlabRef ref{};
-    // an un-split shape (SWX_PG_POLICY) whose finish is only bias / GELU needs no finish launch at all
-    if (pg_ks2(N, K) == 1 && K % 128 == 0 && !f.ln_out && !f.kcache && !(f.epi & EPI_RES) && f.C)
-        return pg_launch(A, lda, W, ldw, M, N, K, slabs, &ref, &f, s);
-    const int rc = swx_gemm_pg(A, lda, W, ldw, M, N, K, slabs, &ref, s);
-    if (rc < 0) return rc;
-    const int ks2 = ref.ks2;
-    const int64_t stride = ref.stride;
-    {
-        SwxProfScope prof(PC_NORM, (double)ks2 * M * N * 4 + 4.0 * M * N, s);
-        const int nc = cdiv(N, 256);
-        // rows without a fused LayerNorm are split over blockIdx.y in 1280-column pieces (more workgroups, fewer erf per thread)
-        const bool split = !f.ln_out && nc > 5;
-        dim3 fg(M, split ? cdiv(N, 1280) : 1);
-#define SWX_FIN(KS, NC) hipLaunchKernelGGL((splitk_finish_f16<KS, NC>), fg, dim3(256), 0, s, slabs, ks2, stride, N, f)
-        if (split || nc <= 5) {
-            switch (ks2) {
-                case 1: SWX_FIN(1, 5); break;
-                case 2: SWX_FIN(2, 5); break;
-                case 4: SWX_FIN(4, 5); break;
-                case 5: SWX_FIN(5, 5); break;
-                case 8: SWX_FIN(8, 5); break;
-                case 10: SWX_FIN(10, 5); break;
-                case 16: SWX_FIN(16, 5); break;
-                default: SWX_FIN(0, 5); break;
-            }
-        } else {
-            SWX_FIN(0, 20);
-        }
-#undef SWX_FIN
-    }
-    SWX_CHECK_LAUNCH();
-    return 0;
-}
 
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
 {
@@ -885,38 +525,35 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
     if (dtype == SWX_F16) {
         if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;   // tiled: K % 32, skinny: K % 128
         const bool skinny_ok = g.M <= 128 && g.K % 128 == 0 && g.K / 128 <= 10 && g.N <= 16384;   // vocabulary-sized N: tiled
-        const bool use_skinny = force_kernel == 2 ? skinny_ok : ((force_kernel == 1 || force_kernel >= 4) ? false : skinny_ok);
+        const bool use_skinny = force_kernel == 2 ? skinny_ok : ((force_kernel == 1 || force_kernel >= 7) ? false : skinny_ok);
         if (force_kernel == 2 && !skinny_ok) return -4;
         if (use_skinny) {
             SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * ((g.epi & EPI_OUT_F32) ? 4 : 2), s);
             dim3 grid(cdiv(g.N, 16));
             const int mt = cdiv(g.M, 16);
             switch (mt) {
-                case 1: hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
-                case 2: hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
-                case 3: hipLaunchKernelGGL(gemm_f16_skinny<3>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
-                case 4: hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
-                case 5: hipLaunchKernelGGL(gemm_f16_skinny<5>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
-                case 6: hipLaunchKernelGGL(gemm_f16_skinny<6>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
-                case 7: hipLaunchKernelGGL(gemm_f16_skinny<7>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
-                default: hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g, (float *)nullptr, (int64_t)0, 1); break;
+                case 1: hipLaunchKernelGGL(gemm_f16_skinny<1>, grid, dim3(256), 0, s, g); break;
+                case 2: hipLaunchKernelGGL(gemm_f16_skinny<2>, grid, dim3(256), 0, s, g); break;
+                case 3: hipLaunchKernelGGL(gemm_f16_skinny<3>, grid, dim3(256), 0, s, g); break;
+                case 4: hipLaunchKernelGGL(gemm_f16_skinny<4>, grid, dim3(256), 0, s, g); break;
+                case 5: hipLaunchKernelGGL(gemm_f16_skinny<5>, grid, dim3(256), 0, s, g); break;
+                case 6: hipLaunchKernelGGL(gemm_f16_skinny<6>, grid, dim3(256), 0, s, g); break;
+                case 7: hipLaunchKernelGGL(gemm_f16_skinny<7>, grid, dim3(256), 0, s, g); break;
+                default: hipLaunchKernelGGL(gemm_f16_skinny<8>, grid, dim3(256), 0, s, g); break;
             }
         } else {
             SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
             dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
             const bool glds_ok = g.K % 64 == 0 && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0);
-            if (force_kernel >= 4 && !glds_ok) return -4;
-            // 64-column tiles when 128-wide ones would leave CUs idle (encoder at batch 1: M = 1500, N = 1280 is 120 tiles of
-            // 128 x 128 for 256 CUs); force_kernel 8 / 9 = always / never for the A/B
+            if (force_kernel >= 7 && !glds_ok) return -4;
+            // direct-to-LDS kernel by default; the register-staged kernel (force_kernel 1) serves K % 64 != 0 and is the
+            // bit-identity reference.  64-column tiles when 128-wide ones would leave CUs idle (encoder at batch 1: M = 1500,
+            // N = 1280 is 120 tiles of 128 x 128 for 256 CUs); force_kernel 8 / 9 = always / never (A/B in kernel_bench.py)
             const bool narrow = force_kernel == 8 || (force_kernel != 9 && g.N % 64 == 0 && (int64_t)grid.x * grid.y < 224);
-            if (glds_ok && (force_kernel == 4 || force_kernel == 5))
-                hipLaunchKernelGGL(gemm_f16_glds_d2_128, grid, dim3(256), 0, s, g);
-            else if (glds_ok && force_kernel == 6)
-                hipLaunchKernelGGL(gemm_f16_glds_s4_128, grid, dim3(256), 0, s, g);
-            else if (glds_ok && narrow && (force_kernel >= 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
-                hipLaunchKernelGGL(gemm_f16_glds_s3_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
-            else if (glds_ok && (force_kernel >= 7 || (force_kernel == 0 && (swx_flags() & SWX_FLAG_GLDS_GEMM))))
-                hipLaunchKernelGGL(gemm_f16_glds_s3_128, grid, dim3(256), 0, s, g);
+            if (glds_ok && force_kernel != 1 && narrow)
+                hipLaunchKernelGGL(gemm_f16_glds_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
+            else if (glds_ok && force_kernel != 1)
+                hipLaunchKernelGGL(gemm_f16_glds_128, grid, dim3(256), 0, s, g);
             else
                 hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
         }

@@ -25,49 +25,21 @@ struct GemmArgs {
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 
-// ---- run-time switches of the decode step (swx_debug_flags(); initial value: SWX_DEFAULT_FLAGS, or the environment
-//      variable SWX_FLAGS).  Every switch is arithmetic-neutral: results are bit-identical with it on or off
-//      (tests/test_gpu_model.py::test_decode_f16_step_switches_are_bit_identical).  Measured on MI355X, large-v3,
-//      20 windows x beam 5, ms per 10-minute pass (profiles/README.md): none 735, 4 -> 714, 4|16 -> 682, 4|16|64 -> 668,
-//      4|16|32|64 -> 678.  Non-temporal weight / cross-KV loads measured +1.2 % / +4.7 % slower and were removed again.
-#define SWX_FLAG_NO_FAST_STEP 1     // decode steps go through the generic per-op path (A/B reference for the fused step)
-#define SWX_FLAG_SC1_SLABS 4        // decode-step GEMM: write-through (agent-scope) stores for the split-K partial slabs
-#define SWX_FLAG_FUSE_SELF 16       // self-attention finishes q|k|v from the split-K slabs, appends K/V and attends in one launch
-#define SWX_FLAG_FUSE_CROSS_Q 64    // cross-attention finishes q from the split-K slabs (no finish launch for the query projection)
-#define SWX_FLAG_XATTN_PIPE 32      // decode cross-attention: hand double-buffered key blocks (next block's loads before this block's math)
-#define SWX_FLAG_DEC_V3 512        // decode step, small teacher-forced passes and the prefill on the un-split "dec" GEMMs (swx_decstep.hip)
-#define SWX_FLAG_NO_PACKED_XKV 2048 // decode cross-attention reads the row-layout K / V^T instead of the fragment-ordered copy (A/B)
-#define SWX_FLAG_FLASH_V1 4096      // MFMA flash attention: first-generation kernel (A/B)
-#define SWX_FLAG_SELECT_MEM 8192    // logit filters + token selection: the kernel that walks the row in memory (A/B and bit-identity reference)
-#define SWX_FLAG_DEC_V3_FORCE 1024 // ... for every row count (tests)
-#define SWX_FLAG_GLDS_GEMM 256     // tiled f16 GEMM (encoder, cross-KV, scoring): direct-to-LDS operand staging (global_load_lds)
-#define SWX_DEFAULT_FLAGS (SWX_FLAG_SC1_SLABS | SWX_FLAG_FUSE_SELF | SWX_FLAG_FUSE_CROSS_Q | SWX_FLAG_DEC_V3 | SWX_FLAG_GLDS_GEMM)
+// ---- run-time A/B switches (swx_debug_flags(); tests and scripts only -- no environment variable reads them).  Each one
+//      selects the bit-identity / parity REFERENCE of a kernel class; the superseded generations these flags used to keep
+//      alive (split-K decode step, flash attention v1, DTW generation 2, the tiled-GEMM variants that lost) were deleted in
+//      round 3.
+#define SWX_FLAG_NO_FAST_STEP 1       // decode steps / small passes go through the generic per-op path (LayerNorm launches,
+                                      // row-major weights, skinny / tiled GEMMs): the reference of the fused "dec" step
+#define SWX_FLAG_NO_PACKED_XKV 2048   // decode cross-attention reads the row-layout K / V^T instead of the fragment-ordered copy
+#define SWX_FLAG_SELECT_MEM 8192      // logit filters + token selection: the kernel that walks the row in memory (reference of
+                                      // the register-resident kernel, and its fallback for vocabularies > 51 * 1024)
+#define SWX_FLAG_NO_GRAPH 16384       // decode loop: launch every step eagerly instead of replaying the captured two-step graph
+#define SWX_DEFAULT_FLAGS 0
 int swx_flags();
 
-// split-K partial sums left by swx_gemm_pg for a consumer kernel that finishes them itself:
-// value[row][col] = bias[col] + sum_{k < ks2} slabs[k * stride + row * N + col]
-struct SlabRef { const float *slabs; int ks2; int64_t stride; int N; const float *bias; };
-
-// ---- decode-step GEMM = split-K weight streaming into f32 slabs + a finish kernel that reduces the slabs and applies
-//      bias / GELU / residual, optionally fused with the NEXT LayerNorm and with the scatter of new K/V into the cache
-struct FinishArgs {
-    const float *bias; int epi;          // EPI_BIAS | EPI_GELU | EPI_RES
-    const void *R; int64_t ldr;          // residual (compute dtype)
-    void *C; int64_t ldc;                // output (compute dtype); with kv scatter only columns [0, d) are written here
-    const float *ln_g, *ln_b; void *ln_out; int64_t ld_ln;   // fused LayerNorm of the finished row (null = off)
-    void *kcache, *vcache; const int32_t *pos0; int n_ctx, d;   // QKV scatter (null = off)
-};
-// slabs must hold swx_skinny_slab_floats(M, N, K) floats; returns <0 when the shape is not supported by this path
-size_t swx_skinny_slab_floats(int M, int N, int K);
-int swx_gemm_skinny_splitk(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs,
-                           const FinishArgs &f, hipStream_t s);
-// the weight-streaming half alone: leaves the partial sums in `slabs` and describes them in *ref (bias is the caller's)
-int swx_pg_splits(int N, int K);     // the ks2 swx_gemm_pg will use for this shape (0 = shape not supported)
-int swx_gemm_pg(const void *A, int64_t lda, const void *W, int64_t ldw, int M, int N, int K, float *slabs, SlabRef *ref,
-                hipStream_t s);
-
-// ---- decode-step GEMM, third generation (swx_decstep.hip): M split over workgroups, K whole -> the kernel finishes its own
-//      outputs (no f32 slabs, no finish launch), LayerNorm folded into the consumer (statistics from the staged tile)
+// ---- decode-step GEMM (swx_decstep.hip): M split over workgroups, K whole -> the kernel finishes its own outputs (no f32
+//      slabs, no finish launch), LayerNorm folded into the consumer (statistics from the staged tile)
 #define DEC_LN 1        // out = rstd[m] * (acc - mean[m] * c1[n]) + c2[n]   (A = raw residual stream, W = gamma-folded weights)
 #define DEC_GELU 2
 #define DEC_RES 4       // X[m][n] = f16(X + c2[n] + acc)   (in place)
@@ -87,7 +59,6 @@ struct DecGemmArgs {
     int rps;                             // DEC_QKV: rows per sequence (0 / 1: one new token per row); row m = sequence m / rps, token m % rps
     int row_mul;                         // DEC_QKV: cache row (and pos0 index) of sequence q = q * row_mul (0 / 1: q itself; the prefill writes row w * G)
     int ks2, kslice, n_rg; int64_t slab_stride;   // filled by the launcher
-    int abl;                             // experiment switches (SWX_DEC_ABL, scripts/dec_ablate.sh); 0 in production
 };
 int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation
 size_t swx_dec_slab_floats(int M, int N, int K);
@@ -133,7 +104,6 @@ struct AttnArgs {
     void *o; int64_t ldo;
     int B, H, nq, nk;
     int q_rows_per_batch;            // rows of q per batch item (== nq unless grouped)
-    SlabRef qs;                      // qs.slabs != null: q = f16(bias + sum of slabs) instead of a.q (decode cross-attention only)
     const void *kv_packed;           // decode cross-attention: K and V^T of batch item 0 in MFMA fragment order (swx_xkv_pack),
                                      // batch stride k_bs; null = read a.k / a.v
 };
@@ -156,11 +126,10 @@ struct SelfAttnArgs {
     const int32_t *pos0;             // [R] position of the first new token of each row
     void *o; int64_t ldo;            // [R*n_new][d]
     int R, n_new, H, n_ctx, d;
-    int skip_append;                 // K/V of the new token were already scattered into the cache (split-K finish kernel)
+    int skip_append;                 // K/V of the new tokens were already scattered into the cache (QKV projection's epilogue)
     int step_cached;                 // n_new == 1, f16: q at a.qkv (row stride ldqkv), the new K/V already appended -> the
-                                     // latency-optimised single-token kernel (third-generation decode step)
-    SlabRef qkvs;                    // qkvs.slabs != null (n_new == 1, f16): q|k|v of the new token come from the split-K slabs;
-                                     // the kernel finishes them, appends k/v to the cache and attends in ONE launch
+                                     // latency-optimised single-token kernel of the decode step
+    int step_pos;                    // profiler only: position of the new token when the host knows it (decode loop), else 0
 };
 // logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);

@@ -2,6 +2,7 @@
 // sequence the gfx950 kernels for the encoder, the decoding loop and the teacher-forced scoring pass.
 // No device allocation happens here: the caller binds the arena and the workspace (PyTorch owns the memory).
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 #include <cmath>
@@ -50,7 +51,11 @@ struct swx_model {
     size_t arena_bytes = 0;
     unsigned char *arena = nullptr;
     bool has_fold = false;          // the layout holds the folded copies (f16, d % 128 == 0)
-    bool folded = false;            // ... and swx_weights_finalize has filled them
+    // ... and swx_weights_finalize has filled them.  The state belongs to the ARENA, not to the handle: views made by
+    // swx_share_weights hold the same flag, so a tensor reloaded through the owner (flag cleared until the next finalize)
+    // takes every view off the folded copies as well
+    std::shared_ptr<bool> fold_state = std::make_shared<bool>(false);
+    bool is_folded() const { return has_fold && *fold_state; }
     // alignment heads
     std::vector<std::vector<int>> heads_by_layer;   // per decoder layer
     std::vector<int> head_slot0;                    // first capture slot of each layer
@@ -72,6 +77,18 @@ struct swx_model {
 
     template <typename P> P *A(size_t off) const { return (P *)(arena + off); }
     template <typename P> P *Wp(size_t off) const { return (P *)(ws + off); }
+
+    // captured two-step decode graphs (swx_decode): keyed on everything a kernel argument of the step depends on
+    struct StepGraph { std::vector<uint64_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; uint64_t used = 0; };
+    std::vector<StepGraph> graphs;
+    uint64_t graph_clock = 0;
+    hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream, which cannot capture)
+    bool graphs_off = false;            // set when capture / replay failed once on this handle: eager from then on
+    void drop_graphs() {
+        for (auto &g : graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+        graphs.clear();
+    }
+    ~swx_model() { drop_graphs(); if (cap_stream) (void)hipStreamDestroy(cap_stream); }
 };
 
 namespace {
@@ -254,11 +271,7 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
     L.sd = take((size_t)Bmax * (n_align > 0 ? n_align : 1) * D.n_audio_ctx * 4);
     L.suppress = take((size_t)MAX_SUPPRESS * 4);
     {
-        size_t mx = 0;
-        const int shapes[4][2] = {{3 * dt, dt}, {dt, dt}, {4 * dt, dt}, {dt, 4 * dt}};
-        for (auto &sh : shapes) { const size_t f = swx_skinny_slab_floats(128, sh[0], sh[1]); if (f > mx) mx = f; }
-        const size_t f3 = swx_dec_slab_floats(Mmax > 128 ? Mmax : 128, dt, 4 * dt);     // the K = 4d projection of the "dec" step
-        if (f3 > mx) mx = f3;
+        size_t mx = swx_dec_slab_floats(Mmax > 128 ? Mmax : 128, dt, 4 * dt);     // the K = 4d projection of the decode step
         const size_t f4 = swx_dec_slab_floats(160, dt, 4 * dt);      // the small multi-token pass on the dec GEMMs
         if (f4 > mx) mx = f4;
         L.slabs = take(mx * 4 + 256);
@@ -276,12 +289,8 @@ inline hipStream_t S(void *s) { return (hipStream_t)s; }
 // ---------------------------------------------------------------------------------------------- profiler
 struct ProfRec { int cls; double work; hipEvent_t a, b; };
 bool g_prof_enabled = false;
-// decode-step switches (SWX_FLAG_* in swx_kernels.h); the environment variable SWX_FLAGS overrides the built-in default
-int g_debug_flags = [] { const char *e = getenv("SWX_FLAGS"); return e ? atoi(e) : SWX_DEFAULT_FLAGS; }();
-// the un-split "dec" step is used from this many live sequences on; SWX_DEC_MIN_ROWS overrides.  Measured (round 2, call 7): with
-// the threshold at 48 rows the sequential transcribe() (5 rows) ran 48x real time, batch 4 295x, batch 8 502x; at 1: 62x /
-// 394x / 654x -- the un-split step wins at every row count, so it is always used.
-int g_dec_min_rows = [] { const char *e = getenv("SWX_DEC_MIN_ROWS"); return e ? atoi(e) : 1; }();
+// A/B switches (SWX_FLAG_* in swx_kernels.h), set through swx_debug_flags() by tests and scripts; no environment variable
+int g_debug_flags = SWX_DEFAULT_FLAGS;
 std::vector<ProfRec> g_prof;
 std::vector<hipEvent_t> g_pool;
 size_t g_pool_next = 0;
@@ -345,81 +354,13 @@ struct FwdCfg {
     bool capture; int cap_row0, cap_rows, cap_ld_n;
 };
 
-// One decoder step (n_new == 1) for <= 128 rows in fp16: every projection is a split-K weight-streaming GEMM whose
-// finish kernel also applies the next LayerNorm / scatters the new K,V into the cache.  Leaves ln(x) of the LAST layer
-// (the model's final LayerNorm) in the `h` buffer.
-int decoder_step_fast(swx_model *m, const FwdCfg &f, hipStream_t s)
-{
-    const swx_dims &D = m->dims;
-    const int d = D.n_text_state, H = D.n_text_head;
-    const size_t e = m->esz;
-    const int rows = f.W * f.rpw;
-    unsigned char *x = m->ws + m->L.x, *h = m->ws + m->L.h, *qkv = m->ws + m->L.qkv, *att = m->ws + m->L.att, *u = m->ws + m->L.u;
-    float *slabs = m->Wp<float>(m->L.slabs);
-    SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, rows, 1, m->arena + m->o_tok_emb,
-                      m->A<float>(m->o_dec_pos), d, x, s));
-    SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->dec[0].ln1_g), m->A<float>(m->dec[0].ln1_b), h, d, rows, d, s));
-    const int64_t chunk = xkv_chunk_elems(m);
-    // cross-attention rows of a window are its f.rpw consecutive rows: q row (b, qn) = b * rpw + qn, as the slabs are laid out
-    const bool fuse_self = (g_debug_flags & SWX_FLAG_FUSE_SELF) && swx_pg_splits(3 * d, d) <= 16;
-    const bool fuse_cq = (g_debug_flags & SWX_FLAG_FUSE_CROSS_Q) && f.rpw <= 16 && D.n_audio_ctx >= 128 && swx_pg_splits(d, d) <= 16;
-    for (int l = 0; l < D.n_text_layer; ++l) {
-        const LayerW &w = m->dec[l];
-        unsigned char *kc = f.kcache + (size_t)l * f.layer_stride, *vc = f.vcache + (size_t)l * f.layer_stride;
-        FinishArgs fq{};
-        fq.bias = m->A<float>(w.bqkv); fq.epi = EPI_BIAS; fq.C = qkv; fq.ldc = 3 * d;
-        fq.kcache = kc; fq.vcache = vc; fq.pos0 = f.pos0; fq.n_ctx = D.n_text_ctx; fq.d = d;
-        SelfAttnArgs sa{};
-        sa.qkv = qkv; sa.ldqkv = 3 * d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
-        sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
-        if (fuse_self) {    // the attention kernel finishes q|k|v from the partial slabs itself (no finish launch)
-            SWX_TRY(swx_gemm_pg(h, d, m->arena + w.wqkv, d, rows, 3 * d, d, slabs, &sa.qkvs, s));
-            sa.qkvs.bias = fq.bias;
-        } else {
-            SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wqkv, d, rows, 3 * d, d, slabs, fq, s));
-        }
-        SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
-        FinishArgs fo{};
-        fo.bias = m->A<float>(w.bo); fo.epi = EPI_BIAS | EPI_RES; fo.R = x; fo.ldr = d; fo.C = x; fo.ldc = d;
-        fo.ln_g = m->A<float>(w.lnx_g); fo.ln_b = m->A<float>(w.lnx_b); fo.ln_out = h; fo.ld_ln = d;
-        SWX_TRY(swx_gemm_skinny_splitk(att, d, m->arena + w.wo, d, rows, d, d, slabs, fo, s));
-        FinishArgs fc{};
-        fc.bias = m->A<float>(w.bcq); fc.epi = EPI_BIAS; fc.C = qkv; fc.ldc = d;
-        const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
-        AttnArgs ca{};
-        if (fuse_cq) {
-            SWX_TRY(swx_gemm_pg(h, d, m->arena + w.wcq, d, rows, d, d, slabs, &ca.qs, s));
-            ca.qs.bias = fc.bias;
-        } else {
-            SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.wcq, d, rows, d, d, slabs, fc, s));
-        }
-        ca.q = qkv; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
-        ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
-        ca.B = f.W; ca.H = H; ca.nq = f.rpw; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw;
-        SWX_TRY(swx_attention(m->dtype, ca, 0, s));
-        FinishArgs fx{};
-        fx.bias = m->A<float>(w.bco); fx.epi = EPI_BIAS | EPI_RES; fx.R = x; fx.ldr = d; fx.C = x; fx.ldc = d;
-        fx.ln_g = m->A<float>(w.ln2_g); fx.ln_b = m->A<float>(w.ln2_b); fx.ln_out = h; fx.ld_ln = d;
-        SWX_TRY(swx_gemm_skinny_splitk(att, d, m->arena + w.wco, d, rows, d, d, slabs, fx, s));
-        FinishArgs f1{};
-        f1.bias = m->A<float>(w.b1); f1.epi = EPI_BIAS | EPI_GELU; f1.C = u; f1.ldc = 4 * d;
-        SWX_TRY(swx_gemm_skinny_splitk(h, d, m->arena + w.w1, d, rows, 4 * d, d, slabs, f1, s));
-        FinishArgs f2{};
-        f2.bias = m->A<float>(w.b2); f2.epi = EPI_BIAS | EPI_RES; f2.R = x; f2.ldr = d; f2.C = x; f2.ldc = d;
-        const bool last = l + 1 == D.n_text_layer;
-        f2.ln_g = m->A<float>(last ? m->o_ln_g : m->dec[l + 1].ln1_g);
-        f2.ln_b = m->A<float>(last ? m->o_ln_b : m->dec[l + 1].ln1_b);
-        f2.ln_out = h; f2.ld_ln = d;
-        SWX_TRY(swx_gemm_skinny_splitk(u, 4 * d, m->arena + w.w2, 4 * d, rows, d, 4 * d, slabs, f2, s));
-    }
-    return 1;   // h holds the final LayerNorm of x
-}
-
-// One decoder step (n_new == 1), third generation: un-split "dec" GEMMs (swx_decstep.hip) that finish their own outputs.
+// One decoder step (n_new == 1) in fp16: un-split "dec" GEMMs (swx_decstep.hip) that finish their own outputs.
 // 8 launches per layer (QKV+scatter, self-attention, out-proj+residual, cross-q, cross-attention, out-proj+residual, MLP-in+GELU,
-// MLP-out [+ its slab reduction]) instead of 12; no LayerNorm launch, no f32 slabs except for the K = 4d projection.
+// MLP-out [+ its slab reduction]); no LayerNorm launch, no f32 slabs except for the K = 4d projection.  (The split-K
+// generation of rounds 1-2 -- 12 launches per layer -- was deleted in round 3; the generic per-op path below is the
+// bit-identity-free reference: SWX_FLAG_NO_FAST_STEP.)
 // Leaves the RAW residual stream in `x` (returns 0: the caller applies the final LayerNorm).
-int decoder_step_v3(swx_model *m, const FwdCfg &f, hipStream_t s)
+int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
     const swx_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head;
@@ -545,19 +486,13 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
 
 int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
-    static const bool no_dec_prefill = [] { const char *e = getenv("SWX_NO_DEC_PREFILL"); return e && atoi(e) != 0; }();   // A/B
-    if (m->dtype == SWX_F16 && m->folded && f.n_new > 1 && f.W * f.rpw * f.n_new <= 160 && !(no_dec_prefill && f.row_mul > 1) &&
-        (g_debug_flags & SWX_FLAG_DEC_V3) && !(g_debug_flags & SWX_FLAG_NO_FAST_STEP) &&
+    const bool dec_ok = m->dtype == SWX_F16 && m->is_folded() && !(g_debug_flags & SWX_FLAG_NO_FAST_STEP);
+    if (dec_ok && f.n_new > 1 && f.W * f.rpw * f.n_new <= 160 &&
         swx_dec_slab_floats(f.W * f.rpw * f.n_new, m->dims.n_text_state, 4 * m->dims.n_text_state) * 4 <= m->L.slab_bytes)
         return decoder_forward_dec(m, f, s);
-    if (m->dtype == SWX_F16 && m->folded && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.rpw <= 16 && m->dims.n_audio_ctx >= 128 &&
-        !(g_debug_flags & SWX_FLAG_NO_FAST_STEP) &&
-        ((g_debug_flags & SWX_FLAG_DEC_V3_FORCE) || ((g_debug_flags & SWX_FLAG_DEC_V3) && f.W * f.rpw >= g_dec_min_rows)) &&
+    if (dec_ok && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.rpw <= 16 && m->dims.n_audio_ctx >= 128 &&
         (size_t)f.W * f.rpw <= (size_t)m->L.rows_big)
-        return decoder_step_v3(m, f, s);
-    if (!(g_debug_flags & SWX_FLAG_NO_FAST_STEP) && m->dtype == SWX_F16 && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.W * f.rpw <= 128 &&
-        m->dims.n_text_state % 128 == 0 && swx_skinny_slab_floats(f.W * f.rpw, 3 * m->dims.n_text_state, m->dims.n_text_state) > 0)
-        return decoder_step_fast(m, f, s);
+        return decoder_step_dec(m, f, s);
     const swx_dims &D = m->dims;
     const int d = D.n_text_state, H = D.n_text_head;
     const size_t e = m->esz;
@@ -610,6 +545,45 @@ int logits_gemm(swx_model *m, const void *hid, int64_t ld, int rows, float *out,
     const swx_dims &D = m->dims;
     return swx_gemm(m->dtype, gemm_args(hid, ld, m->arena + m->o_tok_emb, D.n_text_state, nullptr, out, D.n_vocab, rows,
                                         D.n_vocab, D.n_text_state, EPI_OUT_F32), 0, s);
+}
+
+
+// The captured two-step graph of a decode job, from the handle's cache or captured now.  `record` enqueues the two units on the
+// stream it is given.  The key lists everything a kernel argument of the step depends on: the decode configuration, the
+// buffers (workspace / arena / cross-K/V / timestamp mask), the switches.  Buffer CONTENTS are read at run time.
+template <typename F>
+swx_model::StepGraph *step_graph(swx_model *m, const DecodeBufs &b, const void *d_xkv, int cur, F record)
+{
+    const swx_decode_cfg &c = b.cfg;
+    uint32_t tbits, pbits;
+    memcpy(&tbits, &c.temperature, 4); memcpy(&pbits, &c.patience, 4);
+    std::vector<uint64_t> key = {
+        (uint64_t)c.n_windows, (uint64_t)c.n_group, (uint64_t)c.beam, tbits, pbits, (uint64_t)c.sample_len, (uint64_t)c.sample_begin,
+        (uint64_t)c.sot_index, (uint64_t)c.suppress_blank, (uint64_t)c.apply_timestamp_rules, (uint64_t)(int64_t)c.max_initial_timestamp_index,
+        (uint64_t)c.eot, (uint64_t)c.sot, (uint64_t)(int64_t)c.no_timestamps, (uint64_t)c.timestamp_begin, (uint64_t)(int64_t)c.no_speech,
+        (uint64_t)(int64_t)c.blank_token, (uint64_t)c.n_suppress, (uint64_t)c.min_tokens, (uint64_t)c.seed,
+        (uint64_t)(uintptr_t)b.ts_mask, (uint64_t)(uintptr_t)b.win_uid, (uint64_t)(uintptr_t)d_xkv, (uint64_t)(uintptr_t)m->arena,
+        (uint64_t)(uintptr_t)m->ws, (uint64_t)m->ws_bytes, (uint64_t)g_debug_flags, (uint64_t)cur, (uint64_t)m->is_folded()};
+    ++m->graph_clock;
+    for (auto &g : m->graphs) if (g.key == key) { g.used = m->graph_clock; return &g; }
+    if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) { m->cap_stream = nullptr; return nullptr; }
+    swx_model::StepGraph ng;
+    if (hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return nullptr;
+    const int rc = record(m->cap_stream);
+    hipError_t er = hipStreamEndCapture(m->cap_stream, &ng.graph);
+    if (rc < 0 || er != hipSuccess || !ng.graph) { if (ng.graph) (void)hipGraphDestroy(ng.graph); return nullptr; }
+    if (hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(ng.graph); return nullptr; }
+    ng.key = std::move(key); ng.used = m->graph_clock;
+    constexpr size_t MAX_GRAPHS = 8;
+    if (m->graphs.size() >= MAX_GRAPHS) {       // least recently used entry makes room
+        size_t lru = 0;
+        for (size_t i = 1; i < m->graphs.size(); ++i) if (m->graphs[i].used < m->graphs[lru].used) lru = i;
+        (void)hipGraphExecDestroy(m->graphs[lru].exec); (void)hipGraphDestroy(m->graphs[lru].graph);
+        m->graphs[lru] = std::move(ng);
+        return &m->graphs[lru];
+    }
+    m->graphs.push_back(std::move(ng));
+    return &m->graphs.back();
 }
 
 __global__ __launch_bounds__(256) void token_prob_kernel(const float *__restrict__ logits, int V, int eot,
@@ -745,6 +719,7 @@ size_t swx_weights_bytes(const swx_model *m) { return m ? m->arena_bytes : 0; }
 
 int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes)
 {
+    if (m) m->drop_graphs();          // captured steps hold the old pointers
     if (!m || !d_arena || bytes < m->arena_bytes) return -1;
     m->arena = (unsigned char *)d_arena;
     hipError_t e = hipMemset(d_arena, 0, m->arena_bytes);
@@ -757,7 +732,7 @@ int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes)
     e = hipMemcpy(m->arena + m->o_twiddle, tw.data(), sizeof(double2) * SWX_N_FFT, hipMemcpyHostToDevice);
     if (e != hipSuccess) return -100 - (int)e;
     for (auto &kv : m->slots) kv.second.loaded = false;
-    m->folded = false;
+    m->fold_state = std::make_shared<bool>(false);       // a new arena: a state of its own (views of the old one keep theirs)
     return upload_heads(m);
 }
 
@@ -769,7 +744,7 @@ int swx_share_weights(swx_model *m, const swx_model *owner)
     if (m->dtype != owner->dtype || m->arena_bytes != owner->arena_bytes || memcmp(&m->dims, &owner->dims, sizeof(swx_dims)) != 0)
         return -1;
     m->arena = owner->arena;
-    m->folded = owner->folded && m->has_fold;
+    m->fold_state = owner->fold_state;
     for (auto &kv : m->slots) {
         auto it = owner->slots.find(kv.first);
         kv.second.loaded = it != owner->slots.end() && it->second.loaded;
@@ -796,7 +771,7 @@ int swx_load_tensor(swx_model *m, const char *name, const float *d_src, int64_t 
         if (e != hipSuccess) return -100 - (int)e;
     }
     sl.loaded = true;
-    m->folded = false;        // the folded copies are stale until the next swx_weights_finalize
+    *m->fold_state = false;   // the folded copies are stale until the next swx_weights_finalize (for every view of this arena)
     return 0;
 }
 
@@ -833,7 +808,7 @@ int swx_weights_finalize(swx_model *m, void *stream)
         SWX_TRY(swx_fold_ln(m->arena + w.wco, nullptr, nullptr, nullptr, m->arena + w.wco_p, nullptr, nullptr, d, d, s));
         SWX_TRY(swx_fold_ln(m->arena + w.w2, nullptr, nullptr, nullptr, m->arena + w.w2_p, nullptr, nullptr, d, 4 * d, s));
     }
-    m->folded = true;
+    *m->fold_state = true;
     return 0;
 }
 
@@ -874,6 +849,7 @@ size_t swx_workspace_bytes(const swx_model *m, int max_windows, int max_rows)
 
 int swx_bind_workspace(swx_model *m, void *d_ws, size_t bytes, int max_windows, int max_rows)
 {
+    if (m) m->drop_graphs();
     if (!m || !d_ws || max_windows <= 0 || max_rows <= 0) return -1;
     swx_model::WsLayout L;
     ws_layout(m, max_windows, max_rows, m->n_align, L);
@@ -968,7 +944,7 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
         a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * e; a.v = qkv + (size_t)2 * d * e; a.ldkv = 3 * d; a.o = att; a.ldo = d;
         a.k_bs = (int64_t)S_ * 3 * d; a.v_bs = a.k_bs; a.vt_kp = 0;
         a.B = B; a.H = H; a.nq = S_; a.nk = S_; a.q_rows_per_batch = S_;
-        if (m->dtype == SWX_F16 && !(g_debug_flags & SWX_FLAG_FLASH_V1)) {
+        if (m->dtype == SWX_F16) {
             // V of this layer transposed per head (one streaming pass, ~35 us for 20 windows): the flash kernel then stages both
             // operands with 16-byte vector stores; the `u` buffer (MLP hidden, 4d wide) is free until the MLP of this layer
             SWX_TRY(swx_transpose_v(a.v, 3 * d, a.v_bs, S_, u, SWX_VT_KP, (int64_t)H * 64 * SWX_VT_KP, B, H, s));
@@ -1065,6 +1041,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
     b.row_done = m->Wp<int32_t>(m->L.row_done);
     b.win_done = m->Wp<int32_t>(m->L.win_done); b.win_done_prev = m->Wp<int32_t>(m->L.win_done_prev);
     b.n_done = m->Wp<int32_t>(m->L.n_done);
+    b.step_dev = b.n_done + 1;
     b.fin_tokens = m->Wp<int32_t>(m->L.fin_tokens); b.fin_score = m->Wp<float>(m->L.fin_score);
     b.fin_len = m->Wp<int32_t>(m->L.fin_len); b.fin_count = m->Wp<int32_t>(m->L.fin_count);
     b.cand_lp = m->Wp<float>(m->L.cand_lp); b.cand_tok = m->Wp<int32_t>(m->L.cand_tok);
@@ -1087,6 +1064,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
         if (eu != hipSuccess) return -100 - (int)eu;
         b.win_uid = d_uid;
     }
+    b.cfg.window_uid = nullptr;          // a host pointer: the kernels read the device copy (b.win_uid) only
     hipError_t er = hipMemsetAsync(b.win_done_prev, 0, (size_t)W * 4, s);
     if (er != hipSuccess) return -100 - (int)er;
 
@@ -1115,32 +1093,68 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
     int cur = 0, steps = 0;
     int32_t h_done = 0;
     const int CHECK = 8;
-    for (int i = 0; i < cfg->sample_len; ++i) {
-        SWX_TRY(swx_decode_select(b, i, cur, s));
-        if (cfg->beam) cur ^= 1;
+    // One unit of the loop = [forward pass of the rows' newest tokens -> final LayerNorm -> logits] + [selection of token i].
+    // Token 0 is selected from the prefill logits; after every selection the loop's exit conditions are looked at:
+    // context full (decode.py:60), every window done (one host sync every CHECK steps), budget used up.
+    auto unit = [&](int cur_in, hipStream_t st) -> int {
+        FwdCfg g{};
+        g.W = W; g.rpw = G; g.row_mul = 1; g.n_new = 1;
+        g.tokens = b.tokens[cur_in]; g.ld_tok = b.TS; g.pos0 = b.pos0;
+        g.kcache = f.kcache; g.vcache = f.vcache; g.layer_stride = layer_stride; g.cache_rows = m->max_rows;
+        g.anc = use_anc ? b.anc[cur_in] : nullptr; g.xkv = (const unsigned char *)d_xkv; g.capture = false;
+        const int fr = decoder_forward(m, g, st);
+        if (fr < 0) return fr;
+        unsigned char *hh = m->ws + m->L.h;
+        if (fr == 0)   // the step leaves the raw residual stream in x
+            SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, M, d, st));
+        SWX_TRY(logits_gemm(m, hh, d, M, b.logits, st));
+        return swx_decode_select(b, cur_in, st);
+    };
+    // returns 1 when the loop ends after the selection of token i
+    auto after_select = [&](int i) -> int {
         steps = i + 1;
-        if (n_init + i + 1 > D.n_text_ctx) break;          // tokens.shape[-1] > n_ctx (decode.py:60)
+        if (n_init + i + 1 > D.n_text_ctx) return 1;          // tokens.shape[-1] > n_ctx (decode.py:60)
         // early-exit poll (one host sync); pointless while EOT is still suppressed by min_tokens
         if ((steps % CHECK == 0 && steps >= cfg->min_tokens) || steps == cfg->sample_len) {
             er = hipMemcpyAsync(&h_done, b.n_done, 4, hipMemcpyDeviceToHost, s);
             if (er != hipSuccess) return -100 - (int)er;
             er = hipStreamSynchronize(s);
             if (er != hipSuccess) return -100 - (int)er;
-            if (h_done >= W) break;
+            if (h_done >= W) return 1;
         }
-        if (i + 1 >= cfg->sample_len) break;
-        // ---- one decoder step for all M rows
-        FwdCfg g{};
-        g.W = W; g.rpw = G; g.row_mul = 1; g.n_new = 1;
-        g.tokens = b.tokens[cur]; g.ld_tok = b.TS; g.pos0 = b.pos0;
-        g.kcache = f.kcache; g.vcache = f.vcache; g.layer_stride = layer_stride; g.cache_rows = m->max_rows;
-        g.anc = use_anc ? b.anc[cur] : nullptr; g.xkv = (const unsigned char *)d_xkv; g.capture = false;
-        const int fr = decoder_forward(m, g, s);
-        if (fr < 0) return fr;
-        unsigned char *hh = m->ws + m->L.h;
-        if (fr == 0)   // the fast step leaves ln(x) in h already
-            SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, M, d, s));
-        SWX_TRY(logits_gemm(m, hh, d, M, b.logits, s));
+        return i + 1 >= cfg->sample_len ? 1 : 0;
+    };
+    SWX_TRY(swx_decode_select(b, cur, s));
+    if (cfg->beam) cur ^= 1;
+    int stop = after_select(0);
+    if (stop < 0) return stop;
+    // Units 2k, 2k+1 (k >= 1) are replayed from ONE captured graph: a step is ~290 kernel launches, which the host cannot issue
+    // as fast as the device retires them below ~50 rows (sequential transcribe(): 5 rows).  Everything that differs between two
+    // steps is device state (token buffers, positions, ancestor tables, the step counter); the token-buffer parity returns
+    // to its start after two steps.  The poll above only falls after odd units, the context check is made for both units up front.
+    const bool graph_ok = !g_prof_enabled && !(g_debug_flags & SWX_FLAG_NO_GRAPH) && !m->graphs_off;
+    swx_model::StepGraph *sg = nullptr;
+    for (int i = 1; !stop; ) {
+        const bool pair = graph_ok && !m->graphs_off && i >= 2 && (i & 1) == 0 && i + 1 < cfg->sample_len && n_init + i + 1 <= D.n_text_ctx;
+        if (pair) {
+            if (!sg) sg = step_graph(m, b, d_xkv, cur, [&](hipStream_t cs) -> int {
+                SWX_TRY(unit(cur, cs));
+                return unit(cfg->beam ? cur ^ 1 : cur, cs);
+            });
+            if (sg && hipGraphLaunch(sg->exec, s) == hipSuccess) {
+                stop = after_select(i + 1);
+                if (stop < 0) return stop;
+                i += 2;
+                continue;
+            }
+            (void)hipGetLastError();
+            m->graphs_off = true;            // capture or replay is not available here: eager for the rest of this handle's life
+        }
+        SWX_TRY(unit(cur, s));
+        if (cfg->beam) cur ^= 1;
+        stop = after_select(i);
+        if (stop < 0) return stop;
+        ++i;
     }
     const int G_out = swx_decode_gout(cfg);
     SWX_TRY(swx_decode_finalize(b, cur, steps, d_tokens_out, d_lens_out, d_sumlp_out, G_out, s));
@@ -1305,25 +1319,6 @@ int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, cons
     GemmArgs g = gemm_args(d_a, lda, d_w, K, d_bias, d_c, ldc, M, N, K, epilogue);
     g.R = d_res; g.ldr = ldc;
     return swx_gemm(dtype, g, force_kernel, S(stream));
-}
-
-int swx_test_gemm_splitk(const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
-                         void *d_c, int64_t ldc, const float *d_ln_g, const float *d_ln_b, void *d_ln_out,
-                         int M, int N, int K, int epilogue, void *stream)
-{
-    static float *slabs = nullptr;            // grown on demand, kept for the life of the process (test hook)
-    static size_t slab_floats = 0;
-    const size_t need = swx_skinny_slab_floats(M, N, K);
-    if (need == 0) return -4;
-    if (need > slab_floats) {
-        if (slabs) (void)hipFree(slabs);
-        if (hipMalloc((void **)&slabs, need * sizeof(float) + 256) != hipSuccess) { slabs = nullptr; slab_floats = 0; return -2; }
-        slab_floats = need;
-    }
-    FinishArgs f{};
-    f.bias = d_bias; f.epi = epilogue & (EPI_BIAS | EPI_GELU | EPI_RES); f.R = d_res; f.ldr = ldc; f.C = d_c; f.ldc = ldc;
-    f.ln_g = d_ln_g; f.ln_b = d_ln_b; f.ln_out = d_ln_out; f.ld_ln = N;
-    return swx_gemm_skinny_splitk(d_a, lda, d_w, K, M, N, K, slabs, f, S(stream));
 }
 
 int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float *d_gamma, const float *d_beta, const float *d_bias,

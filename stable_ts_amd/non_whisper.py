@@ -16,7 +16,7 @@ from typing import Callable, Optional, Union
 import numpy as np
 import torch
 
-from .stabilization import host_single_thread
+from .stabilization import _single_host_thread
 from .audio_io import (AudioLoader, audio_to_tensor_resample, check_source, get_samplerate, load_audio, reject_denoiser,
                        resample, to_s16, voice_freq_filter, write_wav)
 from .result import WhisperResult
@@ -39,7 +39,6 @@ def _wav_bytes(audio: torch.Tensor, sr: int) -> bytes:
         return f.getvalue()
 
 
-@host_single_thread
 def transcribe_any(inference_func: Callable, audio: Union[str, np.ndarray, torch.Tensor, bytes, AudioLoader],
                    audio_type: Optional[str] = None, input_sr: Optional[int] = None, model_sr: Optional[int] = None,
                    inference_kwargs: Optional[dict] = None, temp_file: Optional[str] = None, verbose: Optional[bool] = False,
@@ -146,10 +145,13 @@ def transcribe_any(inference_func: Callable, audio: Union[str, np.ndarray, torch
         if not isinstance(result, WhisperResult):
             result = WhisperResult(result, force_order=force_order, check_sorted=check_sorted)
         if suppress_silence:
-            result.adjust_by_silence(audio, vad, vad_onnx=vad_onnx, vad_threshold=vad_threshold, q_levels=q_levels,
-                                     k_size=k_size, sample_rate=current_sr(True), min_word_dur=min_word_dur,
-                                     word_level=suppress_word_ts, verbose=verbose, nonspeech_error=nonspeech_error,
-                                     use_word_position=use_word_position, min_silence_dur=min_silence_dur)
+            # this package's own host section (element-wise passes over the waveform): the intra-op pool is parked here and
+            # only here -- `inference_func` above ran with the caller's thread settings
+            with _single_host_thread():
+                result.adjust_by_silence(audio, vad, vad_onnx=vad_onnx, vad_threshold=vad_threshold, q_levels=q_levels,
+                                         k_size=k_size, sample_rate=current_sr(True), min_word_dur=min_word_dur,
+                                         word_level=suppress_word_ts, verbose=verbose, nonspeech_error=nonspeech_error,
+                                         use_word_position=use_word_position, min_silence_dur=min_silence_dur)
             result.set_current_as_orig()
         if result.has_words and regroup:
             result.regroup(regroup)

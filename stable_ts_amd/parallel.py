@@ -88,6 +88,38 @@ def _span_queue(n_items: int, step: int):
         yield first
 
 
+def _first_live_window(audio: torch.Tensor, *, suppress_silence=True, q_levels=20, k_size=5, min_word_dur=None,
+                       min_silence_dur=None, nonspeech_skip=None):
+    """The audio of the first fixed-stride 30-s window that transcribe(batch_size=N) would decode: windows the silence analysis
+    marks silent are skipped, a window that opens with a non-speech section >= nonspeech_skip is skipped, a later long section
+    cuts the window short (transcribe.py `window_input`, original_whisper.py:505-526)."""
+    import numpy as np
+    from .audio import N_SAMPLES, SAMPLE_RATE
+    from .stabilization import NonSpeechPredictor
+    mwd = 0.1 if min_word_dur is None else min_word_dur
+    predictor = NonSpeechPredictor(q_levels=q_levels, k_size=k_size, min_word_dur=mwd, min_silence_dur=min_silence_dur,
+                                   loudness=bool(suppress_silence))
+    for k in range(0, int(audio.shape[-1]), N_SAMPLES):
+        seg = audio[k:k + N_SAMPLES]
+        if not seg.numel():
+            continue
+        pred = predictor.predict(seg, offset=k / SAMPLE_RATE)
+        if pred["is_silent"]:
+            continue
+        if nonspeech_skip and pred["timings"] is not None:
+            starts = pred["timings"][0] - k / SAMPLE_RATE
+            ends = pred["timings"][1] - k / SAMPLE_RATE
+            long_idx = np.flatnonzero((ends - starts) >= nonspeech_skip)
+            if len(long_idx):
+                j = long_idx[0]
+                if starts[j] < mwd or int(starts[j] * SAMPLE_RATE) == 0:
+                    continue
+                seg = seg[: int(starts[j] * SAMPLE_RATE)]
+        if seg.numel():
+            return seg
+    return None
+
+
 def transcribe_sharded(model, audio: torch.Tensor, *, batch_size: int = 8, mode: str = "windows", spans_per_rank: int = 4,
                        work_queue: bool = True, lockstep: int = 2, **kw):
     """Transcription of ONE long recording over all ranks; the segments are gathered on rank 0 (returns a WhisperResult
@@ -132,15 +164,13 @@ def transcribe_sharded(model, audio: torch.Tensor, *, batch_size: int = 8, mode:
     kw = dict(kw)
     regroup = kw.pop("regroup", True)
     if not kw.get("language") and getattr(model, "is_multilingual", False):
-        # ONE language for the whole recording: every rank detects it on the same audio -- the first window that is not
-        # exact silence (what the single-GPU run settles on, original_whisper.py:319-336 / :532) -- so all ranks decode with
-        # the same tokenizer without a collective
-        first = None
-        for k in range(0, int(audio.shape[-1]), N_SAMPLES):
-            w = audio[k:k + N_SAMPLES]
-            if w.numel() and bool((w != 0).any()):
-                first = w
-                break
+        # ONE language for the whole recording, settled where the single-GPU window-parallel run settles it (transcribe.py
+        # `settle_language`, original_whisper.py:505-532): at the first window the silence analysis does not skip, on that
+        # window's audio as trimmed by nonspeech_skip.  Every rank runs the same analysis on the same audio, so all ranks
+        # decode with the same tokenizer without a collective.
+        first = _first_live_window(audio, suppress_silence=kw.get("suppress_silence", True), q_levels=kw.get("q_levels", 20),
+                                   k_size=kw.get("k_size", 5), min_word_dur=kw.get("min_word_dur"),
+                                   min_silence_dur=kw.get("min_silence_dur"), nonspeech_skip=kw.get("nonspeech_skip"))
         if first is not None:
             _, probs = model.detect_language(model.log_mel(first, N_SAMPLES - int(first.shape[-1])))
             kw["language"] = max(probs, key=probs.get)

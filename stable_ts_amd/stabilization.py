@@ -26,22 +26,36 @@ class _single_host_thread:
     throttled 45-65 ms at a time -- `align()` of a host waveform ran at 580x real time with them and 1 270x without
     (DESIGN.md section 5).  The operations are far too small to gain from threads, so they run on the calling thread."""
 
+    # torch.set_num_threads is process-wide for the intra-op pool: nested / concurrent uses are counted under a lock and only
+    # the outermost entry saves and the last exit restores the caller's setting
+    _lock = threading.Lock()
+    _depth = 0
+    _saved = 1
+
     def __enter__(self):
-        self.n = torch.get_num_threads()
-        if self.n != 1:
-            torch.set_num_threads(1)
+        cls = _single_host_thread
+        with cls._lock:
+            if cls._depth == 0:
+                cls._saved = torch.get_num_threads()
+                if cls._saved != 1:
+                    torch.set_num_threads(1)
+            cls._depth += 1
 
     def __exit__(self, *exc):
-        if self.n != 1:
-            torch.set_num_threads(self.n)
+        cls = _single_host_thread
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._saved != 1:
+                torch.set_num_threads(cls._saved)
         return False
 
 
 def host_single_thread(fn):
-    """Decorator of the public entry points (model.transcribe / align / align_words / refine / locate / transcribe_spans):
-    everything this package computes on the host is small (token bookkeeping, 1501-point loudness curves, index lists); the
-    arithmetic is on the GPU.  torch's intra-op pool is therefore parked for the duration of the call (and restored after),
-    for the reason given at `_single_host_thread`."""
+    """Decorator of the entry points whose arithmetic is all on the GPU (model.transcribe / align / align_words / refine / locate /
+    transcribe_spans): everything this package computes on the host there is small (token bookkeeping, 1501-point loudness
+    curves, index lists).  torch's intra-op pool is parked for the duration of the call (and restored after), for the reason
+    given at `_single_host_thread`.  NOT used on `transcribe_any`: its `inference_func`, denoisers and callbacks are the
+    caller's code and may well be CPU torch models -- there only this package's own silence analysis parks the pool."""
     @functools.wraps(fn)
     def wrapped(*args, **kw):
         # a model object that does its arithmetic on the host (the CPU stand-in of the test-suite: tests/oracle_engine.py)
@@ -137,7 +151,9 @@ def loudness_from_probe(n: int, thr: float, idx: np.ndarray, vals: torch.Tensor)
     if x is None:
         if len(cache) > 4:
             cache.clear()
-        x = cache[n] = torch.full((n,), float("nan"), dtype=torch.float32)
+        x = torch.full((n,), float("nan"), dtype=torch.float32)
+        if n <= 2 * 480000:                    # only window-sized scratch is kept (<= 3.8 MB each, five per thread)
+            cache[n] = x
     x[torch.from_numpy(idx.astype(np.int64))] = vals / min(1.0, float(thr_t) * 1.75)
     out = F.interpolate(x[None, None], size=units, mode="linear", align_corners=False)[0, 0]
     if bool(torch.isnan(out).any()):
@@ -203,7 +219,9 @@ class NonSpeechPredictor:
     def predict(self, audio: Optional[torch.Tensor], offset: float = 0.0, *, loud=False) -> dict:
         """``loud``: the loudness curve of the window from the device probe (``loudness_from_probe``; None = window too short
         for a mask); with it ``audio`` is not read."""
-        if loud is False and self.loudness and audio is not None and audio.is_cuda:
+        if loud is False and self.loudness and audio is not None and audio.is_cuda and audio.numel() <= 2 * 480000:
+            # (windows only: a whole recording handed in on the device takes the full-length path below -- the probe's NaN-filled
+            # scratch of the window length is cached per thread, which is fine for 1.9 MB and not for an hour of samples)
             # a window that is resident on the GPU: k-th largest level + the samples the curve reads come from the device
             # probe (24 KB instead of a 1.9 MB copy-out and a host selection); same values, same arithmetic
             from .engine import loudness_probe

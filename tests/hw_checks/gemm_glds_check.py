@@ -1,7 +1,6 @@
-"""Hardware check of the direct-to-LDS tiled GEMM (gemm_f16_glds<SINGLE, OCC>, force_kernel = 5 double buffered, 6 / 7
-single buffered at 4 / 3 workgroups per CU; 7 is the default, which picks 64-column tiles for shapes with few tiles:
-8 / 9 = always / never): each runs the same MFMA sequence per accumulator as
-gemm_f16_tiled (force_kernel = 1), so all must agree BIT FOR BIT; they are also held to a CPU float64 reference.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
+"""Hardware check of the direct-to-LDS tiled GEMM (gemm_f16_glds_128 / _64; force_kernel 7 = the default dispatch, which picks
+64-column tiles for shapes with few tiles, 8 / 9 = 64-column tiles always / never): each runs the same MFMA sequence per
+accumulator as the register-staged gemm_f16_tiled (force_kernel = 1), so all must agree BIT FOR BIT; they are also held to a CPU float64 reference.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
 
     python tests/hw_checks/gemm_glds_check.py
 """
@@ -34,7 +33,7 @@ def main() -> int:
         bias = torch.randn(N, generator=g).float().to(dev)
         res = torch.randn(M, N, generator=g).half().to(dev)
         outs = []
-        for force in (1, 5, 6, 7, 8, 9):
+        for force in (1, 7, 8, 9):
             c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
             rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), p(res) if epi & EPI_RES else None, p(c), N, M, N, K, epi, force, st)
             torch.cuda.synchronize()
@@ -47,7 +46,7 @@ def main() -> int:
         if epi & EPI_RES:
             ref = ref + res.cpu().double()
         (rc1, c1), (rc4, c4) = outs[0], outs[1]
-        same = rc1 == 0 and all(rc == 0 and torch.equal(c1, c) for rc, c in outs[1:])     # 5 / 6 / 7: generation-2 variants
+        same = rc1 == 0 and all(rc == 0 and torch.equal(c1, c) for rc, c in outs[1:])     # 7 / 8 / 9: the direct-to-LDS kernel at both tile widths
         err = ((c4.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max().item() if rc4 == 0 else float("inf")
         ok = same and err < 4e-3
         print(("ok   " if ok else "FAIL ") + f"M={M} N={N} K={K} epi={epi}: rc={rc1},{rc4} identical to tiled={same} max rel err vs CPU f64 {err:.2e}")

@@ -118,7 +118,7 @@ def _words_both(st, text, num_samples=480000):
     ti, tj = job.debug["path"]
     p_ref = np.asarray(cache["text_token_probs"], dtype=np.float64)
     p_got = np.asarray(job.debug["token_probs"], dtype=np.float64)[:len(p_ref)]
-    mid = (p_ref > 1e-6) & (p_ref < 0.99)                       # unsaturated probabilities only (p ~ 1 hides any error)
+    mid = (p_ref > 1e-30) & (p_ref < 0.99)                       # unsaturated probabilities only (p ~ 1 hides any error)
     dt = np.asarray([(abs(a.start - b.start), abs(a.end - b.end)) for a, b in zip(words, ref_words)])
     # frames by which the two DTW paths differ, per text-token row (first frame of each row)
     first = lambda i, j: {int(r): int(c) for r, c in reversed(list(zip(i.tolist(), j.tolist())))}

@@ -120,7 +120,7 @@ def _kernel_meta(src_name):
 
 @pytest.mark.parametrize("src,kernels,max_vgpr", [
     # the default tiled GEMMs: three workgroups per CU need <= 168 VGPRs and <= 53 KB of LDS each
-    ("swx_gemm.hip", ["gemm_f16_glds_s3_128", "gemm_f16_glds_s3_64"], 168),
+    ("swx_gemm.hip", ["gemm_f16_glds_128", "gemm_f16_glds_64"], 168),
     # DTW generation 3 (x chunks in registers) and the register-resident logit filters (1024 threads: <= 128 VGPRs)
     ("swx_dtw.hip", ["swx_dtw4_kernelILi1ELb1E", "swx_dtw4_kernelILi2ELb0E"], 256),
     ("swx_decode.hip", ["decode_select_reg_kernel"], 128),
@@ -133,5 +133,5 @@ def test_hot_kernels_do_not_spill(src, kernels, max_vgpr):
         for n, v in hits.items():
             assert v["private_segment_fixed_size"] == 0, (n, v)            # no scratch: nothing spilled
             assert v["vgpr_count"] <= max_vgpr, (n, v)
-            if "glds_s3" in n:
+            if "gemm_f16_glds" in n:
                 assert v["group_segment_fixed_size"] <= 53 * 1024, (n, v)
