@@ -50,7 +50,7 @@ size_t swx_weights_bytes(const swx_model *m);
 int swx_bind_weights(swx_model *m, void *d_arena, size_t bytes);
 /* a further handle (same dims and dtype) on the arena of `owner`, which stays the owner of the memory: the weights are
  * shared, nothing is cleared; each handle has its own workspace, alignment heads and stream, so host threads can drive
- * them concurrently (stream lanes) or with different head sets (the every-head view of swx_score_qk) */
+ * them concurrently (stream lanes) or with different head sets */
 int swx_share_weights(swx_model *m, const swx_model *owner);
 /* copy one checkpoint tensor (upstream state_dict key, fp32, device memory) into its packed slot,
  * converting/re-laying it out (QKV fusion, conv tap-major layout, fp16 cast) on the device */
@@ -154,14 +154,40 @@ int swx_score(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int
               float *d_token_probs, float *d_neg_matrix, void *stream);
 
 /* raw attention scores of the configured alignment heads from the same teacher-forced pass (what timing.py:41-67
- * _compute_qks hooks out of every cross-attention layer), for the head-selection variants of the alignment stage that
- * work on per-head scores: dynamic heads (timing.py:87-103), the 'new' aligner (timing.py:115-163).  Configure the
- * handle with every (layer, head) pair to get all heads.
+ * _compute_qks hooks out of every cross-attention layer): a test / inspection hook since round 3 -- the head-selection variants
+ * no longer materialise per-head scores (swx_score_q / swx_heads_* below).
  *  d_qk f32 [W][n_align][n_rows][1500]: (q * scale) . (k * scale) of token rows row0 .. row0+n_rows-1 (row0 + n_rows <= max_n),
  *       heads in the order of swx_set_alignment_heads sorted by (layer, head); pre-softmax, qk_scale not applied
  *  d_token_probs as in swx_score, or NULL */
 int swx_score_qk(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int n_sot, int eot,
                  int row0, int n_rows, const void *d_xkv, float *d_token_probs, float *d_qk, void *stream);
+
+/* ---- head-selection variants of the alignment stage (reference: stable_whisper/timing.py:87-103 `dynamic_heads`,
+ * :115-163 `aligner='new'`, :177-189 `extra_models`; csrc/swx_headsel.hip).  The reference hooks the scores of EVERY head out
+ * of the pass ([L*H][tokens][1500] f32, 0.4-1.7 GB for large-v3) and runs tensor expressions over them; here the pass keeps
+ * the cross-attention QUERIES of every layer and the kernels recompute a head's score row from q and the window's cross-K.
+ *
+ * swx_score_q: the teacher-forced pass of ONE window (timing.py:41-67).  d_q receives [n_text_layer][max_n][d] in the compute
+ *   dtype (swx_qcap_bytes); d_token_probs as in swx_score (or NULL); d_xkv = the cross-K/V of that single window.
+ * swx_heads_dynamic: rows row0 .. row0+n_rows-1; per row the `count` heads with the smallest sum_f |peak - f| / 1500 * p[f]
+ *   (peak = the row's own argmax, or d_peaks[i] = the previous DTW pass's jump midpoint, f64); d_qk_sel f32
+ *   [count][n_rows][ld_f] receives their RAW scaled scores = the input of swx_align_weights (H = count, N = n_rows).
+ * swx_heads_new: over the n_tok rows: median filter -> * qk_scale -> softmax per head; score = w_colnorm * sum_f ||w[:, f]|| +
+ *   w_rownorm * sum_i ||w[i, :]|| - w_coverage * penalty; the topk heads, column-normalised and averaged; d_neg_matrix f32
+ *   [n_out][ld_f] receives MINUS that mean for rows row0 .. row0+n_out-1 (the DTW input).
+ * swx_weighted_sum: d_out[e] = sum_j h_coef[j] * h_xs[j][e] (n_in <= 8 device arrays): pooling several models' head means.
+ * d_scratch: swx_heads_scratch_bytes(m, max_n) of device memory; nothing is allocated inside. */
+size_t swx_qcap_bytes(const swx_model *m, int max_n);
+int swx_score_q(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int max_n, int n_sot, int eot,
+                const void *d_xkv, float *d_token_probs, void *d_q, void *stream);
+size_t swx_heads_scratch_bytes(const swx_model *m, int max_n);
+int swx_heads_dynamic(swx_model *m, const void *d_q, int max_n, int row0, int n_rows, const void *d_xkv, int n_frames,
+                      float qk_scale, int count, const double *d_peaks, float *d_qk_sel, int ld_f, void *d_scratch,
+                      size_t scratch_bytes, void *stream);
+int swx_heads_new(swx_model *m, const void *d_q, int max_n, int n_tok, int row0, int n_out, const void *d_xkv, int n_frames,
+                  float qk_scale, int medfilt_width, int topk, float w_colnorm, float w_rownorm, float w_coverage,
+                  float *d_neg_matrix, int ld_f, void *d_scratch, size_t scratch_bytes, void *stream);
+int swx_weighted_sum(const float *const *h_xs, const float *h_coef, int n_in, float *d_out, int64_t n, void *stream);
 
 /* full-sequence logits of a teacher-forced pass (model(mel, tokens) as used by refine/locate; also a test hook):
  * d_logits f32 [W][max_n][n_vocab].  Language detection (model.detect_language, original_whisper.py:329) is this call
@@ -208,6 +234,9 @@ int swx_prof_enable(int on);
  * flags < 0 only queries.  Returns the previous value. */
 int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);
+/* how swx_decode ran on this handle so far: out[0] = two-step graphs captured, out[1] = graph replays (2 decode steps each),
+ * out[2] = decode steps launched eagerly, out[3] = 1 if capture / replay failed once (the handle then launches eagerly) */
+int swx_graph_stats(const swx_model *m, int64_t *out);
 
 /* ---- building blocks exported for the parity tests (same kernels the calls above launch) */
 int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,

@@ -10,14 +10,14 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$C
-  ( timeout 500 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o pmc -- python $R/bench.py --steps 1 --warmup 0 --tokens 8 --no-cpu-baseline --no-roofline --no-f32 2>&1 | tail -2 ) > $R/gpurun_out/pmc_$C.log
+  ( timeout 500 rocprofv3 --pmc $C --kernel-trace -d /tmp/pmc_$C -o pmc -- python $R/bench.py --steps 1 --warmup 0 --tokens 8 --no-cpu-baseline --no-roofline --no-f32 --debug-flags 16384 2>&1 | tail -2 ) > $R/gpurun_out/pmc_$C.log
 done
 cd $R
 python - "$tag" <<'PY'
 import sqlite3, glob, json, sys, collections
 tag = sys.argv[1]
 CLASSES = [("gemm_dec_f16", "decode-step GEMM"), ("attn_decode_cross", "attn_decode_cross_f16"), ("gemm_f16_glds", "gemm_f16_tiled"),
-           ("gemm_f16_tiled", "gemm_f16_tiled"), ("attn_flash", "attn_flash_f16"), ("self_attn_fused", "self_attn (decode step)"),
+           ("gemm_f16_tiled", "gemm_f16_tiled"), ("attn_flash", "attn_flash_f16"), ("self_attn_step", "self_attn (decode step)"),
            ("decode_select", "decode_select"), ("dec_slab_finish", "splitk_finish / layernorm"), ("layernorm_kernel", "splitk_finish / layernorm"),
            ("swx_dtw", "dtw"), ("swx_align", "align_weights"), ("swx_mel", "mel")]
 per_kernel = collections.defaultdict(lambda: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
@@ -53,7 +53,7 @@ for name, g, n, fa, wa, b in rows:
             agg[cls][1] += n
             break
 out = {cls: {"bytes_per_launch": round(t / n), "launches_sampled": n,
-             "source": f"profiles/r02_pmc_{tag}.csv: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate kernel-trace passes, "
+             "source": f"profiles/r03_pmc_{tag}.csv: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate kernel-trace passes, "
                        "8 decode steps of the bench workload); FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, "
                        "MI355X_MICROARCH.md), KB -> bytes"} for cls, (t, n) in agg.items() if n}
 json.dump(out, open('gpurun_out/pmc_traffic.json', 'w'), indent=1)
@@ -65,4 +65,4 @@ scripts/rocprof_kernels.sh bench_$tag python $R/bench.py --steps 1 --warmup 1 --
 head -30 gpurun_out/bench_${tag}_kernels.csv
 echo "== smoke"; ( timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 )
 echo "== default bench line"; ( timeout 900 python bench.py 2>&1 | tail -1 ) | tee gpurun_out/bench_$tag.json | cut -c1-4000
-echo "== gpu suite"; ( timeout 1500 python -m pytest tests -m gpu -q -n 4 --timeout=900 2>&1 | tail -8 ) | tee gpurun_out/gpu_suite_$tag.log
+if [ -z "$SKIP_SUITE" ]; then echo "== gpu suite"; ( timeout 1500 python -m pytest tests -m gpu -q --timeout=900 2>&1 | tail -8 ) | tee gpurun_out/gpu_suite_$tag.log; fi

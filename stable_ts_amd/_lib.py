@@ -61,6 +61,14 @@ SYMBOLS = {
                           c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "swx_score_qk": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                              c_void_p, c_void_p, c_void_p]),
+    "swx_qcap_bytes": (c_size_t, [c_void_p, c_int]),
+    "swx_score_q": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "swx_heads_scratch_bytes": (c_size_t, [c_void_p, c_int]),
+    "swx_heads_dynamic": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p,
+                                  c_int, c_void_p, c_size_t, c_void_p]),
+    "swx_heads_new": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float, c_int, c_int, c_float,
+                              c_float, c_float, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "swx_weighted_sum": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "swx_forward_logits": (c_int, [c_void_p, c_void_p, POINTER(c_int32), c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "swx_align_weights_scratch_bytes": (c_size_t, [c_int, c_int, c_int]),
     "swx_align_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int32), c_float, c_int, c_void_p,
@@ -73,6 +81,7 @@ SYMBOLS = {
     "swx_prof_enable": (c_int, [c_int]),
     "swx_debug_flags": (c_int, [c_int]),
     "swx_prof_collect": (c_int, [POINTER(ctypes.c_double), c_int]),
+    "swx_graph_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "swx_test_gemm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                               c_int, c_int, c_int, c_void_p]),
     "swx_test_dec_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,

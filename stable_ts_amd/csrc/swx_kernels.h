@@ -148,5 +148,17 @@ int swx_mel_ragged_launch(const float *d_pcm, const int *d_lens, int B, const fl
                           const float *d_filters, int n_mels, float *d_mel, unsigned *d_gmax, int per_item_max,
                           hipStream_t s);
 
+// ---- swx_headsel.hip: the head-selection variants of the word-timestamp stage from the captured cross-attention queries
+//      qcap [L][max_n][d] and the window's cross-K (row layout, layer stride in elements); see the file header
+constexpr int SWX_HS_MAXF = 1536;
+int swx_headsel_dynamic_launch(int dtype, const void *qcap, int max_n, int d, int row0, int n_rows, const void *xkv,
+                               int64_t layer_stride, int L, int H, int F, int nk, float qk_scale, int count, const double *d_peaks,
+                               double *d_score, int32_t *d_sel, float *d_out, int out_ld_f, hipStream_t s);
+int swx_headsel_new_launch(int dtype, const void *qcap, int max_n, int d, int n, int row0, int n_out, const void *xkv,
+                           int64_t layer_stride, int L, int H, int F, float qk_scale, int medfilt_width, int topk, float w_col,
+                           float w_row, float w_cov, float *d_colnorm, float *d_score, int32_t *d_top, float *d_out, int out_ld_f,
+                           hipStream_t s);
+int swx_weighted_sum_launch(const float *const *h_xs, const float *h_coef, int n_in, float *d_out, int64_t n, hipStream_t s);
+
 // ---- swx_decode.hip
 struct DecodeState;   // device-resident bookkeeping, defined in swx_decode.hip

@@ -84,6 +84,7 @@ struct swx_model {
     uint64_t graph_clock = 0;
     hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream, which cannot capture)
     bool graphs_off = false;            // set when capture / replay failed once on this handle: eager from then on
+    int64_t n_captures = 0, n_replays = 0, n_eager_units = 0;      // swx_graph_stats
     void drop_graphs() {
         for (auto &g : graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
         graphs.clear();
@@ -352,6 +353,7 @@ struct FwdCfg {
     int32_t *anc;
     const unsigned char *xkv;
     bool capture; int cap_row0, cap_rows, cap_ld_n;
+    unsigned char *qcap;   // non-null: the cross-attention queries of every layer are copied here, [L][rows][d] (swx_score_q)
 };
 
 // One decoder step (n_new == 1) in fp16: un-split "dec" GEMMs (swx_decstep.hip) that finish their own outputs.
@@ -456,6 +458,10 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
         g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
         SWX_TRY(swx_gemm_dec(g, s));
+        if (f.qcap) {
+            hipError_t qe = hipMemcpyAsync(f.qcap + (size_t)l * rows * d * e, q, (size_t)rows * d * e, hipMemcpyDeviceToDevice, s);
+            if (qe != hipSuccess) return -100 - (int)qe;
+        }
         const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
         AttnArgs ca{};
         ca.q = q; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
@@ -518,6 +524,10 @@ int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
         // cross attention
         SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.lnx_g), m->A<float>(w.lnx_b), h, d, rows, d, s));
         SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wcq, d, m->A<float>(w.bcq), qkv, d, rows, d, d, EPI_BIAS), 0, s));
+        if (f.qcap) {
+            hipError_t qe = hipMemcpyAsync(f.qcap + (size_t)l * rows * d * e, qkv, (size_t)rows * d * e, hipMemcpyDeviceToDevice, s);
+            if (qe != hipSuccess) return -100 - (int)qe;
+        }
         // cross K/V of this layer: per window [K: 1500 x d row-major | V^T: d x SWX_VT_KP, keys contiguous]
         const int64_t chunk = xkv_chunk_elems(m);
         const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
@@ -574,6 +584,7 @@ swx_model::StepGraph *step_graph(swx_model *m, const DecodeBufs &b, const void *
     if (rc < 0 || er != hipSuccess || !ng.graph) { if (ng.graph) (void)hipGraphDestroy(ng.graph); return nullptr; }
     if (hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(ng.graph); return nullptr; }
     ng.key = std::move(key); ng.used = m->graph_clock;
+    ++m->n_captures;
     constexpr size_t MAX_GRAPHS = 8;
     if (m->graphs.size() >= MAX_GRAPHS) {       // least recently used entry makes room
         size_t lru = 0;
@@ -1142,6 +1153,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
                 return unit(cfg->beam ? cur ^ 1 : cur, cs);
             });
             if (sg && hipGraphLaunch(sg->exec, s) == hipSuccess) {
+                ++m->n_replays;
                 stop = after_select(i + 1);
                 if (stop < 0) return stop;
                 i += 2;
@@ -1151,6 +1163,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
             m->graphs_off = true;            // capture or replay is not available here: eager for the rest of this handle's life
         }
         SWX_TRY(unit(cur, s));
+        ++m->n_eager_units;
         if (cfg->beam) cur ^= 1;
         stop = after_select(i);
         if (stop < 0) return stop;
@@ -1166,7 +1179,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
 // ------------------------------------------------------------------------------------------------------ score
 // capture: raw qk of the alignment heads for token rows cap_row0 .. cap_row0 + cap_rows - 1 -> L.cap [W][n_align][cap_ld][1500]
 static int score_forward(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int W, int max_n, int cap_row0,
-                         int cap_rows, int cap_ld, const void *d_xkv, bool capture, hipStream_t s)
+                         int cap_rows, int cap_ld, const void *d_xkv, bool capture, hipStream_t s, void *qcap = nullptr)
 {
     const swx_dims &D = m->dims;
     if (W > m->max_windows) return -8;
@@ -1179,6 +1192,7 @@ static int score_forward(swx_model *m, const int32_t *d_tokens, const int32_t *h
     f.kcache = m->ws + m->L.sk; f.vcache = m->ws + m->L.sv; f.layer_stride = 0; f.cache_rows = m->max_windows;
     f.anc = nullptr; f.xkv = (const unsigned char *)d_xkv;
     f.capture = capture;
+    f.qcap = (unsigned char *)qcap;
     f.cap_row0 = cap_row0; f.cap_rows = cap_rows; f.cap_ld_n = cap_ld;
     if (capture && (cap_rows <= 0 || cap_row0 < 0 || cap_row0 + cap_rows > max_n || cap_ld < cap_rows)) return -1;
     return decoder_forward(m, f, s);
@@ -1284,6 +1298,97 @@ int swx_forward_logits(swx_model *m, const int32_t *d_tokens, const int32_t *h_n
     const int rows = W * max_n;
     SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(m->o_ln_g), m->A<float>(m->o_ln_b), hh, d, rows, d, s));
     return logits_gemm(m, hh, d, rows, d_logits, s);
+}
+
+// ------------------------------------------------------------------------------- head-selection variants (f4)
+// The teacher-forced pass of ONE window that keeps the cross-attention queries of every layer instead of any head's scores:
+// d_q [n_text_layer][max_n][d] in the compute dtype (swx_qcap_bytes).  timing.py:41-67 with the hooks of :50-56 replaced by
+// "keep q": a head's score row is q . K^T of the window's cross-K, which swx_cross_kv left in d_xkv.
+size_t swx_qcap_bytes(const swx_model *m, int max_n)
+{
+    if (!m || max_n <= 0) return 0;
+    return (size_t)m->dims.n_text_layer * max_n * m->dims.n_text_state * m->esz;
+}
+
+int swx_score_q(swx_model *m, const int32_t *d_tokens, const int32_t *h_n_tok, int max_n, int n_sot, int eot, const void *d_xkv,
+                float *d_token_probs, void *d_q, void *stream)
+{
+    if (!m || !m->arena || !m->ws) return -9;
+    if (!d_q || !d_tokens || !h_n_tok) return -1;
+    if (h_n_tok[0] - n_sot - 2 < 0) return -1;
+    hipStream_t s = S(stream);
+    SWX_TRY(score_forward(m, d_tokens, h_n_tok, 1, max_n, 0, 0, max_n, d_xkv, false, s, d_q));
+    if (d_token_probs) SWX_TRY(score_token_probs(m, d_tokens, 1, max_n, n_sot, eot, d_token_probs, s));
+    return 0;
+}
+
+// scratch of the two calls below: head scores (f64) and picks of every row, column norms / scores / picks of every head
+size_t swx_heads_scratch_bytes(const swx_model *m, int max_n)
+{
+    if (!m || max_n <= 0) return 0;
+    const size_t LH = (size_t)m->dims.n_text_layer * m->dims.n_text_head;
+    return align_up(LH * max_n * sizeof(double)) + align_up(LH * max_n * sizeof(int32_t)) + align_up(LH * SWX_HS_MAXF * sizeof(float)) +
+           align_up(LH * sizeof(float)) + align_up(LH * sizeof(int32_t));
+}
+
+// dynamic_heads (timing.py:87-103): rows row0 .. row0 + n_rows - 1 of the pass; d_qk_sel [count][n_rows][ld_f] f32 receives the RAW
+// scaled scores of the count heads picked per row -- the input layout of swx_align_weights (H = count, N = n_rows), which
+// applies qk_scale / softmax / z-normalisation / median / head mean exactly as on the default path.  d_peaks: null (every row's
+// own attention peak) or the n_rows jump midpoints of the previous DTW pass (f64).
+int swx_heads_dynamic(swx_model *m, const void *d_q, int max_n, int row0, int n_rows, const void *d_xkv, int n_frames, float qk_scale,
+                      int count, const double *d_peaks, float *d_qk_sel, int ld_f, void *d_scratch, size_t scratch_bytes, void *stream)
+{
+    if (!m || !m->arena) return -9;
+    if (!d_q || !d_xkv || !d_qk_sel || !d_scratch) return -1;
+    if (row0 < 0 || n_rows <= 0 || row0 + n_rows > max_n || ld_f < m->dims.n_audio_ctx) return -1;
+    if (scratch_bytes < swx_heads_scratch_bytes(m, max_n)) return -8;
+    const swx_dims &D = m->dims;
+    const size_t LH = (size_t)D.n_text_layer * D.n_text_head;
+    unsigned char *p = (unsigned char *)d_scratch;
+    double *score = (double *)p; p += align_up(LH * max_n * sizeof(double));
+    int32_t *sel = (int32_t *)p;
+    int F = n_frames < 1 ? 1 : (n_frames > D.n_audio_ctx ? D.n_audio_ctx : n_frames);
+    return swx_headsel_dynamic_launch(m->dtype, d_q, max_n, D.n_text_state, row0, n_rows, d_xkv, xkv_chunk_elems(m), D.n_text_layer,
+                                      D.n_text_head, F, D.n_audio_ctx, qk_scale, count, d_peaks, score, sel, d_qk_sel, ld_f, S(stream));
+}
+
+// aligner = 'new' (timing.py:115-163) over the n_tok rows of the pass; d_neg_matrix [n_out][ld_f] f32 receives MINUS the
+// column-normalised mean map of the topk sharpest heads for rows row0 .. row0 + n_out - 1 (= the DTW input, timing.py:194)
+int swx_heads_new(swx_model *m, const void *d_q, int max_n, int n_tok, int row0, int n_out, const void *d_xkv, int n_frames,
+                  float qk_scale, int medfilt_width, int topk, float w_colnorm, float w_rownorm, float w_coverage,
+                  float *d_neg_matrix, int ld_f, void *d_scratch, size_t scratch_bytes, void *stream)
+{
+    if (!m || !m->arena) return -9;
+    if (!d_q || !d_xkv || !d_neg_matrix || !d_scratch) return -1;
+    if (n_tok <= 0 || n_tok > max_n) return -1;
+    if (scratch_bytes < swx_heads_scratch_bytes(m, max_n)) return -8;
+    const swx_dims &D = m->dims;
+    const size_t LH = (size_t)D.n_text_layer * D.n_text_head;
+    unsigned char *p = (unsigned char *)d_scratch;
+    p += align_up(LH * max_n * sizeof(double)) + align_up(LH * max_n * sizeof(int32_t));
+    float *colnorm = (float *)p; p += align_up(LH * SWX_HS_MAXF * sizeof(float));
+    float *score = (float *)p; p += align_up(LH * sizeof(float));
+    int32_t *top = (int32_t *)p;
+    int F = n_frames < 1 ? 1 : (n_frames > D.n_audio_ctx ? D.n_audio_ctx : n_frames);
+    return swx_headsel_new_launch(m->dtype, d_q, max_n, D.n_text_state, n_tok, row0, n_out, d_xkv, xkv_chunk_elems(m), D.n_text_layer,
+                                  D.n_text_head, F, qk_scale, medfilt_width, topk, w_colnorm, w_rownorm, w_coverage, colnorm, score, top,
+                                  d_neg_matrix, ld_f, S(stream));
+}
+
+// d_out[e] = sum_j coef[j] * d_xs[j][e], n_in <= 8 (extra_models: the pooled matrix from each model's own head mean)
+int swx_weighted_sum(const float *const *h_xs, const float *h_coef, int n_in, float *d_out, int64_t n, void *stream)
+{
+    if (!h_xs || !h_coef || !d_out) return -1;
+    return swx_weighted_sum_launch(h_xs, h_coef, n_in, d_out, n, S(stream));
+}
+
+// how the decode loops of this handle ran so far: out[0] = step graphs captured, out[1] = two-step graph replays,
+// out[2] = steps launched eagerly, out[3] = 1 when capture / replay failed once and the handle fell back to eager launches
+int swx_graph_stats(const swx_model *m, int64_t *out)
+{
+    if (!m || !out) return -1;
+    out[0] = m->n_captures; out[1] = m->n_replays; out[2] = m->n_eager_units; out[3] = m->graphs_off ? 1 : 0;
+    return 0;
 }
 
 // ----------------------------------------------------------------------------- stand-alone alignment weights

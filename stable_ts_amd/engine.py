@@ -310,15 +310,71 @@ class Engine:
         p = probs.cpu().numpy()
         return [p[w, :n_tok[w] - n_sot - 2].astype(np.float64).tolist() for w in range(W)], qk
 
-    def all_heads(self) -> "Engine":
-        """An engine on the same weights whose alignment heads are ALL (layer, head) pairs in layer-major order, with a
-        one-window workspace (the capture buffer of 640 heads x 448 rows x 1500 frames is 1.7 GB for large-v3)."""
-        view = getattr(self, "_all_heads_view", None)
-        if view is None:
-            view = self.clone_shared(max_windows=1, max_rows=1)
-            view.set_alignment_heads([(l, h) for l in range(self.dims.n_text_layer) for h in range(self.dims.n_text_head)])
-            self._all_heads_view = view
-        return view
+    def graph_stats(self) -> dict:
+        """how the decode loops of this engine ran: captured step graphs, graph replays (two steps each), eager steps"""
+        out = (ctypes.c_int64 * 4)()
+        check(self.lib.swx_graph_stats(self.h, out), "swx_graph_stats")
+        return dict(captures=int(out[0]), replays=int(out[1]), eager_steps=int(out[2]), fell_back=bool(out[3]))
+
+    # ------------------------------------------------------------------ f4: head-selection variants (swx_headsel.hip)
+    def score_q(self, xkv: torch.Tensor, tokens: Sequence[int], *, n_sot: int, eot: int) -> dict:
+        """Teacher-forced pass of ONE window that keeps the cross-attention queries of every layer ([L, n, d], compute dtype)
+        instead of any head's scores: the head-selection kernels recompute score rows from them and the window's cross-K.
+        Returns the state the two calls below take (token probabilities included)."""
+        n = len(tokens)
+        self.reserve(max(1, self.max_windows), max(self.max_rows, 1))
+        d_tok = torch.tensor(np.asarray([list(tokens)], dtype=np.int32), device=self.device)
+        probs = torch.zeros(1, n, dtype=torch.float32, device=self.device)
+        q = torch.empty(self.lib.swx_qcap_bytes(self.h, n), dtype=torch.uint8, device=self.device)
+        check(self.lib.swx_score_q(self.h, _ptr(d_tok), _i32arr([n]), n, n_sot, eot, _ptr(xkv), _ptr(probs), _ptr(q), self.stream),
+              "swx_score_q")
+        scratch = torch.empty(self.lib.swx_heads_scratch_bytes(self.h, n), dtype=torch.uint8, device=self.device)
+        p = probs.cpu().numpy()
+        return dict(q=q, n=n, n_sot=n_sot, xkv=xkv, scratch=scratch, probs=p[0, :n - n_sot - 2].astype(np.float64).tolist())
+
+    def heads_dynamic(self, st: dict, n_frames: int, *, count: int, qk_scale: float = 1.0, medfilt_width: int = 7,
+                      jump_indices=None) -> torch.Tensor:
+        """timing.py:87-112 with ``dynamic_heads``: per text-token row the ``count`` heads of the whole decoder whose attention
+        mass lies nearest the row's expected frame, then the default z-normalisation / median / head mean.  Returns the NEGATED
+        matrix [T + 1, 1500] (f32, device)."""
+        n, n_sot = st["n"], st["n_sot"]
+        rows = n - n_sot - 1
+        F = int(n_frames)
+        ld_f = self.dims.n_audio_ctx
+        peaks = None
+        if jump_indices is not None:                                     # timing.py:96-98: midpoints of the previous pass's jumps
+            j = np.pad(np.asarray(jump_indices), (0, 1), constant_values=F)
+            peaks = torch.from_numpy(np.ascontiguousarray(j[:-1] + ((j[1:] - j[:-1]) * 0.5), dtype=np.float64)).to(self.device)
+            assert peaks.numel() == rows
+        sel = torch.empty(1, count, rows, ld_f, dtype=torch.float32, device=self.device)
+        check(self.lib.swx_heads_dynamic(self.h, _ptr(st["q"]), n, n_sot, rows, _ptr(st["xkv"]), F, float(qk_scale), int(count),
+                                         _ptr(peaks), _ptr(sel), ld_f, _ptr(st["scratch"]), st["scratch"].numel(), self.stream),
+              "swx_heads_dynamic")
+        return align_weights(sel, [F], qk_scale=qk_scale, medfilt_width=medfilt_width)[0]
+
+    def heads_new(self, st: dict, n_frames: int, *, qk_scale: float = 1.0, medfilt_width: int = 7, topk: int = 20,
+                  w_colnorm: float = 1, w_rownorm: float = 1, w_coverage: float = 0) -> torch.Tensor:
+        """timing.py:115-163 (``aligner='new'``): the ``topk`` sharpest heads of the whole decoder, column-normalised and
+        averaged.  Returns the NEGATED matrix of the text-token rows [T + 1, 1500] (f32, device)."""
+        n, n_sot = st["n"], st["n_sot"]
+        rows = n - n_sot - 1
+        ld_f = self.dims.n_audio_ctx
+        neg = torch.zeros(rows, ld_f, dtype=torch.float32, device=self.device)
+        check(self.lib.swx_heads_new(self.h, _ptr(st["q"]), n, n, n_sot, rows, _ptr(st["xkv"]), int(n_frames), float(qk_scale),
+                                     int(medfilt_width), int(topk), float(w_colnorm), float(w_rownorm), float(w_coverage),
+                                     _ptr(neg), ld_f, _ptr(st["scratch"]), st["scratch"].numel(), self.stream), "swx_heads_new")
+        return neg
+
+    def pool_matrices(self, negs: Sequence[torch.Tensor], n_heads: Sequence[int]) -> torch.Tensor:
+        """timing.py:177-189 (``extra_models``): the head mean over the heads of several models from each model's own (negated)
+        head mean: sum_m (H_m / sum H) * neg_m"""
+        assert 1 <= len(negs) <= 8 and all(x.shape == negs[0].shape and x.is_contiguous() for x in negs)
+        tot = float(sum(n_heads))
+        out = torch.empty_like(negs[0])
+        ptrs = (ctypes.c_void_p * len(negs))(*[x.data_ptr() for x in negs])
+        coef = (ctypes.c_float * len(negs))(*[h / tot for h in n_heads])
+        check(self.lib.swx_weighted_sum(ptrs, coef, len(negs), _ptr(out), out.numel(), self.stream), "swx_weighted_sum")
+        return out
 
     def median_filter(self, x: torch.Tensor, width: int) -> torch.Tensor:
         return median_filter(x, width)

@@ -7,10 +7,10 @@ swx_dtw.hip); what stays here is the token<->word bookkeeping, which is string w
 
 The default ('legacy') aligner with the model's alignment heads is one fused device call (``swx_score``).  The
 head-selection variants -- ``dynamic_heads`` (timing.py:87-103), ``aligner='new'`` (timing.py:115-163) and
-``extra_models`` (timing.py:177-189) -- work on per-head scores: the raw scores come from ``swx_score_qk`` (for the
-dynamic / new variants from an engine view configured with every head), the selection arithmetic is a handful of tensor
-expressions on that device tensor written exactly as the reference writes them, the median filter and the DTW are the
-same kernels as on the default path.
+``extra_models`` (timing.py:177-189) -- are kernels too since round 3 (csrc/swx_headsel.hip): the pass keeps the
+cross-attention queries of every layer (``swx_score_q``, 8-37 MB) instead of every head's scores (0.4-1.7 GB in the
+reference), a head's score row is recomputed from q and the resident cross-K where it is needed; z-normalisation, median
+filter, head mean and DTW are the kernels of the default path.
 """
 import string
 from dataclasses import dataclass
@@ -159,67 +159,12 @@ def parse_dynamic_heads(dynamic_heads) -> tuple:
     return int(k), int(n)
 
 
-def _znorm_medfilt(eng, weights, medfilt_width: int):
-    """timing.py:108-110: normalise every (head, frame) column over the tokens (population std), median over frames"""
-    import torch
-    std, mean = torch.std_mean(weights, dim=-2, keepdim=True, unbiased=False)
-    return eng.median_filter((weights - mean) / std, medfilt_width)
-
-
-def _legacy_head_weights(eng, xkv_w, job: AlignmentJob, n_sot: int, eot: int, qk_scale: float, medfilt_width: int,
-                         dynamic_count: Optional[int], jump_indices: Optional[np.ndarray]):
-    """``_compute_atten_weights`` (timing.py:70-112) for one window on one model.  Returns (token probabilities, weights
-    [heads, T+1, frames]).  With ``dynamic_count`` the heads are picked per token from ALL heads: those whose attention
-    mass lies closest to the token's expected frame (its own peak, or the previous pass's jump midpoints)."""
-    import torch
-    n = len(job.tokens)
-    F = job.n_frames
-    src = eng.all_heads() if dynamic_count else eng
-    probs, qk = src.score_qk(xkv_w, [job.tokens], n_sot=n_sot, eot=eot, row0=n_sot, n_rows=n - n_sot - 1)
-    qk = (qk[0, :, :, :F] * qk_scale).softmax(dim=-1)                                   # [heads, T+1, F]
-    if not dynamic_count:
-        return probs[0], _znorm_medfilt(eng, qk, medfilt_width)
-    if jump_indices is None:
-        peaks = qk.topk(1, dim=-1).indices
-    else:
-        j = np.pad(jump_indices, (0, 1), constant_values=F)
-        peaks = torch.from_numpy(j[:-1] + ((j[1:] - j[:-1]) * 0.5)).to(qk.device)[None, :, None]
-    distances = (peaks.expand_as(qk) - torch.arange(qk.size(-1), device=qk.device)).abs() / 1500
-    scores = (distances * qk).sum(dim=-1)
-    heads = [sc.topk(dynamic_count, largest=False).indices for sc in scores.T]
-    weights = torch.stack([qk[h, i] for i, h in enumerate(heads)], dim=1)
-    return probs[0], _znorm_medfilt(eng, weights, medfilt_width)
-
-
-def _new_aligner_matrix(eng, xkv_w, job: AlignmentJob, n_sot: int, eot: int, qk_scale: float, medfilt_width: int,
-                        topk: int = 20, w_colnorm: float = 1, w_rownorm: float = 1, w_coverage: float = 0):
-    """``_compute_atten_weights_new`` (timing.py:115-163, arXiv:2509.09987): the ``topk`` heads of the whole decoder
-    with the sharpest attention maps (column / row norms, optional coverage penalty), column-normalised and averaged."""
-    import torch
-    n = len(job.tokens)
-    L, H = eng.dims.n_text_layer, eng.dims.n_text_head
-    probs, qk = eng.all_heads().score_qk(xkv_w, [job.tokens], n_sot=n_sot, eot=eot, row0=0, n_rows=n)
-    w = qk[0].reshape(L, H, n, -1)[..., :job.n_frames]
-    w = (eng.median_filter(w, medfilt_width) * qk_scale).softmax(dim=-1)
-    score = torch.zeros(L, H, device=w.device)
-    if w_colnorm > 0:
-        score += w_colnorm * w.norm(dim=-2).sum(-1)
-    if w_rownorm > 0:
-        score += w_rownorm * w.norm(dim=-1).sum(-1)
-    if w_coverage > 0:
-        coverage = torch.sum(w, dim=2)
-        penalty = torch.max(coverage, coverage.clone().fill_(0.5)).sum(-1) - coverage.size(-1) * 0.5
-        score -= w_coverage * penalty
-    top = score.flatten().topk(topk).indices
-    m = w[top // H, top % H]
-    m = torch.mean(m / m.norm(dim=-2, keepdim=True), 0)
-    return probs[0], m[n_sot:-1]
-
-
 def _find_alignment_variants(model, jobs, xkv, *, medfilt_width, qk_scale, dynamic_heads, aligner, extra_models, mel,
                              return_debug):
-    """timing.py:166-198 + 202-306 for the head-selection variants, one window at a time."""
-    import torch
+    """timing.py:166-198 + 202-306 for the head-selection variants, one window at a time.  The per-head arithmetic runs in
+    csrc/swx_headsel.hip through the engine: ``score_q`` (the pass, keeping the cross-attention queries), ``heads_dynamic``
+    (timing.py:87-112), ``heads_new`` (timing.py:115-163), ``pool_matrices`` (timing.py:177-189); what stays here is the
+    control flow of the reference (which models, how many refinement iterations, which probabilities are averaged)."""
     from .transcribe import _xkv_select
     assert isinstance(aligner, dict) or aligner in ("new", "legacy"), f'aligner must be "new"/"legacy", got "{aligner}"'
     if extra_models and (bad := set(map(type, extra_models)) - {type(model)}):
@@ -235,30 +180,42 @@ def _find_alignment_variants(model, jobs, xkv, *, medfilt_width, qk_scale, dynam
         if mel is None:
             raise ValueError("extra_models need the windows' log-mel (each model encodes the audio itself)")
         extras = [(m, m.cross_kv(m.encoder(mel))) for m in extra_models]
+
+    def legacy_matrix(m, xkv_w, job, state, jump):
+        """one model's NEGATED head mean for the text-token rows + its token probabilities + how many heads went into it"""
+        eng = m.engine
+        if count:
+            st = state.get(id(m)) or state.setdefault(id(m), eng.score_q(xkv_w, job.tokens, n_sot=n_sot, eot=eot))
+            neg = eng.heads_dynamic(st, job.n_frames, count=count, qk_scale=qk_scale, medfilt_width=medfilt_width, jump_indices=jump)
+            return neg, st["probs"], count
+        p, neg, T = eng.score(xkv_w, [job.tokens], [job.n_frames], n_sot=n_sot, eot=eot, qk_scale=qk_scale, medfilt_width=medfilt_width)
+        return neg[0, :T[0] + 1].contiguous(), p[0], eng.n_alignment_heads
+
     out = []
     for w, job in enumerate(jobs):
         eng = model.engine
         xkv_w = _xkv_select(model, xkv, [w])
-        jump, probs = None, None
+        jump, probs, state = None, None, {}
         for _ in range(iterations or 1):
             if new:
-                p, matrix = _new_aligner_matrix(eng, xkv_w, job, n_sot, eot, qk_scale, medfilt_width,
-                                                **(aligner if isinstance(aligner, dict) else {}))
-                probs = p
+                st = state.get("new") or state.setdefault("new", eng.score_q(xkv_w, job.tokens, n_sot=n_sot, eot=eot))
+                neg = eng.heads_new(st, job.n_frames, qk_scale=qk_scale, medfilt_width=medfilt_width,
+                                    **({k: v for k, v in aligner.items()} if isinstance(aligner, dict) else {}))
+                probs = st["probs"]
             else:
-                p, weights = _legacy_head_weights(eng, xkv_w, job, n_sot, eot, qk_scale, medfilt_width, count, jump)
+                neg, p, n_heads = legacy_matrix(model, xkv_w, job, state, jump)
                 probs = p if probs is None else probs          # the main model's pass is cached across iterations
                 if extras:
-                    stacks, extra_probs = [weights], []
+                    negs, heads, extra_probs = [neg], [n_heads], []
                     for m, xkv_m in extras:
-                        pe, we = _legacy_head_weights(m.engine, _xkv_select(m, xkv_m, [w]), job, n_sot, eot, qk_scale,
-                                                      medfilt_width, count, None)
-                        stacks.append(we)
+                        ne, pe, he = legacy_matrix(m, _xkv_select(m, xkv_m, [w]), job, state, None)
+                        negs.append(ne)
+                        heads.append(he)
                         extra_probs.append(pe)
-                    weights = torch.cat(stacks, dim=0)
-                    probs = torch.tensor(extra_probs + [probs]).mean(dim=0).tolist()       # timing.py:183-189
-                matrix = weights.mean(dim=0)
-            neg = (-matrix).contiguous()[None]
+                    neg = eng.pool_matrices(negs, heads)
+                    import torch
+                    probs = torch.tensor(extra_probs + [probs]).mean(dim=0).tolist()       # timing.py:183-189 (host, a few floats)
+            neg = neg[None, :, :job.n_frames].contiguous() if neg.shape[-1] != job.n_frames else neg[None].contiguous()
             (text_idx, time_idx), = eng.dtw(neg, [neg.shape[1]], [neg.shape[2]])
             jumps = np.pad(np.diff(text_idx), (1, 0), constant_values=1).astype(bool)
             jump = time_idx[jumps].clip(min=0)

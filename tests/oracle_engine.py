@@ -154,6 +154,63 @@ class OracleEngine:
         view._every_head = True
         return view
 
+    @property
+    def n_alignment_heads(self):
+        return int(self.m.alignment_heads.indices().shape[1])
+
+    # ---- the head-selection variants (product: csrc/swx_headsel.hip through Engine.score_q / heads_dynamic / heads_new /
+    #      pool_matrices).  The stand-in computes them the way the REFERENCE writes them (timing.py:87-163) from every head's
+    #      scores, so the CPU tests compare the product's control flow with the reference's on identical arithmetic.
+    def score_q(self, xkv, tokens, *, n_sot, eot):
+        n = len(tokens)
+        probs, qk = self.all_heads().score_qk(xkv, [list(tokens)], n_sot=n_sot, eot=eot, row0=0, n_rows=n)
+        return dict(qk=qk[0], n=n, n_sot=n_sot, probs=probs[0])
+
+    def heads_dynamic(self, st, n_frames, *, count, qk_scale=1.0, medfilt_width=7, jump_indices=None):
+        n, n_sot, F = st["n"], st["n_sot"], int(n_frames)
+        qk = (st["qk"][:, n_sot:n - 1, :F] * qk_scale).softmax(dim=-1)                     # [heads, T+1, F]
+        if jump_indices is None:
+            peaks = qk.topk(1, dim=-1).indices
+        else:
+            j = np.pad(np.asarray(jump_indices), (0, 1), constant_values=F)
+            peaks = torch.from_numpy(j[:-1] + ((j[1:] - j[:-1]) * 0.5))[None, :, None]
+        distances = (peaks.expand_as(qk) - torch.arange(qk.size(-1))).abs() / 1500
+        scores = (distances * qk).sum(dim=-1)
+        heads = [sc.topk(count, largest=False).indices for sc in scores.T]
+        weights = torch.stack([qk[h, i] for i, h in enumerate(heads)], dim=1)
+        std, mean = torch.std_mean(weights, dim=-2, keepdim=True, unbiased=False)
+        neg = torch.zeros(weights.shape[1], self.dims.n_audio_ctx)
+        neg[:, :F] = -self.median_filter((weights - mean) / std, medfilt_width).mean(dim=0)
+        return neg
+
+    def heads_new(self, st, n_frames, *, qk_scale=1.0, medfilt_width=7, topk=20, w_colnorm=1, w_rownorm=1, w_coverage=0):
+        n, n_sot, F = st["n"], st["n_sot"], int(n_frames)
+        L, H = self.dims.n_text_layer, self.dims.n_text_head
+        w = st["qk"].reshape(L, H, n, -1)[..., :F]
+        w = (self.median_filter(w, medfilt_width) * qk_scale).softmax(dim=-1)
+        score = torch.zeros(L, H)
+        if w_colnorm > 0:
+            score += w_colnorm * w.norm(dim=-2).sum(-1)
+        if w_rownorm > 0:
+            score += w_rownorm * w.norm(dim=-1).sum(-1)
+        if w_coverage > 0:
+            coverage = torch.sum(w, dim=2)
+            penalty = torch.max(coverage, coverage.clone().fill_(0.5)).sum(-1) - coverage.size(-1) * 0.5
+            score -= w_coverage * penalty
+        top = score.flatten().topk(topk).indices
+        m = w[top // H, top % H]
+        m = torch.mean(m / m.norm(dim=-2, keepdim=True), 0)
+        neg = torch.zeros(n - 1 - n_sot, self.dims.n_audio_ctx)
+        neg[:, :F] = -m[n_sot:-1]
+        return neg
+
+    def pool_matrices(self, negs, n_heads):
+        tot = float(sum(n_heads))
+        out = torch.zeros_like(negs[0])
+        for x, h in zip(negs, n_heads):
+            out += (h / tot) * x
+        return out
+
     def median_filter(self, x, width):
         from oracle.whisper.timing import median_filter
         return median_filter(x, width)

@@ -325,12 +325,15 @@ def test_lv3_dims_f16_score_probs_vs_oracle_unsaturated():
         ti, tj = paths[w]
         jr = rj[np.pad(np.diff(ri), (1, 0), constant_values=1).astype(bool)]
         jt = tj[np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)]
+        dl = np.abs(np.log(p_got[mid]) - np.log(p_ref[mid]))
         rep.append(dict(tokens=len(p_ref), unsaturated=int(mid.sum()), prob_range=(float(p_ref.min()), float(p_ref.max())),
-                        max_dlogp=float(np.abs(np.log(p_got[mid]) - np.log(p_ref[mid])).max()),
+                        max_dlogp=float(dl.max()), max_dlogp_over_tol=float((dl / (2e-2 + 1e-3 * np.abs(np.log(p_ref[mid])))).max()),
                         dtw_path_identical=bool(ti.tolist() == ri.tolist() and tj.tolist() == rj.tolist()),
                         max_jump_frame_diff=int(np.abs(jr - jt).max())))
     _report("score_probs_unsaturated", rep)
     for r in rep:
         assert r["unsaturated"] >= r["tokens"] // 2, r
-        assert r["max_dlogp"] <= 2e-2, r             # 2 layers of fp16 storage: ~1e-3 relative per logit
+        # fp16 storage of the hidden states: ~1e-3 relative per logit, so |delta log p| <= 2e-2 + 1e-3 |log p| (a token of
+        # p = 1e-20 sits 46 below the row maximum: measured 0.027 there, 0.006 for p > 0.05)
+        assert r["max_dlogp_over_tol"] <= 1.0, r
         assert r["max_jump_frame_diff"] <= 1, r      # token boundaries within one 20-ms frame of the oracle's

@@ -382,11 +382,13 @@ def test_decode_graph_replay_is_bit_identical(name, mode, sample_len):
     xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
     init = [list(task.initial_tokens)] * 3
     old = lib.swx_debug_flags(-1)
+    st0 = eng.graph_stats()
     try:
         assert not (old & 16384)
         g1 = eng.decode(xkv, init, **kw)
         g2 = eng.decode(xkv, init, **kw)
         g3 = eng.decode(xkv, init, **dict(kw, sample_len=sample_len - 3, min_tokens=min(kw["min_tokens"], sample_len - 3)))
+        st1 = eng.graph_stats()
         lib.swx_debug_flags(old | 16384)
         e1 = eng.decode(xkv, init, **kw)
         e3 = eng.decode(xkv, init, **dict(kw, sample_len=sample_len - 3, min_tokens=min(kw["min_tokens"], sample_len - 3)))
@@ -398,6 +400,12 @@ def test_decode_graph_replay_is_bit_identical(name, mode, sample_len):
         assert np.array_equal(np.asarray(a["sum_logprobs"]), np.asarray(b["sum_logprobs"]))
         assert np.array_equal(np.asarray(a["no_speech_prob"]), np.asarray(b["no_speech_prob"]))
     assert int(np.asarray(g1["lens"]).max()) > 8
+    # the graph really ran: replays were counted, the second call reused the first call's graph (one capture less than calls),
+    # nothing fell back to eager launches, and the eager runs added no replay
+    assert not st1["fell_back"], st1
+    assert st1["replays"] - st0["replays"] >= 3 * ((int(g1["steps"]) - 2) // 2) - 3, (st0, st1, g1["steps"])
+    assert st1["captures"] - st0["captures"] <= 2, (st0, st1)
+    assert eng.graph_stats()["replays"] == st1["replays"]
 
 
 @pytest.mark.parametrize("name,heads", [("tiny.en", HEADS_TINY), ("base.en", None)])
