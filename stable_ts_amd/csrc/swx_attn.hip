@@ -550,6 +550,21 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
 // shuffles).  Arithmetic order is self_attn_cached's, so both paths agree bit for bit.
 // HBM traffic: K and V of every cached position of every row once = R * (pos + 1) * d * 2 * 2 bytes per launch (57 MB at
 // position 111 for 100 rows of large-v3: at the end of a window's decode this kernel is bandwidth-, not latency-bound).
+// same rule as swx_decstep.hip::dec_pf_addr: the `line`-th 128-byte line of XCD `xcd`'s share of the next projection's weights
+__device__ __forceinline__ const unsigned char *attn_pf_addr(const DecPrefetch &pf, int xcd, int line)
+{
+    const int units_x = (pf.units - xcd + 7) >> 3;
+    const int lpp = pf.nks * 8, lpu = lpp * 4;
+    const int lines_x = units_x * lpu;
+    if (lines_x <= 0) return (const unsigned char *)pf.base;
+    line = line < lines_x ? line : lines_x - 1;
+    const int ui = line / lpu, rem = line - ui * lpu;
+    const int piece = rem / lpp, l = rem - piece * lpp;
+    const int u = xcd + 8 * ui;
+    const int panel = u / pf.ks2, ks = u - panel * pf.ks2;
+    return (const unsigned char *)pf.base + ((size_t)(panel * 4 + piece) * pf.k32 + (size_t)ks * pf.nks) * 1024 + (size_t)l * 128;
+}
+
 __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
 {
     constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
@@ -591,6 +606,18 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
             const int prj = j < 64 ? pa : pb;                       // (pr0 / pr1 are r for the new position)
             const bool ok = j <= pos;
             vpre[i] = *(const f16x8 *)(vc + ((size_t)(ok ? prj : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
+        }
+    }
+    // ---- L2 prefetch of the out-projection's weights, which the NEXT launch streams (swx_decstep.hip, DecPrefetch): one line per
+    //      lane, the youngest load of the wave; the first blocks of the grid cover an XCD's share (3 200 lines for d = 1280)
+    unsigned pfv = 0;
+    if (a.pf.base) {
+        const int bid = blockIdx.y * gridDim.x + blockIdx.x, xcd = bid & 7;
+        const int line = (bid >> 3) * 64 + lane;
+        const int lines_x = ((a.pf.units - xcd + 7) >> 3) * a.pf.nks * 32;
+        if (line < lines_x) {
+            const unsigned char *pa = attn_pf_addr(a.pf, xcd, line);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pfv) : "v"(pa) : "memory");
         }
     }
     __syncthreads();                                        // qs visible
@@ -664,6 +691,9 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
 #pragma unroll
         for (int e = 0; e < 8; ++e) op[e] = (f16)acc[e];
     }
+    // the prefetch load's destination register stays allocated until the load has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(pfv));
 }
 
 

