@@ -23,8 +23,8 @@ for F in 0 32768; do
   head -c 230 $O/bench_base_en_f$F.json; echo
 done
 stamp "per-kernel durations, eager launches, prefetch on / off"
-scripts/rocprof_kernels.sh r03_eager_pf_on python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-f32 --debug-flags 16384
-scripts/rocprof_kernels.sh r03_eager_pf_off python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-f32 --debug-flags 49152
+scripts/rocprof_kernels.sh r03_eager_pf_on python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-f32 --debug-flags 16384
+scripts/rocprof_kernels.sh r03_eager_pf_off python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --no-f32 --debug-flags 49152
 head -14 gpurun_out/r03_eager_pf_on_kernels.csv | cut -c1-150
 head -14 gpurun_out/r03_eager_pf_off_kernels.csv | cut -c1-150
 stamp "done"

@@ -377,7 +377,10 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
     // L2 prefetch chain (DecPrefetch, swx_kernels.h): each kernel touches the weights of the projection that follows it, except
     // across the two attention kernels that stream tens of MB through the L2s (self-attention itself prefetches the
     // out-projection; nothing survives the cross-attention's 154 MB)
-    const bool pf_on = !(g_debug_flags & SWX_FLAG_NO_PREFETCH);
+    // (from 32 rows on: with one 16-row tile per panel -- sequential transcribe(), 5 rows -- a launch has 20-80 workgroups, too
+    // few lanes to cover a projection, and waits for its own prefetch at its end: measured 58.0 -> 56.7x there, 460.8 -> 450.4 ms
+    // per pass at 100 rows, profiles/r03_dec_prefetch_ab.txt)
+    const bool pf_on = !(g_debug_flags & SWX_FLAG_NO_PREFETCH) && rows >= 32;
     auto pf_of = [&](size_t w_off, int N, int K, int epi) {
         return pf_on ? swx_dec_prefetch_of(m->A<f16>(w_off), rows, N, K, epi) : DecPrefetch{};
     };
