@@ -230,7 +230,7 @@ int swx_prof_enable(int on);
 /* A/B switches for tests and scripts (SWX_FLAG_* in csrc/swx_kernels.h): 1 = decode steps and small passes through the general
  * per-op path instead of the fused "dec" step (its reference), 2048 = decode cross-attention on the row-layout K / V^T
  * (reference of the fragment-ordered copy), 8192 = memory-walking logit filters (reference of the register kernel),
- * 16384 = decode loop without the captured step graph, 32768 = decode step without the L2 prefetch of the next projection's
+ * 16384 = decode loop without the captured step graph, 32768 = decode step without the cache prefetch of the next projection's
  * weights.  Default 0; nothing reads an environment variable.
  * flags < 0 only queries.  Returns the previous value. */
 int swx_debug_flags(int flags);

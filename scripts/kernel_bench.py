@@ -44,6 +44,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--only", default="")
+    ap.add_argument("--flash-kernel", type=int, default=2, help="force_kernel of the flash attention: 2 default dispatch, 4 / 6 / 5 = 32 / 48 / 64 queries per wave")
     ap.add_argument("--gemm-kernel", type=int, default=7, help="force_kernel of the tiled GEMM: 1 register-staged, 7 direct-to-LDS (default dispatch), 8 / 9 = 64-column tiles always / never")
     args = ap.parse_args()
     from stable_ts_amd import _lib
@@ -66,12 +67,15 @@ def main():
             print(f"  M={M:6d} N={N:6d} K={K:5d}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s")
 
     if args.only in ("", "flash"):
-        print("-- encoder self-attention (flash), B=20 H=20 nq=nk=1500")
-        B, H, n = 20, 20, 1500
-        q, k, v = rnd(B, n, H * 64), rnd(B, n, H * 64), rnd(B, n, H * 64)
+        print("-- encoder self-attention (flash, V transposed per head as the encoder hands it over), B=20 H=20 nq=nk=1500")
+        B, H, n, kp = 20, 20, 1500, 1536
+        q, k = rnd(B, n, H * 64), rnd(B, n, H * 64)
+        vt = torch.zeros(B, H, 64, kp, dtype=torch.half, device=dev)
+        vt[..., :n] = rnd(B, H, 64, n)
         o = torch.empty_like(q)
-        us = timed(lambda: lib.swx_test_attention(1, p(q), H * 64, p(k), p(v), H * 64, p(o), H * 64, B, H, n, n, 2, 0, st), max(args.iters // 10, 5))
-        print(f"  {us:9.1f} us  {4.0 * B * H * n * n * 64 / us / 1e6:7.1f} TFLOP/s")
+        for fk in ([args.flash_kernel] if args.flash_kernel != 2 else [4, 6, 5, 4, 6, 5]):
+            us = timed(lambda: lib.swx_test_attention(1, p(q), H * 64, p(k), p(vt), H * 64, p(o), H * 64, B, H, n, n, fk, kp, st), max(args.iters // 10, 5))
+            print(f"  force_kernel {fk} ({ {4: 32, 6: 48, 5: 64}.get(fk, 0) } queries per wave): {us:9.1f} us  {4.0 * B * H * n * n * 64 / us / 1e6:7.1f} TFLOP/s")
 
     if args.only in ("", "cross"):
         print("-- decode-step cross-attention, B=20 H=20 nq=5 nk=1500 (transposed-V layout)")

@@ -31,38 +31,39 @@ constexpr int FL_LD = 72;            // halfs per LDS row (144 B: keeps b128 / b
 // Swapped QK^T (S^T = K.Q^T), so a lane's accumulator registers all belong to ONE query: the online-softmax row statistics are
 // lane-local + two shuffles and the exponentiated tile is already laid out as the B operand of O^T += V^T.P^T (no LDS round
 // trip for P).  Against the first kernel (16 queries per wave, single-buffered tiles: 0.10 of the MFMA peak, deleted in round 3):
-//   * a wave owns 32 queries (two 16-query blocks): every K / V^T fragment read from LDS feeds two MFMAs, and a workgroup
-//     covers 128 queries per barrier instead of 64;
+//   * a wave owns QB 16-query blocks (QB = 2: 32 queries; QB = 4: 64 queries for long query axes): every K / V^T fragment read
+//     from LDS feeds QB MFMAs -- 24 fragment reads per 16 QB MFMAs per wave and tile -- and a workgroup covers 64 QB queries per
+//     barrier;
 //   * K / V^T tiles are double-buffered in LDS, the global loads of tile t+1 are issued into registers BEFORE the MFMAs of
 //     tile t and written to the other buffer after them: one barrier per tile, no exposed load latency;
 //   * with VT (V already transposed per head in HBM: cross-KV layout, and the encoder's V through swx_transpose_v) both
 //     tiles are written with 16-byte vector stores; the row-major-V form (scalar transposing stores) is kept for the callers
 //     that have no transposed copy.
-template <bool VT>
-__global__ __launch_bounds__(256) void attn_flash2_f16(AttnArgs a)
+template <bool VT, int QB>
+__global__ __launch_bounds__(256, 2) void attn_flash2_f16(AttnArgs a)
 {
     __shared__ __attribute__((aligned(16))) f16 Ks[2][FL_KT][FL_LD];   // [buf][key][d]
     __shared__ __attribute__((aligned(16))) f16 Vt[2][DH][FL_LD];      // [buf][d][key]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (QB * 64) + wave * (QB * 16);
     const int qn = lane & 15, g = lane >> 4;
     const f16 *Q = (const f16 *)a.q;
     const f16 *K = (const f16 *)a.k + (size_t)b * a.k_bs + h * DH;
     const f16 *V = (const f16 *)a.v + (size_t)b * a.v_bs + (VT ? (size_t)h * DH * a.vt_kp : (size_t)h * DH);
 
-    f16x8 qf[2][2];
+    f16x8 qf[QB][2];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + qb * 16 + qn;
         const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qi < a.nq ? qi : a.nq - 1)) * a.ldq + h * DH + g * 8;   // clamped
         qf[qb][0] = *(const f16x8 *)(qp);
         qf[qb][1] = *(const f16x8 *)(qp + 32);
     }
-    f32x4 o[2][4];
-    float m_run[2], l_run[2];
+    f32x4 o[QB][4];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         m_run[qb] = -__builtin_inff(); l_run[qb] = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) o[qb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -107,15 +108,15 @@ __global__ __launch_bounds__(256) void attn_flash2_f16(AttnArgs a)
     for (int t = 0; t < ntile; ++t) {
         const int cur = t & 1, kt0 = t * FL_KT;
         if (t + 1 < ntile) load_tile(kt0 + FL_KT);
-        // K fragments of this tile, shared by the two query blocks
+        // K fragments of this tile, shared by the QB query blocks
         f16x8 kf[4][2];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) kf[tt][kk] = *(const f16x8 *)&Ks[cur][tt * 16 + qn][kk * 32 + g * 8];
-        f16x8 pb[2][2];
+        f16x8 pb[QB][2];
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
+        for (int qb = 0; qb < QB; ++qb) {
             f32x4 sc[4];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_flash2_f16(AttnArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { pb[qb][c][r] = (f16)sc[2 * c][r]; pb[qb][c][4 + r] = (f16)sc[2 * c + 1][r]; }
         }
-        // O^T += V^T . P^T : every V^T fragment feeds both query blocks
+        // O^T += V^T . P^T : every V^T fragment feeds all QB query blocks
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -176,15 +177,15 @@ __global__ __launch_bounds__(256) void attn_flash2_f16(AttnArgs a)
                 f16x8 va;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { va[e] = lo[e]; va[4 + e] = hi[e]; }
-                o[0][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[0][c], o[0][tt], 0, 0, 0);
-                o[1][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[1][c], o[1][tt], 0, 0, 0);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) o[qb][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va, pb[qb][c], o[qb][tt], 0, 0, 0);
             }
         if (t + 1 < ntile) store_tile(cur ^ 1);
         __syncthreads();
     }
 
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
         const int qi = q0 + qb * 16 + qn;
         if (qi < a.nq) {
             const float inv = 1.0f / l_run[qb];
@@ -550,21 +551,6 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
 // shuffles).  Arithmetic order is self_attn_cached's, so both paths agree bit for bit.
 // HBM traffic: K and V of every cached position of every row once = R * (pos + 1) * d * 2 * 2 bytes per launch (57 MB at
 // position 111 for 100 rows of large-v3: at the end of a window's decode this kernel is bandwidth-, not latency-bound).
-// same rule as swx_decstep.hip::dec_pf_addr: the `line`-th 128-byte line of XCD `xcd`'s share of the next projection's weights
-__device__ __forceinline__ const unsigned char *attn_pf_addr(const DecPrefetch &pf, int xcd, int line)
-{
-    const int units_x = (pf.units - xcd + 7) >> 3;
-    const int lpp = pf.nks * 8, lpu = lpp * 4;
-    const int lines_x = units_x * lpu;
-    if (lines_x <= 0) return (const unsigned char *)pf.base;
-    line = line < lines_x ? line : lines_x - 1;
-    const int ui = line / lpu, rem = line - ui * lpu;
-    const int piece = rem / lpp, l = rem - piece * lpp;
-    const int u = xcd + 8 * ui;
-    const int panel = u / pf.ks2, ks = u - panel * pf.ks2;
-    return (const unsigned char *)pf.base + ((size_t)(panel * 4 + piece) * pf.k32 + (size_t)ks * pf.nks) * 1024 + (size_t)l * 128;
-}
-
 __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
 {
     constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
@@ -606,18 +592,6 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
             const int prj = j < 64 ? pa : pb;                       // (pr0 / pr1 are r for the new position)
             const bool ok = j <= pos;
             vpre[i] = *(const f16x8 *)(vc + ((size_t)(ok ? prj : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
-        }
-    }
-    // ---- L2 prefetch of the out-projection's weights, which the NEXT launch streams (swx_decstep.hip, DecPrefetch): one line per
-    //      lane, the youngest load of the wave; the first blocks of the grid cover an XCD's share (3 200 lines for d = 1280)
-    unsigned pfv = 0;
-    if (a.pf.base) {
-        const int bid = blockIdx.y * gridDim.x + blockIdx.x, xcd = bid & 7;
-        const int line = (bid >> 3) * 64 + lane;
-        const int lines_x = ((a.pf.units - xcd + 7) >> 3) * a.pf.nks * 32;
-        if (line < lines_x) {
-            const unsigned char *pa = attn_pf_addr(a.pf, xcd, line);
-            asm volatile("global_load_dword %0, %1, off" : "=v"(pfv) : "v"(pa) : "memory");
         }
     }
     __syncthreads();                                        // qs visible
@@ -691,9 +665,6 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
 #pragma unroll
         for (int e = 0; e < 8; ++e) op[e] = (f16)acc[e];
     }
-    // the prefetch load's destination register stays allocated until the load has landed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" ::"v"(pfv));
 }
 
 
@@ -768,7 +739,7 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
 {
     if (a.B <= 0 || a.nq <= 0 || a.nk <= 0) return 0;
     if (a.nk > RW_MAXK) return -5;
-    const bool flash = (dtype == SWX_F16) && (force_kernel == 2 || (force_kernel == 0 && a.nq >= 32));
+    const bool flash = (dtype == SWX_F16) && (force_kernel == 2 || (force_kernel >= 4 && force_kernel <= 6) || (force_kernel == 0 && a.nq >= 32));
     const size_t esz = dtype == SWX_F16 ? 2 : 4;
     // the decode kernel also takes a SMALL multi-row pass (align(): one window of ~100 rows) as groups of 16 rows, when the
     // fragment-ordered K / V^T copy exists and the flash grid would be tiny
@@ -787,9 +758,14 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
-        dim3 g(cdiv(a.nq, 128), a.H, a.B);
-        if (a.vt_kp) hipLaunchKernelGGL(attn_flash2_f16<true>, g, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(attn_flash2_f16<false>, g, dim3(256), 0, s, a);
+        // queries per wave: 64 when the query axis is long (encoder self-attention: 1 500 queries), 32 otherwise; force_kernel
+        // 4 / 6 / 5 pin 32 / 48 / 64 (scripts/kernel_bench.py --flash-kernel)
+        const int qb = !a.vt_kp ? 2 : force_kernel == 4 ? 2 : force_kernel == 6 ? 3 : (force_kernel == 5 || a.nq >= 1024) ? 4 : 2;
+        dim3 g(cdiv(a.nq, 64 * qb), a.H, a.B);
+        if (!a.vt_kp) hipLaunchKernelGGL((attn_flash2_f16<false, 2>), g, dim3(256), 0, s, a);
+        else if (qb == 4) hipLaunchKernelGGL((attn_flash2_f16<true, 4>), g, dim3(256), 0, s, a);
+        else if (qb == 3) hipLaunchKernelGGL((attn_flash2_f16<true, 3>), g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_flash2_f16<true, 2>), g, dim3(256), 0, s, a);
     } else {
         // algorithmic bytes: K and V of every (window, head) once + q in + o out
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);

@@ -37,7 +37,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DEC_MAXMT = 3;
-constexpr int DEC_NPF = 4;        // L2-prefetch loads per wave (64 lines of 128 B each): the 14 workgroups an XCD runs of the smallest launch
+constexpr int DEC_NPF = 4;        // prefetch loads per wave (64 lines of 128 B each): the 14 workgroups an XCD runs of the smallest launch
                                   // (N = 1280, 16-row tiles, M = 100) x 4 waves x 4 x 8 KB = 1.8 MB >= an XCD's share of any projection (1.6 MB)
 
 // Address of the `line`-th 128-byte line (in the order of this XCD's share) of the next projection's packed weights: XCD x owns
@@ -138,10 +138,10 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             xres[t] = *(const f16x4 *)(g.X + (size_t)(m < g.M ? m : g.M - 1) * g.ldx + nc);
         }
     }
-    // ---- L2 prefetch of the NEXT projection's weights: DEC_NPF more loads per wave, the youngest in the queue, whose results
+    // ---- cache prefetch of the NEXT projection's weights: DEC_NPF more loads per wave, the youngest in the queue, whose results
     //      nobody reads (kept in registers until the wave's last wait so that the allocator cannot hand those registers out
-    //      while a load is still in flight).  What the r02 ablation measured per launch with L2-hot instead of HBM-cold weights:
-    //      -1.0 .. -2.0 us; here the previous kernel of the chain warms the L2 of the XCD that will run each panel.
+    //      while a load is still in flight).  The r02 ablation measured -1.0 .. -2.0 us per launch with warm instead of HBM-cold
+    //      weights; here the previous kernel of the chain does the warming (measured -0.8 .. -1.2 us on the consumer).
     unsigned pfv[DEC_NPF];
     {
         const DecPrefetch pf = g.pf.base ? g.pf : DecPrefetch{g.W, g.K >> 5, NKS, g.ks2, panels * g.ks2};   // none: own weights (already in flight)

@@ -35,7 +35,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_SELECT_MEM 8192      // logit filters + token selection: the kernel that walks the row in memory (reference of
                                       // the register-resident kernel, and its fallback for vocabularies > 51 * 1024)
 #define SWX_FLAG_NO_GRAPH 16384       // decode loop: launch every step eagerly instead of replaying the captured two-step graph
-#define SWX_FLAG_NO_PREFETCH 32768    // decode step: no L2 prefetch of the next projection's weights (A/B; no functional effect)
+#define SWX_FLAG_NO_PREFETCH 32768    // decode step: no cache prefetch of the next projection's weights (A/B; no functional effect)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
 
@@ -46,11 +46,12 @@ int swx_flags();
 #define DEC_RES 4       // X[m][n] = f16(X + c2[n] + acc)   (in place)
 #define DEC_QKV 8       // columns [0,d) -> C, [d,2d) -> kcache[m][pos0[m]], [2d,3d) -> vcache[m][pos0[m]]
 #define DEC_SLAB 16     // K-split allowed: f32 partials to slabs + dec_slab_finish (needs DEC_RES)
-// The packed weights of the projection that runs NEXT in the decode step, for the L2 prefetch the current kernel issues: the
-// unit (64-column panel x K slice) u of the next launch runs on XCD u % 8 (block id -> XCD is id % 8 in hardware, and
-// swx_gemm_dec numbers its blocks accordingly), so the workgroups of the current kernel that sit on XCD x touch the 128-byte
-// lines of the units u = x, x + 8, ... -- one load per line, into THAT XCD's L2 (4 MB each, not shared).  No functional
-// effect; a wrong guess about the placement costs nothing but the benefit.  base == null: nothing to prefetch.
+// The packed weights of the projection that runs NEXT in the decode step, for the cache prefetch the current kernel issues: a few
+// loads per wave whose results nobody reads, one per 128-byte line.  The lines are dealt so that the workgroups sitting on XCD x
+// touch the units (64-column panel x K slice) u = x, x + 8, ... that XCD x will run (block id -> XCD is id % 8 in hardware and
+// swx_gemm_dec numbers its blocks accordingly) -- but what the counters show being warmed is the memory-side Infinity Cache, not
+// the L2s (the consumer's FETCH_SIZE does not drop, its latency does: section 5 of DESIGN.md), so the placement is immaterial.
+// No functional effect.  base == null: nothing to prefetch.
 struct DecPrefetch {
     const void *base;                    // packed weights [N/16][K/32][64][8] halfs
     int k32, nks, ks2, units;            // K / 32, k-steps per slice, K slices, (N / 64) * ks2
@@ -71,7 +72,7 @@ struct DecGemmArgs {
     int rps;                             // DEC_QKV: rows per sequence (0 / 1: one new token per row); row m = sequence m / rps, token m % rps
     int row_mul;                         // DEC_QKV: cache row (and pos0 index) of sequence q = q * row_mul (0 / 1: q itself; the prefill writes row w * G)
     int ks2, kslice, n_rg; int64_t slab_stride;   // filled by the launcher
-    DecPrefetch pf;                      // L2 prefetch of the NEXT projection's weights (pf.base == null: none)
+    DecPrefetch pf;                      // cache prefetch of the NEXT projection's weights (pf.base == null: none)
 };
 int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation
 size_t swx_dec_slab_floats(int M, int N, int K);
@@ -143,7 +144,6 @@ struct SelfAttnArgs {
     int step_cached;                 // n_new == 1, f16: q at a.qkv (row stride ldqkv), the new K/V already appended -> the
                                      // latency-optimised single-token kernel of the decode step
     int step_pos;                    // profiler only: position of the new token when the host knows it (decode loop), else 0
-    DecPrefetch pf;                  // decode step: the weights of the out-projection that follows (L2 prefetch), or base == null
 };
 // logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);

@@ -374,9 +374,11 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
     SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, rows, 1, m->arena + m->o_tok_emb,
                       m->A<float>(m->o_dec_pos), d, x, s));
     const int64_t chunk = xkv_chunk_elems(m);
-    // L2 prefetch chain (DecPrefetch, swx_kernels.h): each kernel touches the weights of the projection that follows it, except
-    // across the two attention kernels that stream tens of MB through the L2s (self-attention itself prefetches the
-    // out-projection; nothing survives the cross-attention's 154 MB)
+    // Prefetch chain (DecPrefetch, swx_kernels.h): each projection touches the weights of the NEXT projection.  What the
+    // counters say it warms is the 256 MB Infinity Cache, not an L2 (profiles/r03_pmc_final.csv: the consumer's FETCH_SIZE does
+    // not drop -- the L2s drop their clean lines at a kernel boundary -- but it is 0.8-1.2 us faster, r03_eager_pf_*_kernels.csv),
+    // so a prefetch also survives the attention kernel in between (<= 57 MB / 154 MB through a 256 MB cache).  A prefetch issued
+    // BY the self-attention kernel was tried and dropped: +0.36 us on it.
     // (from 32 rows on: with one 16-row tile per panel -- sequential transcribe(), 5 rows -- a launch has 20-80 workgroups, too
     // few lanes to cover a projection, and waits for its own prefetch at its end: measured 58.0 -> 56.7x there, 460.8 -> 450.4 ms
     // per pass at 100 rows, profiles/r03_dec_prefetch_ab.txt)
@@ -393,12 +395,12 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g.A = x; g.lda = d; g.W = m->A<f16>(w.wqkv_f); g.ldw = d; g.N = 3 * d; g.K = d; g.epi = DEC_LN | DEC_QKV;
         g.c1 = m->A<float>(w.qkv_c1); g.c2 = m->A<float>(w.qkv_c2); g.C = q; g.ldc = d;
         g.kcache = kc; g.vcache = vc; g.pos0 = f.pos0; g.n_ctx = D.n_text_ctx; g.d = d;
+        g.pf = pf_of(w.wo_p, d, d, DEC_RES);                 // used after the self-attention (<= 57 MB through the cache)
         SWX_TRY(swx_gemm_dec(g, s));
         SelfAttnArgs sa{};
         sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1; sa.step_cached = 1;
         sa.step_pos = f.step_pos;
-        sa.pf = pf_of(w.wo_p, d, d, DEC_RES);
         SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
         // x += att Wo^T + bo
         g = DecGemmArgs{};
@@ -410,6 +412,7 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g = DecGemmArgs{};
         g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
         g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
+        g.pf = pf_of(w.wco_p, d, d, DEC_RES);                // used after the cross-attention (154 MB through the cache)
         SWX_TRY(swx_gemm_dec(g, s));
         const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
         AttnArgs ca{};

@@ -284,7 +284,7 @@ def test_attention_kernels(B, H, nq, nk):
     assert (o.cpu().double() - ref).abs().max().item() < 2e-5
     qh, kh, vh = q.half(), k.half(), v.half()
     refh = _attn_ref(qh, kh, vh)
-    for force in (1, 2):   # rowwise f16, flash MFMA f16
+    for force in (1, 2, 4, 6, 5):   # rowwise f16; flash MFMA f16: default dispatch, 32 / 48 / 64 queries per wave
         for kp in (0, 1536):
             o = _attn(1, qh.cuda(), kh.cuda(), vh.cuda(), force, kp)
             err = (o.cpu().double() - refh).abs().max().item()
