@@ -458,6 +458,10 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
     SWX_TRY(swx_embed(m->dtype, f.tokens, f.ld_tok, nullptr, f.pos0, R, f.n_new, m->arena + m->o_tok_emb,
                       m->A<float>(m->o_dec_pos), d, x, s));
     const int64_t chunk = xkv_chunk_elems(m);
+    const bool pf_on = !(g_debug_flags & SWX_FLAG_NO_PREFETCH) && rows >= 32;       // the decode step's prefetch chain (decoder_step_dec)
+    auto pf_of = [&](size_t w_off, int N, int K, int epi) {
+        return pf_on ? swx_dec_prefetch_of(m->A<f16>(w_off), rows, N, K, epi) : DecPrefetch{};
+    };
     for (int l = 0; l < D.n_text_layer; ++l) {
         const LayerW &w = m->dec[l];
         f16 *kc = (f16 *)(f.kcache + (size_t)l * f.layer_stride), *vc = (f16 *)(f.vcache + (size_t)l * f.layer_stride);
@@ -465,6 +469,7 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wqkv_f); g.ldw = d; g.N = 3 * d; g.K = d; g.epi = DEC_LN | DEC_QKV;
         g.c1 = m->A<float>(w.qkv_c1); g.c2 = m->A<float>(w.qkv_c2); g.C = q; g.ldc = d;
         g.kcache = kc; g.vcache = vc; g.pos0 = f.pos0; g.n_ctx = D.n_text_ctx; g.d = d; g.rps = f.n_new; g.row_mul = f.row_mul;
+        g.pf = pf_of(w.wo_p, d, d, DEC_RES);
         SWX_TRY(swx_gemm_dec(g, s));
         SelfAttnArgs sa{};
         sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
@@ -473,10 +478,12 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g = DecGemmArgs{};
         g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
+        g.pf = pf_of(w.wcq_f, d, d, DEC_LN);
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
         g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
+        g.pf = pf_of(w.wco_p, d, d, DEC_RES);
         SWX_TRY(swx_gemm_dec(g, s));
         if (f.qcap) {
             hipError_t qe = hipMemcpyAsync(f.qcap + (size_t)l * rows * d * e, q, (size_t)rows * d * e, hipMemcpyDeviceToDevice, s);
@@ -497,14 +504,17 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g = DecGemmArgs{};
         g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bco); g.X = x; g.ldx = d;
+        g.pf = pf_of(w.w1_f, 4 * d, d, DEC_LN | DEC_GELU);
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.w1_f); g.ldw = d; g.N = 4 * d; g.K = d; g.epi = DEC_LN | DEC_GELU;
         g.c1 = m->A<float>(w.w1_c1); g.c2 = m->A<float>(w.w1_c2); g.C = u; g.ldc = 4 * d;
+        g.pf = pf_of(w.w2_p, d, 4 * d, DEC_RES | DEC_SLAB);
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
         g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
+        if (l + 1 < D.n_text_layer) g.pf = pf_of(m->dec[l + 1].wqkv_f, 3 * d, d, DEC_LN | DEC_QKV);
         SWX_TRY(swx_gemm_dec(g, s));
     }
     return 0;
