@@ -311,10 +311,16 @@ class Whisper:
 def _read_checkpoint(path: str):
     # weights_only: a checkpoint is data (upstream's are {"dims": dict, "model_state_dict": tensors}); a pickle that needs
     # arbitrary classes to load is refused rather than executed
-    ckpt = torch.load(path, map_location="cpu", weights_only=True)
-    dims = ckpt["dims"]
-    dims = ModelDimensions(**dims) if isinstance(dims, dict) else ModelDimensions(**dims.__dict__)
-    return dims, ckpt["model_state_dict"]
+    import pickle
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        raise RuntimeError(f"{path}: not a plain-data checkpoint (upstream's are {{'dims': dict, 'model_state_dict': tensors}}); a "
+                           f"pickle that needs classes to load -- e.g. 'dims' saved as a ModelDimensions object -- is refused. "
+                           f"Re-save it with dims=dataclasses.asdict(dims).  ({e})") from e
+    if not isinstance(ckpt, dict) or "dims" not in ckpt or "model_state_dict" not in ckpt:
+        raise RuntimeError(f"{path}: expected a checkpoint of the form {{'dims': dict, 'model_state_dict': tensors}}")
+    return ModelDimensions(**dict(ckpt["dims"])), ckpt["model_state_dict"]
 
 
 # HuggingFace parameter names -> upstream checkpoint names (the inverse of the table the reference keeps for its HF back
