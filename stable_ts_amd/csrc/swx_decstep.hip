@@ -37,25 +37,8 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int DEC_MAXMT = 3;
-constexpr int DEC_NPF = 4;        // prefetch loads per wave (64 lines of 128 B each): the 14 workgroups an XCD runs of the smallest launch
-                                  // (N = 1280, 16-row tiles, M = 100) x 4 waves x 4 x 8 KB = 1.8 MB >= an XCD's share of any projection (1.6 MB)
-
-// Address of the `line`-th 128-byte line (in the order of this XCD's share) of the next projection's packed weights: XCD x owns
-// the units u = x, x + 8, ...; a unit = 4 pieces (one per wave of the workgroup that will run it) of nks KB each, piece
-// (panel, w, ks) at ((panel * 4 + w) * k32 + ks * nks) KB.  Lines past the share re-touch its last line.
-__device__ __forceinline__ const unsigned char *dec_pf_addr(const DecPrefetch &pf, int xcd, int line)
-{
-    const int units_x = (pf.units - xcd + 7) >> 3;
-    const int lpp = pf.nks * 8, lpu = lpp * 4;              // lines per piece / per unit
-    const int lines_x = units_x * lpu;
-    if (lines_x <= 0) return (const unsigned char *)pf.base;
-    line = line < lines_x ? line : lines_x - 1;
-    const int ui = line / lpu, rem = line - ui * lpu;
-    const int piece = rem / lpp, l = rem - piece * lpp;
-    const int u = xcd + 8 * ui;
-    const int panel = u / pf.ks2, ks = u - panel * pf.ks2;
-    return (const unsigned char *)pf.base + ((size_t)(panel * 4 + piece) * pf.k32 + (size_t)ks * pf.nks) * 1024 + (size_t)l * 128;
-}
+constexpr int DEC_NPF = 4;        // prefetch loads per wave (64 lines of 128 B each): the smallest launch at M = 100 (N = 1280: 140 workgroups)
+                                  // x 4 waves x 4 x 8 KB = 18 MB >= any projection (13 MB)
 
 // cache policy of the weight stream: every weight byte is read once per step by ONE XCD (the row groups of a panel share it
 // through that XCD's L2).  Built with -DSWX_DEC_NT the loads carry `nt` (MI355X_MICROARCH.md "nt-weights": -5..-10 % per layer
@@ -144,13 +127,17 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     //      weights; here the previous kernel of the chain does the warming (measured -0.8 .. -1.2 us on the consumer).
     unsigned pfv[DEC_NPF];
     {
-        const DecPrefetch pf = g.pf.base ? g.pf : DecPrefetch{g.W, g.K >> 5, NKS, g.ks2, panels * g.ks2};   // none: own weights (already in flight)
-        // the workgroups of this launch that sit on this XCD and got a unit (slots 0 .. gx - 1, this one among them)
-        const int gx = ((panels * g.ks2 - xcd + 7) >> 3) * g.n_rg;
-        const int t = (slot * 4 + wave) * 64 + lane;
+        // lines are dealt over the lanes of the workgroups that got a unit, in the order (unit, row group, wave, lane); a launch
+        // with fewer lanes than the next projection has lines covers a prefix of it, lanes past the end re-touch the last line
+        const unsigned char *pbase = g.pf.base ? (const unsigned char *)g.pf.base : (const unsigned char *)g.W;
+        const int plines = g.pf.base ? g.pf.lines : (g.N >> 6) * (g.K >> 6) * 64;          // N * K * 2 / 128 (own weights: already in flight)
+        const int t = ((unit * g.n_rg + rg) * 4 + wave) * 64 + lane;
+        const int stride = panels * g.ks2 * g.n_rg * 256;
 #pragma unroll
         for (int i = 0; i < DEC_NPF; ++i) {
-            const unsigned char *pa = dec_pf_addr(pf, xcd, t + i * gx * 256);
+            int line = t + i * stride;
+            line = line < plines ? line : plines - 1;
+            const unsigned char *pa = pbase + (size_t)line * 128;
             asm volatile("global_load_dword %0, %1, off" : "=v"(pfv[i]) : "v"(pa) : "memory");
         }
     }
@@ -354,8 +341,8 @@ DecPrefetch swx_dec_prefetch_of(const void *packed_w, int M, int N, int K, int e
 {
     DecPrefetch pf{};
     int mt = 1, ks2 = 1;
-    if (!packed_w || swx_dec_plan(M, N, K, epi, &mt, &ks2) < 0) return pf;
-    pf.base = packed_w; pf.k32 = K >> 5; pf.ks2 = ks2; pf.nks = (K / ks2) >> 5; pf.units = (N / 64) * ks2;
+    if (!packed_w || swx_dec_plan(M, N, K, epi, &mt, &ks2) < 0) return pf;        // only shapes the dec kernels run have packed weights
+    pf.base = packed_w; pf.lines = (int)(((int64_t)N * K * 2) >> 7);
     return pf;
 }
 

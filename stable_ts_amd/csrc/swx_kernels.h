@@ -47,14 +47,12 @@ int swx_flags();
 #define DEC_QKV 8       // columns [0,d) -> C, [d,2d) -> kcache[m][pos0[m]], [2d,3d) -> vcache[m][pos0[m]]
 #define DEC_SLAB 16     // K-split allowed: f32 partials to slabs + dec_slab_finish (needs DEC_RES)
 // The packed weights of the projection that runs NEXT in the decode step, for the cache prefetch the current kernel issues: a few
-// loads per wave whose results nobody reads, one per 128-byte line.  The lines are dealt so that the workgroups sitting on XCD x
-// touch the units (64-column panel x K slice) u = x, x + 8, ... that XCD x will run (block id -> XCD is id % 8 in hardware and
-// swx_gemm_dec numbers its blocks accordingly) -- but what the counters show being warmed is the memory-side Infinity Cache, not
-// the L2s (the consumer's FETCH_SIZE does not drop, its latency does: section 5 of DESIGN.md), so the placement is immaterial.
-// No functional effect.  base == null: nothing to prefetch.
+// loads per wave whose results nobody reads, one per 128-byte line, dealt over the lanes of the launch in order.  What gets warm
+// is the memory-side Infinity Cache (the consumer's FETCH_SIZE does not drop, its latency does: section 5 of DESIGN.md), so
+// where a line's load is issued from does not matter.  No functional effect.  base == null: nothing to prefetch.
 struct DecPrefetch {
-    const void *base;                    // packed weights [N/16][K/32][64][8] halfs
-    int k32, nks, ks2, units;            // K / 32, k-steps per slice, K slices, (N / 64) * ks2
+    const void *base;                    // packed weights, N * K halfs, contiguous
+    int lines;                           // N * K * 2 / 128
 };
 DecPrefetch swx_dec_prefetch_of(const void *packed_w, int M, int N, int K, int epi);
 
