@@ -1,6 +1,6 @@
 """Per-kernel micro-benchmarks at the bench workload's shapes (large-v3, 20 windows x beam 5) through libswx's test hooks.
 
-    python scripts/kernel_bench.py [--iters 200] [--only gemm|flash|cross|dec|dtw]
+    python scripts/kernel_bench.py [--iters 200] [--only gemm|gemm_small|flash|flash_small|cross|dec|dtw]
 
 One HIP-event pair brackets `iters` back-to-back launches of the same kernel, so the figure is the steady-state
 launch-to-launch time (kernel + one kernel boundary), which is what a dependent chain such as the decode step pays.
@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--only", default="")
     ap.add_argument("--flash-kernel", type=int, default=2, help="force_kernel of the flash attention: 2 default dispatch, 4 / 6 / 5 = 32 / 48 / 64 queries per wave")
-    ap.add_argument("--gemm-kernel", type=int, default=7, help="force_kernel of the tiled GEMM: 1 register-staged, 7 direct-to-LDS (default dispatch), 8 / 9 = 64-column tiles always / never")
+    ap.add_argument("--gemm-kernel", type=int, default=7, help="force_kernel of the tiled GEMM: 1 register-staged, 7 direct-to-LDS (occupancy-overlapped), 8 / 9 = its 64-column tiles always / never, 10 .. 13 ring kernel, 0 = dispatch")
     args = ap.parse_args()
     from stable_ts_amd import _lib
     lib = _lib.load()
@@ -65,6 +65,36 @@ def main():
             bias = torch.zeros(N, device=dev)
             us = timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, args.gemm_kernel, st), max(args.iters // 10, 5))
             print(f"  M={M:6d} N={N:6d} K={K:5d}: {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s")
+
+    if args.only in ("gemm_small",):
+        # the encoder / cross-K/V at batch 1 (align(), sequential transcribe()): launches of 240-480 tiles.  7 = the kernel that
+        # overlaps through occupancy, 10 .. 13 = the ring kernel (64 / 128 columns at depth 4, then depth 3), 0 = the dispatch
+        print("-- tiled MFMA GEMM at batch 1: us per launch by force_kernel")
+        codes = [7, 10, 11, 12, 13, 0]
+        print("  " + " " * 28 + "".join(f"{c:>9d}" for c in codes))
+        for M, N, K in [(1500, 1280, 1280), (1500, 3840, 1280), (1500, 5120, 1280), (1500, 1280, 5120), (1500, 2560, 1280),
+                        (3000, 1280, 384), (1500, 1280, 3840), (1500, 512, 512), (1500, 2048, 512), (1500, 512, 2048),
+                        (4500, 1280, 1280), (6000, 1280, 5120)]:
+            a, w, c = rnd(M, K), rnd(N, K), torch.empty(M, N, dtype=torch.half, device=dev)
+            bias = torch.zeros(N, device=dev)
+            row = []
+            for code in codes:
+                rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, code, st)
+                row.append(timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, code, st),
+                                 max(args.iters // 4, 5)) if rc == 0 else float("nan"))
+            print(f"  M={M:6d} N={N:6d} K={K:5d}:" + "".join(f"{u:9.1f}" for u in row))
+
+    if args.only in ("flash_small",):
+        print("-- encoder self-attention at batch 1 (B=1 H=20 nq=nk=1500) and batch 2 / 4: us per launch by queries per wave")
+        for B in (1, 2, 4):
+            H, n, kp = 20, 1500, 1536
+            q, k = rnd(B, n, H * 64), rnd(B, n, H * 64)
+            vt = torch.zeros(B, H, 64, kp, dtype=torch.half, device=dev)
+            vt[..., :n] = rnd(B, H, 64, n)
+            o = torch.empty_like(q)
+            row = [timed(lambda: lib.swx_test_attention(1, p(q), H * 64, p(k), p(vt), H * 64, p(o), H * 64, B, H, n, n, fk, kp, st),
+                         max(args.iters // 4, 5)) for fk in (4, 6, 5, 2)]
+            print(f"  B={B}: 32 q/wave {row[0]:7.1f}   48 {row[1]:7.1f}   64 {row[2]:7.1f}   dispatch {row[3]:7.1f}")
 
     if args.only in ("", "flash"):
         print("-- encoder self-attention (flash, V transposed per head as the encoder hands it over), B=20 H=20 nq=nk=1500")

@@ -758,9 +758,11 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
-        // queries per wave: 64 when the query axis is long (encoder self-attention: 1 500 queries), 32 otherwise; force_kernel
-        // 4 / 6 / 5 pin 32 / 48 / 64 (scripts/kernel_bench.py --flash-kernel)
-        const int qb = !a.vt_kp ? 2 : force_kernel == 4 ? 2 : force_kernel == 6 ? 3 : (force_kernel == 5 || a.nq >= 1024) ? 4 : 2;
+        // queries per wave: 64 when the query axis is long (encoder self-attention: 1 500 queries) AND the launch still has a
+        // workgroup for every CU that way (at one window 64 queries per wave are 6 x 20 = 120 workgroups), 32 otherwise;
+        // force_kernel 4 / 6 / 5 pin 32 / 48 / 64 (scripts/kernel_bench.py --flash-kernel, --only flash_small)
+        const bool wide_fills = (int64_t)a.B * a.H * cdiv(a.nq, 256) >= 256;
+        const int qb = !a.vt_kp ? 2 : force_kernel == 4 ? 2 : force_kernel == 6 ? 3 : (force_kernel == 5 || (a.nq >= 1024 && wide_fills)) ? 4 : 2;
         dim3 g(cdiv(a.nq, 64 * qb), a.H, a.B);
         if (!a.vt_kp) hipLaunchKernelGGL((attn_flash2_f16<false, 2>), g, dim3(256), 0, s, a);
         else if (qb == 4) hipLaunchKernelGGL((attn_flash2_f16<true, 4>), g, dim3(256), 0, s, a);

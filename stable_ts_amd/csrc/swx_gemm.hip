@@ -361,6 +361,136 @@ __device__ __forceinline__ void gemm_f16_glds_body(const GemmArgs &g)
 __global__ __launch_bounds__(256, 3) void gemm_f16_glds_128(GemmArgs g) { gemm_f16_glds_body<128>(g); }
 __global__ __launch_bounds__(256, 3) void gemm_f16_glds_64(GemmArgs g) { gemm_f16_glds_body<64>(g); }
 
+// ------------------------------------------------------------------------------- tiled f16, direct-to-LDS ring
+// The kernel above hides a K step's memory round trip behind the OTHER workgroups of its CU (three resident).  Shapes with
+// fewer than ~two tiles per CU have nobody to hide behind -- the encoder at batch 1 (align(): M = 1500; N = 1280 is 240 tiles
+// of 128 x 64) runs stage -> wait -> compute serially, ~0.9 us per K step for 0.1-0.2 us of MFMAs: 18.6 us at K = 1280,
+// 65.8 us at K = 5120 (profiles/r02_kb_gemm_narrow_tiles.txt).  Here ONE workgroup keeps NST - 1 K steps in flight: a ring
+// of NST operand stages in LDS, filled by LDS-DMA issued from inline asm (a DMA hipcc can see makes it wait vmcnt(0) before
+// the next LDS read and inside __syncthreads(); cdna_hip_programming.md "glds with >1 tile in flight"), retired by counted
+// `s_waitcnt vmcnt(n)` + a raw `s_barrier`.  Per K step: [wait until stage kt has landed for this wave (the NST - 2 younger
+// stages stay in flight) and this wave's LDS reads of step kt - 1 are back] -> barrier (now true for every wave) -> refill
+// the stage step kt - 1 used -> MFMAs of step kt.  A DMA's data is read one barrier after the wait that retires it, a stage
+// is rewritten one barrier after its last read returned.  Same tile, swizzle, MFMA order per accumulator and epilogue as
+// the kernel above: bit-identical results (tests/hw_checks/gemm_glds_check.py).
+__device__ __forceinline__ void glds16_asm(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;     // M0 is the DMA's LDS base and belongs to hipcc: saved and restored inside the statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void ring_wait_barrier()
+{
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BNT, int NST>
+__device__ __forceinline__ void gemm_f16_ring_body(const GemmArgs &g)
+{
+    constexpr int NJ = BNT / 32;
+    constexpr int TB = BNT * 128;
+    constexpr int STAGE = GL_TILE + TB;
+    constexpr int L = 4 + NJ;                            // DMA instructions per wave and stage
+    static_assert(NST == 3 || NST == 4, "ring depth");
+    static_assert((NST - 2) * L < 64, "vmcnt is a 6-bit field");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];     // NST stages; the f32 epilogue tile afterwards
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = wg % gx; by = wg / gx;
+    }
+    const int m0 = by * BM, n0 = bx * BNT;
+    const f16 *A = (const f16 *)g.A;
+    const f16 *W = (const f16 *)g.W;
+
+    f32x4 acc[4][NJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const f16 *srcA[4], *srcW[NJ];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int r = (wave * 4 + c) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        const int gm = m0 + r < g.M ? m0 + r : g.M - 1;
+        srcA[c] = A + (size_t)gm * g.lda + slot * 8;
+    }
+#pragma unroll
+    for (int c = 0; c < NJ; ++c) {
+        const int r = (wave * NJ + c) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        const int gn = n0 + r < g.N ? n0 + r : g.N - 1;
+        srcW[c] = W + (size_t)gn * g.ldw + slot * 8;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned ring0 = (unsigned)(uintptr_t)(lds_void *)ring;
+    auto stage = [&](int kt, int buf) {
+        const unsigned ta = ring0 + buf * STAGE, tb = ta + GL_TILE;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) glds16_asm(srcA[c] + kt * 64, ta + (wave_u * 4 + c) * 1024);
+#pragma unroll
+        for (int c = 0; c < NJ; ++c) glds16_asm(srcW[c] + kt * 64, tb + (wave_u * NJ + c) * 1024);
+    };
+    const int KT = g.K / 64;                             // the launcher guarantees KT >= NST - 1
+    const int fr = lane & 15, fs = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char *ta = ring + buf * STAGE, *tb = ta + GL_TILE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 a[4], b[NJ];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + fr;
+                a[i] = *(const f16x8 *)(ta + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int row = wn * (BNT / 2) + j * 16 + fr;
+                b[j] = *(const f16x8 *)(tb + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) stage(st, st);
+    int buf = 0, nbuf = NST - 1;                         // stage of step kt, stage the next refill goes to
+    for (int kt = 0; kt < KT; ++kt) {
+        const int ahead = KT - 1 - kt;                   // K steps after this one: min(ahead, NST - 2) stages may stay in flight
+        if (ahead >= NST - 2) ring_wait_barrier<(NST - 2) * L>();
+        else if (NST == 4 && ahead == 1) ring_wait_barrier<L>();
+        else ring_wait_barrier<0>();
+        if (kt + NST - 1 < KT) stage(kt + NST - 1, nbuf);
+        compute(buf);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
+    __syncthreads();                                     // every wave is done with the ring: it becomes the epilogue's f32 tile
+    tile_epilogue_f16<NJ>(g, ring, acc, m0, n0, tid, lane, wm, wn);
+}
+
+template <int BNT, int NST>
+__global__ __launch_bounds__(256) void gemm_f16_ring(GemmArgs g) { gemm_f16_ring_body<BNT, NST>(g); }
+
+template <int BNT, int NST>
+static void launch_ring(const GemmArgs &g, hipStream_t s)
+{
+    constexpr int stage_bytes = GL_TILE + BNT * 128, epi_bytes = 64 * (BNT + 4) * 4;
+    constexpr int lds = NST * stage_bytes > epi_bytes ? NST * stage_bytes : epi_bytes;
+    hipLaunchKernelGGL((gemm_f16_ring<BNT, NST>), dim3(cdiv(g.N, BNT), cdiv(g.M, BM)), dim3(256), lds, s, g);
+}
+
 // ------------------------------------------------------------------------------------------------ tiled f32
 constexpr int BK32 = 16, LD32 = BK32 + 1;
 
@@ -550,7 +680,23 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             // bit-identity reference.  64-column tiles when 128-wide ones would leave CUs idle (encoder at batch 1: M = 1500,
             // N = 1280 is 120 tiles of 128 x 128 for 256 CUs); force_kernel 8 / 9 = always / never (A/B in kernel_bench.py)
             const bool narrow = force_kernel == 8 || (force_kernel != 9 && g.N % 64 == 0 && (int64_t)grid.x * grid.y < 224);
-            if (glds_ok && force_kernel != 1 && narrow)
+            // the ring kernel for launches that leave a CU fewer than two workgroups to overlap (the encoder / cross-K/V at batch 1;
+            // not the one-row-tile logits GEMM, which streams 133 MB of weights); force_kernel 10 .. 13 = 64 / 128 columns at
+            // depth 4, then at depth 3 (A/B in kernel_bench.py)
+            const int64_t tiles = (int64_t)(narrow ? cdiv(g.N, 64) : grid.x) * grid.y;
+            const bool ring_ok = glds_ok && g.K >= 192;
+            if (force_kernel >= 10 && force_kernel <= 13 && !ring_ok) return -4;
+            const bool ring = (force_kernel >= 10 && force_kernel <= 13) ||
+                              (force_kernel == 0 && ring_ok && tiles <= 512 && g.M > 256 && !(swx_flags() & SWX_FLAG_NO_RING));
+            if (ring) {
+                const int code = force_kernel >= 10 ? force_kernel : (narrow ? 10 : 11);
+                switch (code) {
+                    case 10: launch_ring<64, 4>(g, s); break;
+                    case 11: launch_ring<128, 4>(g, s); break;
+                    case 12: launch_ring<64, 3>(g, s); break;
+                    default: launch_ring<128, 3>(g, s); break;
+                }
+            } else if (glds_ok && force_kernel != 1 && narrow)
                 hipLaunchKernelGGL(gemm_f16_glds_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
             else if (glds_ok && force_kernel != 1)
                 hipLaunchKernelGGL(gemm_f16_glds_128, grid, dim3(256), 0, s, g);

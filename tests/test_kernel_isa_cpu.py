@@ -150,3 +150,49 @@ def test_hot_kernels_do_not_spill(src, kernels, max_vgpr):
             assert v["vgpr_count"] <= max_vgpr, (n, v)
             if "gemm_f16_glds" in n:
                 assert v["group_segment_fixed_size"] <= 53 * 1024, (n, v)
+
+
+def test_ring_gemm_k_loop_waits_are_the_counted_ones():
+    """gemm_f16_ring (csrc/swx_gemm.hip): the LDS-DMA of its operand ring is issued from inline asm and retired by hand --
+    `s_waitcnt vmcnt((NST - 2) * L) lgkmcnt(0)` + `s_barrier` per K step, L = DMA instructions per wave and stage.  Audited
+    on the compiled ISA of all four instantiations: (1) between the first DMA and the last MFMA every `vmcnt` wait is one of
+    the asm statements (an `s_waitcnt vmcnt` hipcc adds on its own there would drain the ring); (2) their immediates are
+    exactly {(NST - 2) L, ..., L, 0}; (3) every asm wait is followed by the barrier; (4) no scratch, and the K loop holds
+    2 x 4 x NJ MFMAs per step."""
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not present")
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(ROOT, "stable_ts_amd", "csrc", "swx_gemm.hip")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                               "--cuda-device-only", src, "-o", os.path.join(td, "g.s")], cwd=td, stderr=subprocess.DEVNULL)
+        text = open(os.path.join(td, "g.s")).read()
+    seen = 0
+    for bnt, nst in ((64, 4), (128, 4), (64, 3), (128, 3)):
+        m = re.search(rf"^(_ZN\S*gemm_f16_ringILi{bnt}ELi{nst}E[^\s:]*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+        assert m, (bnt, nst)
+        seen += 1
+        lines = m.group(2).split("\n")
+        L = 4 + bnt // 32
+        dma = [i for i, ln in enumerate(lines) if "global_load_lds_dwordx4" in ln]
+        mfma = [i for i, ln in enumerate(lines) if "v_mfma_f32_16x16x32_f16" in ln]
+        assert len(dma) == (nst - 1) * L + L, (bnt, nst, len(dma))          # prologue stages + the one refill in the loop
+        assert len(mfma) == 2 * 4 * (bnt // 32), (bnt, nst, len(mfma))
+        in_asm, waits = False, []
+        for i in range(dma[0], max(mfma[-1], dma[-1])):      # the K loop's blocks (hipcc places the MFMA block first)
+            ln = lines[i]
+            if "#ASMSTART" in ln:
+                in_asm = True
+            elif "#ASMEND" in ln:
+                in_asm = False
+            w = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", ln)
+            if w:
+                assert in_asm, f"ring<{bnt},{nst}>: hipcc's own `{ln.strip()}` inside the K loop"
+                assert "lgkmcnt(0)" in ln and "s_barrier" in lines[i + 1], (bnt, nst, ln)
+                waits.append(int(w.group(1)))
+        assert sorted(set(waits)) == sorted({k * L for k in range(nst - 1)}), (bnt, nst, waits)
+    assert seen == 4
+    meta = _kernel_meta("swx_gemm.hip")
+    ring = {n: v for n, v in meta.items() if "gemm_f16_ring" in n}
+    assert len(ring) == 4
+    for n, v in ring.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (n, v)
