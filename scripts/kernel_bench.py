@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--only", default="")
     ap.add_argument("--flash-kernel", type=int, default=2, help="force_kernel of the flash attention: 2 default dispatch, 4 / 6 / 5 = 32 / 48 / 64 queries per wave")
-    ap.add_argument("--gemm-kernel", type=int, default=7, help="force_kernel of the tiled GEMM: 1 register-staged, 7 direct-to-LDS (occupancy-overlapped), 8 / 9 = its 64-column tiles always / never, 10 .. 13 ring kernel, 0 = dispatch")
+    ap.add_argument("--gemm-kernel", type=int, default=7, help="force_kernel of the tiled GEMM: 1 register-staged, 7 direct-to-LDS (occupancy-overlapped), 8 / 9 = its 64-column tiles always / never, 10 / 11 ring kernel at 64 / 128 columns, 0 = dispatch")
     args = ap.parse_args()
     from stable_ts_amd import _lib
     lib = _lib.load()
@@ -68,9 +68,9 @@ def main():
 
     if args.only in ("gemm_small",):
         # the encoder / cross-K/V at batch 1 (align(), sequential transcribe()): launches of 240-480 tiles.  7 = the kernel that
-        # overlaps through occupancy, 10 .. 13 = the ring kernel (64 / 128 columns at depth 4, then depth 3), 0 = the dispatch
+        # overlaps through occupancy, 10 / 11 = the ring kernel at 64 / 128 columns, 0 = the dispatch
         print("-- tiled MFMA GEMM at batch 1: us per launch by force_kernel")
-        codes = [7, 10, 11, 12, 13, 0]
+        codes = [7, 10, 11, 0]
         print("  " + " " * 28 + "".join(f"{c:>9d}" for c in codes))
         for M, N, K in [(1500, 1280, 1280), (1500, 3840, 1280), (1500, 5120, 1280), (1500, 1280, 5120), (1500, 2560, 1280),
                         (3000, 1280, 384), (1500, 1280, 3840), (1500, 512, 512), (1500, 2048, 512), (1500, 512, 2048),

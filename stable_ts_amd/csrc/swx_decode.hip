@@ -407,21 +407,32 @@ __global__ __launch_bounds__(SEL_T) void decode_select_reg_kernel(DecodeBufs b, 
             b.row_done[r] = (next == c.eot) ? 1 : 0;
         }
     } else {
+        // top-(G + 1) of the row: every thread keeps the best of its own 51 values; a round is one block arg-max over those,
+        // and only the thread that owned the winner strikes it out and rescans its 51 (the other 15 waves skip the branch).
+        // Rescanning every thread's values in every round -- 6 x 51 compare / select pairs per thread -- was more than half of
+        // this kernel's VALU work.  Same selections: ties go to the smaller index inside a thread and between threads.
         const int K = b.G + 1;
-        for (int kk = 0; kk < K; ++kk) {
+        auto local_best = [&]() {
             ArgMax best; best.v = NEG_INF; best.i = 0x7fffffff;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int i = tid + k * SEL_T;
                 if (i < V) { ArgMax x; x.v = v[k]; x.i = i; best = argmax_combine(best, x); }
             }
-            best = block_argmax(best, sha);
+            return best;
+        };
+        ArgMax mine = local_best();
+        for (int kk = 0; kk < K; ++kk) {
+            const ArgMax best = block_argmax(mine, sha);
             if (tid == 0) {
                 b.cand_lp[(size_t)r * K + kk] = (best.v - mx) - lse;
                 b.cand_tok[(size_t)r * K + kk] = best.i;
             }
+            if ((best.i & (SEL_T - 1)) == tid) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) if (tid + k * SEL_T == best.i) v[k] = NEG_INF;
+                for (int k = 0; k < NV; ++k) if (tid + k * SEL_T == best.i) v[k] = NEG_INF;
+                mine = local_best();
+            }
         }
     }
 }

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 3) void gemm_f16_glds_64(GemmArgs g) { gemm_f1
 // fewer than ~two tiles per CU have nobody to hide behind -- the encoder at batch 1 (align(): M = 1500; N = 1280 is 240 tiles
 // of 128 x 64) runs stage -> wait -> compute serially, ~0.9 us per K step for 0.1-0.2 us of MFMAs: 18.6 us at K = 1280,
 // 65.8 us at K = 5120 (profiles/r02_kb_gemm_narrow_tiles.txt).  Here ONE workgroup keeps NST - 1 K steps in flight: a ring
-// of NST operand stages in LDS, filled by LDS-DMA issued from inline asm (a DMA hipcc can see makes it wait vmcnt(0) before
+// of NST = 3 operand stages in LDS (72 / 96 KB), filled by LDS-DMA issued from inline asm (a DMA hipcc can see makes it wait vmcnt(0) before
 // the next LDS read and inside __syncthreads(); cdna_hip_programming.md "glds with >1 tile in flight"), retired by counted
 // `s_waitcnt vmcnt(n)` + a raw `s_barrier`.  Per K step: [wait until stage kt has landed for this wave (the NST - 2 younger
 // stages stay in flight) and this wave's LDS reads of step kt - 1 are back] -> barrier (now true for every wave) -> refill
@@ -392,7 +392,7 @@ __device__ __forceinline__ void gemm_f16_ring_body(const GemmArgs &g)
     constexpr int TB = BNT * 128;
     constexpr int STAGE = GL_TILE + TB;
     constexpr int L = 4 + NJ;                            // DMA instructions per wave and stage
-    static_assert(NST == 3 || NST == 4, "ring depth");
+    static_assert(NST == 3 || NST == 4, "ring depth");      // depth 4 measured no better than 3 anywhere and was not kept
     static_assert((NST - 2) * L < 64, "vmcnt is a 6-bit field");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];     // NST stages; the f32 epilogue tile afterwards
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -680,22 +680,19 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             // bit-identity reference.  64-column tiles when 128-wide ones would leave CUs idle (encoder at batch 1: M = 1500,
             // N = 1280 is 120 tiles of 128 x 128 for 256 CUs); force_kernel 8 / 9 = always / never (A/B in kernel_bench.py)
             const bool narrow = force_kernel == 8 || (force_kernel != 9 && g.N % 64 == 0 && (int64_t)grid.x * grid.y < 224);
-            // the ring kernel for launches that leave a CU fewer than two workgroups to overlap (the encoder / cross-K/V at batch 1;
-            // not the one-row-tile logits GEMM, which streams 133 MB of weights); force_kernel 10 .. 13 = 64 / 128 columns at
-            // depth 4, then at depth 3 (A/B in kernel_bench.py)
-            const int64_t tiles = (int64_t)(narrow ? cdiv(g.N, 64) : grid.x) * grid.y;
-            const bool ring_ok = glds_ok && g.K >= 192;
-            if (force_kernel >= 10 && force_kernel <= 13 && !ring_ok) return -4;
-            const bool ring = (force_kernel >= 10 && force_kernel <= 13) ||
-                              (force_kernel == 0 && ring_ok && tiles <= 512 && g.M > 256 && !(swx_flags() & SWX_FLAG_NO_RING));
+            // the ring kernel for launches of at most one workgroup per CU (the encoder / cross-K/V at batch 1: 64-column tiles
+            // when `narrow`, else 128-column ones up to 256 tiles); from ~1.5 workgroups per CU on, the kernel above -- three
+            // resident workgroups, epilogues overlapped with the neighbours' MFMAs -- is as fast or faster (N = 3840 / 5120 at
+            // M = 1500: 29.3 / 29.6 us against 33.4 / 35.9; profiles/r03_kb_gemm_ring.txt).  Not the one-row-tile logits GEMM,
+            // which streams 133 MB of weights.  force_kernel 10 / 11 pin the ring at 64 / 128 columns (kernel_bench.py)
+            const bool ring_ok = glds_ok && g.K >= 128;
+            if ((force_kernel == 10 || force_kernel == 11) && !ring_ok) return -4;
+            const bool ring = force_kernel == 10 || force_kernel == 11 ||
+                              (force_kernel == 0 && ring_ok && g.M > 256 && (narrow || (int64_t)grid.x * grid.y <= 256) &&
+                               !(swx_flags() & SWX_FLAG_NO_RING));
             if (ring) {
-                const int code = force_kernel >= 10 ? force_kernel : (narrow ? 10 : 11);
-                switch (code) {
-                    case 10: launch_ring<64, 4>(g, s); break;
-                    case 11: launch_ring<128, 4>(g, s); break;
-                    case 12: launch_ring<64, 3>(g, s); break;
-                    default: launch_ring<128, 3>(g, s); break;
-                }
+                if (force_kernel == 10 || (force_kernel == 0 && narrow)) launch_ring<64, 3>(g, s);
+                else launch_ring<128, 3>(g, s);
             } else if (glds_ok && force_kernel != 1 && narrow)
                 hipLaunchKernelGGL(gemm_f16_glds_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
             else if (glds_ok && force_kernel != 1)

@@ -155,7 +155,7 @@ def test_hot_kernels_do_not_spill(src, kernels, max_vgpr):
 def test_ring_gemm_k_loop_waits_are_the_counted_ones():
     """gemm_f16_ring (csrc/swx_gemm.hip): the LDS-DMA of its operand ring is issued from inline asm and retired by hand --
     `s_waitcnt vmcnt((NST - 2) * L) lgkmcnt(0)` + `s_barrier` per K step, L = DMA instructions per wave and stage.  Audited
-    on the compiled ISA of all four instantiations: (1) between the first DMA and the last MFMA every `vmcnt` wait is one of
+    on the compiled ISA of both instantiations (64- and 128-column tiles, depth 3): (1) between the first DMA and the last MFMA every `vmcnt` wait is one of
     the asm statements (an `s_waitcnt vmcnt` hipcc adds on its own there would drain the ring); (2) their immediates are
     exactly {(NST - 2) L, ..., L, 0}; (3) every asm wait is followed by the barrier; (4) no scratch, and the K loop holds
     2 x 4 x NJ MFMAs per step."""
@@ -167,7 +167,7 @@ def test_ring_gemm_k_loop_waits_are_the_counted_ones():
                                "--cuda-device-only", src, "-o", os.path.join(td, "g.s")], cwd=td, stderr=subprocess.DEVNULL)
         text = open(os.path.join(td, "g.s")).read()
     seen = 0
-    for bnt, nst in ((64, 4), (128, 4), (64, 3), (128, 3)):
+    for bnt, nst in ((64, 3), (128, 3)):
         m = re.search(rf"^(_ZN\S*gemm_f16_ringILi{bnt}ELi{nst}E[^\s:]*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
         assert m, (bnt, nst)
         seen += 1
@@ -190,9 +190,9 @@ def test_ring_gemm_k_loop_waits_are_the_counted_ones():
                 assert "lgkmcnt(0)" in ln and "s_barrier" in lines[i + 1], (bnt, nst, ln)
                 waits.append(int(w.group(1)))
         assert sorted(set(waits)) == sorted({k * L for k in range(nst - 1)}), (bnt, nst, waits)
-    assert seen == 4
+    assert seen == 2
     meta = _kernel_meta("swx_gemm.hip")
     ring = {n: v for n, v in meta.items() if "gemm_f16_ring" in n}
-    assert len(ring) == 4
+    assert len(ring) == 2
     for n, v in ring.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (n, v)
