@@ -1,6 +1,6 @@
 """Per-kernel micro-benchmarks at the bench workload's shapes (large-v3, 20 windows x beam 5) through libswx's test hooks.
 
-    python scripts/kernel_bench.py [--iters 200] [--only gemm|gemm_small|flash|flash_small|cross|dec|dtw]
+    python scripts/kernel_bench.py [--iters 200] [--only gemm|gemm_small|gemm_big|flash|flash_small|cross|dec|dtw]
 
 One HIP-event pair brackets `iters` back-to-back launches of the same kernel, so the figure is the steady-state
 launch-to-launch time (kernel + one kernel boundary), which is what a dependent chain such as the decode step pays.
@@ -83,6 +83,24 @@ def main():
                 row.append(timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, code, st),
                                  max(args.iters // 4, 5)) if rc == 0 else float("nan"))
             print(f"  M={M:6d} N={N:6d} K={K:5d}:" + "".join(f"{u:9.1f}" for u in row))
+
+    if args.only in ("gemm_big",):
+        # the encoder at 20 / 8 / 4 windows: 7 = 128 x 128 tiles overlapped through occupancy, 12 = 256 x 256 two-stage kernel
+        print("-- tiled MFMA GEMM at large M: us per launch (TFLOP/s) by force_kernel")
+        codes = [7, 12, 0]
+        print("  " + " " * 28 + "".join(f"{c:>18d}" for c in codes))
+        for M, N, K in [(30000, 1280, 1280), (30000, 3840, 1280), (30000, 5120, 1280), (30000, 1280, 5120), (30000, 2560, 1280),
+                        (12000, 1280, 1280), (12000, 3840, 1280), (12000, 5120, 1280), (12000, 1280, 5120),
+                        (6000, 3840, 1280), (6000, 5120, 1280), (6000, 1280, 5120), (60000, 1280, 384), (30000, 1280, 3840)]:
+            a, w, c = rnd(M, K), rnd(N, K), torch.empty(M, N, dtype=torch.half, device=dev)
+            bias = torch.zeros(N, device=dev)
+            row = []
+            epi = EPI_BIAS | (2 if N == 5120 else 0)          # the MLP's first projection carries the GELU
+            for code in codes:
+                rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, epi, code, st)
+                row.append(timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, epi, code, st),
+                                 max(args.iters // 10, 5)) if rc == 0 else float("nan"))
+            print(f"  M={M:6d} N={N:6d} K={K:5d}:" + "".join(f"{u:9.1f} ({2.0 * M * N * K / u / 1e6:6.0f})" for u in row))
 
     if args.only in ("flash_small",):
         print("-- encoder self-attention at batch 1 (B=1 H=20 nq=nk=1500) and batch 2 / 4: us per launch by queries per wave")

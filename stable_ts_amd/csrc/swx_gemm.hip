@@ -491,6 +491,155 @@ static void launch_ring(const GemmArgs &g, hipStream_t s)
     hipLaunchKernelGGL((gemm_f16_ring<BNT, NST>), dim3(cdiv(g.N, BNT), cdiv(g.M, BM)), dim3(256), lds, s, g);
 }
 
+// ---------------------------------------------------------------------- tiled f16, 256 x 256 tile, 8 waves, two stages
+// The large-M shapes (encoder at 20 windows: M = 30 000).  The 128 x 128 tile above reads 16 KB of fragments from LDS per wave
+// and K step for 32 MFMAs -- 64 KB per workgroup against an LDS port of 128 B/clk: exactly as many LDS cycles as MFMA cycles,
+// which is what holds that kernel at 0.29-0.34 of the MFMA peak however it is scheduled.  Here a wave owns 128 x 64 of a
+// 256 x 256 tile (8 waves as 2 x 4): 24 fragment reads feed 64 MFMAs, 0.75 LDS cycles per MFMA cycle.  One workgroup per CU
+// (two waves per SIMD, 128 accumulator registers each), two 64 KB operand stages filled by the ring kernel's asm LDS-DMA:
+// K step kt + 1 lands while step kt computes; one `vmcnt(0)` + raw barrier per step.  Plain epilogues only (bias, GELU, f16
+// residual, f16 rows with 16-byte aligned leading dimensions): the encoder's four projections; everything else stays on the
+// kernels above.  Same MFMA order per accumulator: bit-identical results (tests/hw_checks/gemm_glds_check.py).
+constexpr int BG = 256;                                   // tile edge
+constexpr int BG_STAGE = 2 * BG * 128;                    // bytes per stage: A 256 rows x 64 halfs | B the same
+constexpr int BG_CLD = BG + 4;                            // f32 epilogue row
+
+__global__ __launch_bounds__(512) void gemm_f16_big(GemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];     // 2 stages = 128 KB; the epilogue's 64 x 260 f32 after
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 2, wn = wave & 3;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = wg % gx; by = wg / gx;
+    }
+    const int m0 = by * BG, n0 = bx * BG;
+    const f16 *A = (const f16 *)g.A;
+    const f16 *W = (const f16 *)g.W;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // a wave stages four 8-row chunks of each operand per K step (chunk = wave * 4 + c; rows past M / N clamped)
+    const f16 *srcA[4], *srcW[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int r = (wave * 4 + c) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((r >> 1) & 7);
+        const int gm = m0 + r < g.M ? m0 + r : g.M - 1;
+        const int gn = n0 + r < g.N ? n0 + r : g.N - 1;
+        srcA[c] = A + (size_t)gm * g.lda + slot * 8;
+        srcW[c] = W + (size_t)gn * g.ldw + slot * 8;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned ring0 = (unsigned)(uintptr_t)(lds_void *)ring;
+    auto stage = [&](int kt, int buf) {
+        const unsigned ta = ring0 + buf * BG_STAGE, tb = ta + BG * 128;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) glds16_asm(srcA[c] + kt * 64, ta + (wave_u * 4 + c) * 1024);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) glds16_asm(srcW[c] + kt * 64, tb + (wave_u * 4 + c) * 1024);
+    };
+    const int KT = g.K / 64;
+    const int fr = lane & 15, fs = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char *ta = ring + buf * BG_STAGE, *tb = ta + BG * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            f16x8 a[8], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + fr;
+                b[j] = *(const f16x8 *)(tb + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = wm * 128 + i * 16 + fr;
+                a[i] = *(const f16x8 *)(ta + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        ring_wait_barrier<0>();                          // stage kt landed for every wave; every wave is done with stage kt - 1
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        compute(kt & 1);
+    }
+    __syncthreads();
+
+    // epilogue: four passes of 64 rows through a f32 tile in LDS, 16-byte row-contiguous stores (tile_epilogue_f16's plain path)
+    float (*Cs)[BG_CLD] = (float (*)[BG_CLD])ring;
+    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const int c8 = (tid & 31) * 8, rb = tid >> 5, gn = n0 + c8;
+    const bool col_ok = gn < g.N, full = gn + 8 <= g.N;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = ((g.epi & EPI_BIAS) && gn + e < g.N) ? g.bias[gn + e] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f16x8 rv[4];
+        if (g.epi & EPI_RES) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int gm = m0 + p * 64 + it * 16 + rb;
+                rv[it] = (gm < g.M && full) ? *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn) : (f16x8)(f16)0;
+            }
+        }
+        if (wm == (p >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[ii * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[(p & 1) * 4 + ii][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 16 + rb, gm = m0 + p * 64 + row;
+            if (gm >= g.M || !col_ok) continue;
+            const f32x4 lo = *(const f32x4 *)&Cs[row][c8], hi = *(const f32x4 *)&Cs[row][c8 + 4];
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            if (g.epi & EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            }
+            f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
+            if (full) {
+                if (g.epi & EPI_RES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[it][e];
+                }
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+                *(f16x8 *)cp = o;
+            } else {
+                for (int e = 0; e < 8 && gn + e < g.N; ++e) {
+                    float t = v[e];
+                    if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
+                    cp[e] = (f16)t;
+                }
+            }
+        }
+        if (p < 3) __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ tiled f32
 constexpr int BK32 = 16, LD32 = BK32 + 1;
 
@@ -685,6 +834,23 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             // resident workgroups, epilogues overlapped with the neighbours' MFMAs -- is as fast or faster (N = 3840 / 5120 at
             // M = 1500: 29.3 / 29.6 us against 33.4 / 35.9; profiles/r03_kb_gemm_ring.txt).  Not the one-row-tile logits GEMM,
             // which streams 133 MB of weights.  force_kernel 10 / 11 pin the ring at 64 / 128 columns (kernel_bench.py)
+            // the 256 x 256 kernel (force_kernel 12): plain epilogues, when its tiles fill whole rounds of the 256 CUs -- one
+            // workgroup per CU, so a last round that is 30 % full costs a full round (M = 6000, N = 3840: 360 tiles, 769 against
+            // 885 TFLOP/s) -- or nearly so with a long K to amortise prologue and epilogue (M = 30 000, N = 1280, K = 5120: 590
+            // tiles, 979 against 892); not for K < 512.  profiles/r03_kb_gemm_big.txt
+            const bool big_ok = glds_ok && !(g.epi & ~(EPI_BIAS | EPI_GELU | EPI_RES)) && g.ldc % 8 == 0 && (uintptr_t)g.C % 16 == 0 &&
+                                (!(g.epi & EPI_RES) || (g.ldr % 8 == 0 && (uintptr_t)g.R % 16 == 0));
+            if (force_kernel == 12 && !big_ok) return -4;
+            const int64_t t256 = (int64_t)cdiv(g.M, BG) * cdiv(g.N, BG);
+            const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+            const bool big = force_kernel == 12 || (force_kernel == 0 && big_ok && t256 >= 200 && g.K >= 512 &&
+                                                    (fill >= 0.9 || (fill >= 0.75 && g.K >= 2560)) &&
+                                                    !(swx_flags() & SWX_FLAG_NO_BIG_TILE));
+            if (big) {
+                hipLaunchKernelGGL(gemm_f16_big, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * BG_STAGE, s, g);
+                SWX_CHECK_LAUNCH();
+                return 0;
+            }
             const bool ring_ok = glds_ok && g.K >= 128;
             if ((force_kernel == 10 || force_kernel == 11) && !ring_ok) return -4;
             const bool ring = force_kernel == 10 || force_kernel == 11 ||

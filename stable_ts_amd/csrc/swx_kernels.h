@@ -37,6 +37,7 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 #define SWX_FLAG_NO_GRAPH 16384       // decode loop: launch every step eagerly instead of replaying the captured two-step graph
 #define SWX_FLAG_NO_PREFETCH 32768    // decode step: no cache prefetch of the next projection's weights (A/B; no functional effect)
 #define SWX_FLAG_NO_RING 65536        // tiled GEMM: never the ring kernel for launches with few tiles (A/B; results are bit-identical)
+#define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
 

@@ -308,7 +308,7 @@ def test_attention_decode_cross_kernel(B, H, nq, nk):
 
 @pytest.mark.parametrize("check", ["gemm_glds_check.py", "mel_ragged_check.py", "score_qk_check.py"])
 def test_new_kernel_paths_in_subprocess(check):
-    # gemm_f16_glds (direct-to-LDS tiled GEMM, both tile widths, vs the register-staged kernel: bit-identical) and
+    # gemm_f16_glds / gemm_f16_ring / gemm_f16_big (the direct-to-LDS tiled GEMMs vs the register-staged kernel: bit-identical) and
     # swx_log_mel_ragged (the un-padded spectrogram of refine / locate; index logic CPU-checked in test_mel_ragged_cpu),
     # swx_score_qk (raw per-head scores for the dynamic-heads / 'new' aligner variants; host logic CPU-checked).  Own
     # process: a first-ever hardware run of new device code must not be able to disturb this process's GPU context.
@@ -316,7 +316,7 @@ def test_new_kernel_paths_in_subprocess(check):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "hw_checks", check)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(here, "hw_checks", check)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
 
 
