@@ -62,6 +62,8 @@ class Engine:
         self.max_windows = 0
         self.max_rows = 0
         self.ws = None
+        self.encode_calls = 0          # device passes through the encoder / 30-s windows in them (bench.py reports both)
+        self.encode_windows = 0
         self.reserve(max_windows, max_rows)
 
     def clone_shared(self, max_windows: Optional[int] = None, max_rows: Optional[int] = None) -> "Engine":
@@ -79,6 +81,7 @@ class Engine:
         if self._heads is not None:
             e.set_alignment_heads(self._heads)
         e.max_windows, e.max_rows, e.ws = 0, 0, None
+        e.encode_calls = e.encode_windows = 0
         e.reserve(self.max_windows if max_windows is None else max_windows, self.max_rows if max_rows is None else max_rows)
         return e
 
@@ -200,6 +203,8 @@ class Engine:
         self.reserve(max(B, self.max_windows), max(self.max_rows, 1))
         xa = torch.empty(B, self.dims.n_audio_ctx, self.dims.n_audio_state, dtype=self.tdtype, device=self.device)
         check(self.lib.swx_encode(self.h, _ptr(mel), B, _ptr(xa), self.stream), "swx_encode")
+        self.encode_calls += 1
+        self.encode_windows += B
         return xa
 
     def cross_kv(self, xa: torch.Tensor) -> torch.Tensor:
