@@ -16,7 +16,7 @@ cd $R
 python - "$tag" <<'PY'
 import sqlite3, glob, json, sys, collections
 tag = sys.argv[1]
-CLASSES = [("gemm_dec_f16", "decode-step GEMM"), ("attn_decode_cross", "attn_decode_cross_f16"), ("gemm_f16_glds", "gemm_f16_tiled"),
+CLASSES = [("gemm_dec_f16", "decode-step GEMM"), ("attn_decode_cross", "attn_decode_cross_f16"), ("gemm_f16_glds", "gemm_f16_tiled"), ("gemm_f16_big", "gemm_f16_tiled"), ("gemm_f16_ring", "gemm_f16_tiled"),
            ("gemm_f16_tiled", "gemm_f16_tiled"), ("attn_flash", "attn_flash_f16"), ("self_attn_step", "self_attn (decode step)"),
            ("decode_select", "decode_select"), ("dec_slab_finish", "splitk_finish / layernorm"), ("layernorm_kernel", "splitk_finish / layernorm"),
            ("swx_dtw", "dtw"), ("swx_align", "align_weights"), ("swx_mel", "mel")]
