@@ -231,7 +231,7 @@ int swx_prof_enable(int on);
  * per-op path instead of the fused "dec" step (its reference), 2048 = decode cross-attention on the row-layout K / V^T
  * (reference of the fragment-ordered copy), 8192 = memory-walking logit filters (reference of the register kernel),
  * 16384 = decode loop without the captured step graph, 32768 = decode step without the cache prefetch of the next projection's
- * weights.  Default 0; nothing reads an environment variable.
+ * weights, 65536 / 131072 = tiled GEMM never on the ring / the 256 x 256 kernel (bit-identical either way).  Default 0; nothing reads an environment variable.
  * flags < 0 only queries.  Returns the previous value. */
 int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);
@@ -242,6 +242,9 @@ int swx_graph_stats(const swx_model *m, int64_t *out);
 /* ---- building blocks exported for the parity tests (same kernels the calls above launch) */
 int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, const float *d_bias, const void *d_res,
                   void *d_c, int64_t ldc, int M, int N, int K, int epilogue, int force_kernel, void *stream);
+/* which f16 kernel swx_test_gemm's launch would get (host-only, no GPU): 0 register-staged tiled, 1 skinny, 2 / 3 direct-to-LDS
+ * with 128 / 64-column tiles, 4 / 5 the LDS-DMA ring at 64 / 128 columns, 6 the 256 x 256 two-stage kernel; < 0: not offered */
+int swx_test_gemm_plan(int M, int N, int K, int epilogue, int force_kernel, int flags);
 /* decode-step "dec" GEMM (csrc/swx_decstep.hip), f16: epilogue bits 1 = LayerNorm fold (gamma / beta given, A = raw rows, K = full
  * row), 2 = GELU, 4 = residual update of d_x in place, 8 = QKV scatter (columns >= d go to the caches at pos0[m]), 16 = K-split
  * allowed.  d_scratch: >= N*K*2 + 8N + slab bytes + 1 KiB. */

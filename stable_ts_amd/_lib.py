@@ -84,6 +84,7 @@ SYMBOLS = {
     "swx_graph_stats": (c_int, [c_void_p, POINTER(c_int64)]),
     "swx_test_gemm": (c_int, [c_int, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                               c_int, c_int, c_int, c_void_p]),
+    "swx_test_gemm_plan": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "swx_test_dec_gemm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                   c_void_p]),

@@ -798,15 +798,56 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
 
 }  // namespace
 
+// Which f16 kernel a launch gets.  One pure function (no device state) so that the rule is testable without a GPU
+// (tests/test_gemm_plan_cpu.py restates the benchmarked shapes) and is what swx_gemm executes.  `ptr16` = A, W (and C / R for
+// the big kernel's vector epilogue) are 16-byte aligned; `force_kernel`: 0 dispatch, 1 register-staged, 2 skinny, 7 direct-to-LDS
+// with occupancy overlap (8 / 9: its 64-column tiles always / never), 10 / 11 ring at 64 / 128 columns, 12 the 256 x 256 kernel.
+int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bool ptr16, int force_kernel, int flags)
+{
+    if (K % 32 != 0) return -4;                                            // tiled: K % 32, skinny: K % 128
+    const bool skinny_ok = M <= 128 && K % 128 == 0 && K / 128 <= 10 && N <= 16384;   // vocabulary-sized N: tiled
+    if (force_kernel == 2) return skinny_ok ? SWX_GEMM_SKINNY : -4;
+    if (skinny_ok && force_kernel != 1 && force_kernel < 7) return SWX_GEMM_SKINNY;
+    const bool glds_ok = K % 64 == 0 && ptr16;
+    if (force_kernel >= 7 && !glds_ok) return -4;
+    if (force_kernel == 1 || !glds_ok) return SWX_GEMM_TILED_REG;          // K % 64 != 0, and the bit-identity reference
+    const int64_t t128 = (int64_t)cdiv(N, BN) * cdiv(M, BM);
+    // 64-column tiles when 128-wide ones would leave CUs idle (encoder at one window: M = 1500, N = 1280 is 120 tiles of
+    // 128 x 128 for 256 CUs)
+    const bool narrow = force_kernel == 8 || (force_kernel != 9 && N % 64 == 0 && t128 < 224);
+    // the 256 x 256 kernel: plain epilogues, when its tiles fill whole rounds of the 256 CUs -- one workgroup per CU, so a last
+    // round that is 30 % full costs a full round (M = 6000, N = 3840: 360 tiles, 769 against 885 TFLOP/s) -- or nearly so with
+    // a long K to amortise prologue and epilogue (M = 30 000, N = 1280, K = 5120: 590 tiles, 979 against 892); not for K < 512
+    // (profiles/r03_kb_gemm_big.txt)
+    const bool big_ok = !(epi & ~(EPI_BIAS | EPI_GELU | EPI_RES)) && ldc % 8 == 0 && (!(epi & EPI_RES) || ldr % 8 == 0);
+    if (force_kernel == 12) return big_ok ? SWX_GEMM_BIG : -4;
+    const int64_t t256 = (int64_t)cdiv(M, BG) * cdiv(N, BG);
+    const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    if (force_kernel == 0 && big_ok && t256 >= 200 && K >= 512 && (fill >= 0.9 || (fill >= 0.75 && K >= 2560)) &&
+        !(flags & SWX_FLAG_NO_BIG_TILE))
+        return SWX_GEMM_BIG;
+    // the ring kernel for launches of at most one workgroup per CU (the encoder / cross-K/V at one window: 64-column tiles when
+    // `narrow`, else 128-column ones up to 256 tiles); from ~1.5 workgroups per CU on, gemm_f16_glds -- three resident
+    // workgroups, epilogues overlapped with the neighbours' MFMAs -- is as fast or faster (N = 3840 / 5120 at M = 1500: 29.3 /
+    // 29.6 us against 33.4 / 35.9; profiles/r03_kb_gemm_ring.txt).  Not the one-row-tile logits GEMM (133 MB of weights).
+    const bool ring_ok = K >= 128;
+    if (force_kernel == 10 || force_kernel == 11) return !ring_ok ? -4 : force_kernel == 10 ? SWX_GEMM_RING64 : SWX_GEMM_RING128;
+    if (force_kernel == 0 && ring_ok && M > 256 && (narrow || t128 <= 256) && !(flags & SWX_FLAG_NO_RING))
+        return narrow ? SWX_GEMM_RING64 : SWX_GEMM_RING128;
+    return narrow ? SWX_GEMM_GLDS64 : SWX_GEMM_GLDS128;
+}
+
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
 {
     if (g.M <= 0 || g.N <= 0) return 0;
     if (dtype == SWX_F16) {
-        if (g.K % 32 != 0 || g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;   // tiled: K % 32, skinny: K % 128
-        const bool skinny_ok = g.M <= 128 && g.K % 128 == 0 && g.K / 128 <= 10 && g.N <= 16384;   // vocabulary-sized N: tiled
-        const bool use_skinny = force_kernel == 2 ? skinny_ok : ((force_kernel == 1 || force_kernel >= 7) ? false : skinny_ok);
-        if (force_kernel == 2 && !skinny_ok) return -4;
-        if (use_skinny) {
+        if (g.lda % 8 != 0 || g.ldw % 8 != 0) return -4;
+        const bool ptr16 = (uintptr_t)g.A % 16 == 0 && (uintptr_t)g.W % 16 == 0;
+        // (C / R alignment only matters to the big kernel's 16-byte epilogue: withheld from it by an unaligned leading dimension)
+        const bool cr16 = (uintptr_t)g.C % 16 == 0 && (!(g.epi & EPI_RES) || (uintptr_t)g.R % 16 == 0);
+        const int plan = swx_gemm_plan_f16(g.M, g.N, g.K, g.epi, cr16 ? g.ldc : 1, cr16 ? g.ldr : 1, ptr16, force_kernel, swx_flags());
+        if (plan < 0) return plan;
+        if (plan == SWX_GEMM_SKINNY) {
             SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * ((g.epi & EPI_OUT_F32) ? 4 : 2), s);
             dim3 grid(cdiv(g.N, 16));
             const int mt = cdiv(g.M, 16);
@@ -822,49 +863,16 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             }
         } else {
             SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
-            dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
-            const bool glds_ok = g.K % 64 == 0 && ((uintptr_t)g.A % 16 == 0) && ((uintptr_t)g.W % 16 == 0);
-            if (force_kernel >= 7 && !glds_ok) return -4;
-            // direct-to-LDS kernel by default; the register-staged kernel (force_kernel 1) serves K % 64 != 0 and is the
-            // bit-identity reference.  64-column tiles when 128-wide ones would leave CUs idle (encoder at batch 1: M = 1500,
-            // N = 1280 is 120 tiles of 128 x 128 for 256 CUs); force_kernel 8 / 9 = always / never (A/B in kernel_bench.py)
-            const bool narrow = force_kernel == 8 || (force_kernel != 9 && g.N % 64 == 0 && (int64_t)grid.x * grid.y < 224);
-            // the ring kernel for launches of at most one workgroup per CU (the encoder / cross-K/V at batch 1: 64-column tiles
-            // when `narrow`, else 128-column ones up to 256 tiles); from ~1.5 workgroups per CU on, the kernel above -- three
-            // resident workgroups, epilogues overlapped with the neighbours' MFMAs -- is as fast or faster (N = 3840 / 5120 at
-            // M = 1500: 29.3 / 29.6 us against 33.4 / 35.9; profiles/r03_kb_gemm_ring.txt).  Not the one-row-tile logits GEMM,
-            // which streams 133 MB of weights.  force_kernel 10 / 11 pin the ring at 64 / 128 columns (kernel_bench.py)
-            // the 256 x 256 kernel (force_kernel 12): plain epilogues, when its tiles fill whole rounds of the 256 CUs -- one
-            // workgroup per CU, so a last round that is 30 % full costs a full round (M = 6000, N = 3840: 360 tiles, 769 against
-            // 885 TFLOP/s) -- or nearly so with a long K to amortise prologue and epilogue (M = 30 000, N = 1280, K = 5120: 590
-            // tiles, 979 against 892); not for K < 512.  profiles/r03_kb_gemm_big.txt
-            const bool big_ok = glds_ok && !(g.epi & ~(EPI_BIAS | EPI_GELU | EPI_RES)) && g.ldc % 8 == 0 && (uintptr_t)g.C % 16 == 0 &&
-                                (!(g.epi & EPI_RES) || (g.ldr % 8 == 0 && (uintptr_t)g.R % 16 == 0));
-            if (force_kernel == 12 && !big_ok) return -4;
-            const int64_t t256 = (int64_t)cdiv(g.M, BG) * cdiv(g.N, BG);
-            const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-            const bool big = force_kernel == 12 || (force_kernel == 0 && big_ok && t256 >= 200 && g.K >= 512 &&
-                                                    (fill >= 0.9 || (fill >= 0.75 && g.K >= 2560)) &&
-                                                    !(swx_flags() & SWX_FLAG_NO_BIG_TILE));
-            if (big) {
-                hipLaunchKernelGGL(gemm_f16_big, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * BG_STAGE, s, g);
-                SWX_CHECK_LAUNCH();
-                return 0;
+            const dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
+            switch (plan) {
+                case SWX_GEMM_BIG:
+                    hipLaunchKernelGGL(gemm_f16_big, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * BG_STAGE, s, g); break;
+                case SWX_GEMM_RING64: launch_ring<64, 3>(g, s); break;
+                case SWX_GEMM_RING128: launch_ring<128, 3>(g, s); break;
+                case SWX_GEMM_GLDS64: hipLaunchKernelGGL(gemm_f16_glds_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g); break;
+                case SWX_GEMM_GLDS128: hipLaunchKernelGGL(gemm_f16_glds_128, grid, dim3(256), 0, s, g); break;
+                default: hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g); break;
             }
-            const bool ring_ok = glds_ok && g.K >= 128;
-            if ((force_kernel == 10 || force_kernel == 11) && !ring_ok) return -4;
-            const bool ring = force_kernel == 10 || force_kernel == 11 ||
-                              (force_kernel == 0 && ring_ok && g.M > 256 && (narrow || (int64_t)grid.x * grid.y <= 256) &&
-                               !(swx_flags() & SWX_FLAG_NO_RING));
-            if (ring) {
-                if (force_kernel == 10 || (force_kernel == 0 && narrow)) launch_ring<64, 3>(g, s);
-                else launch_ring<128, 3>(g, s);
-            } else if (glds_ok && force_kernel != 1 && narrow)
-                hipLaunchKernelGGL(gemm_f16_glds_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g);
-            else if (glds_ok && force_kernel != 1)
-                hipLaunchKernelGGL(gemm_f16_glds_128, grid, dim3(256), 0, s, g);
-            else
-                hipLaunchKernelGGL(gemm_f16_tiled, grid, dim3(256), 0, s, g);
         }
     } else {
         if (g.K % 16 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return -4;

@@ -24,6 +24,10 @@ struct GemmArgs {
     int vt_s, vt_kp; int64_t vt_bs;   // EPI_STORE_VT: rows per batch item, padded key stride, element stride between batch items
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
+// the f16 kernel a launch gets (swx_gemm.hip; a pure function of the shape, the epilogue and the switches)
+enum { SWX_GEMM_TILED_REG = 0, SWX_GEMM_SKINNY = 1, SWX_GEMM_GLDS128 = 2, SWX_GEMM_GLDS64 = 3, SWX_GEMM_RING64 = 4, SWX_GEMM_RING128 = 5,
+       SWX_GEMM_BIG = 6 };
+int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bool ptr16, int force_kernel, int flags);
 
 // ---- run-time A/B switches (swx_debug_flags(); tests and scripts only -- no environment variable reads them).  Each one
 //      selects the bit-identity / parity REFERENCE of a kernel class; the superseded generations these flags used to keep

@@ -1457,6 +1457,13 @@ int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, cons
     return swx_gemm(dtype, g, force_kernel, S(stream));
 }
 
+// the f16 kernel swx_gemm picks for a launch (contiguous, 16-byte aligned operands assumed): 0 register-staged tiled, 1 skinny,
+// 2 / 3 direct-to-LDS at 128 / 64 columns, 4 / 5 ring at 64 / 128 columns, 6 the 256 x 256 kernel; < 0 = not offered.  No GPU needed.
+int swx_test_gemm_plan(int M, int N, int K, int epilogue, int force_kernel, int flags)
+{
+    return swx_gemm_plan_f16(M, N, K, epilogue, N, N, true, force_kernel, flags);
+}
+
 int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float *d_gamma, const float *d_beta, const float *d_bias,
                       void *d_c, int64_t ldc, void *d_x, void *d_kcache, void *d_vcache, const int32_t *d_pos0, int n_ctx, int d,
                       int M, int N, int K, int epilogue, void *d_scratch, size_t scratch_bytes, void *stream)
