@@ -3,12 +3,15 @@
 // Every Linear / Conv1d of the Whisper encoder and decoder (upstream whisper/model.py, reached from
 // stable_whisper/decode.py:27-30,40 and timing.py:59-61) goes through these kernels.  Weights keep the
 // checkpoint's [out, in] layout, so both operands are K-contiguous ("B^T input") and each MFMA fragment is one
-// 16-byte load.  Three kernels:
-//   * tiled f16   128x128x32 block tile, 4 waves (2x2), 4x4 v_mfma_f32_16x16x32_f16 per wave, LDS double buffer,
-//                 register-staged global->LDS copies                                   (MFMA-bound shapes)
-//   * tiled f32   same tiling on v_mfma_f32_16x16x4_f32 (exact f32 fma chain)         (strict-parity mode)
-//   * skinny f16  M <= 128 rows: one 16-column weight panel per workgroup, K split over its 4 waves, weights
-//                 streamed straight from HBM into MFMA fragments (no LDS), LDS reduction (HBM-bound decode steps)
+// 16-byte load.  The kernels (swx_gemm_plan_f16 at the end of the file says which launch gets which):
+//   * tiled f16, register-staged   128x128x64 tile, 4 waves (2x2), 4x4 v_mfma_f32_16x16x32_f16 per wave: K % 64 != 0, and the
+//                                  bit-identity reference of the four below
+//   * gemm_f16_glds_128 / _64      the same tile filled by LDS-DMA, one operand buffer, three workgroups per CU overlap each other
+//   * gemm_f16_ring<64|128, 3>     launches with <= 1 workgroup per CU: three LDS stages, LDS-DMA from inline asm, counted waits
+//   * gemm_f16_big                 256x256 tile, 8 waves, two LDS-DMA stages: launches that fill whole rounds of the 256 CUs
+//   * tiled f32                    the 128x128 tiling on v_mfma_f32_16x16x4_f32 (exact f32 fma chain)     (strict-parity mode)
+//   * skinny f16                   M <= 128 rows: one 16-column weight panel per workgroup, K split over its 4 waves, weights
+//                                  streamed straight from HBM into MFMA fragments (no LDS), LDS reduction
 // Epilogue (f32): +bias, GELU(erf), +f32 residual indexed by row % res_mod (positional embedding), +T residual,
 // store as T or f32.
 #include <cstdlib>
