@@ -31,13 +31,7 @@ def _regs(tok):
 
 @pytest.fixture(scope="module")
 def asm_text():
-    if not os.path.exists(HIPCC):
-        pytest.skip("hipcc not present")
-    with tempfile.TemporaryDirectory() as td:
-        src = os.path.join(ROOT, "stable_ts_amd", "csrc", "swx_decstep.hip")
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
-                               "--cuda-device-only", src, "-o", os.path.join(td, "dec.s")], cwd=td)
-        return open(os.path.join(td, "dec.s")).read()
+    return _device_asm("swx_decstep.hip")
 
 
 def _kernels(text):
@@ -114,16 +108,26 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
         assert not early, f"{name}: s_waitcnt vmcnt(0) before the last MFMA (lines {early[:3]}): the weight stream is drained"
 
 
-def _kernel_meta(src_name):
-    """(kernel name -> dict of the metadata hipcc emits) for one csrc file, compiled for gfx950 (device only)"""
+_ASM_CACHE = {}
+
+
+def _device_asm(src_name):
+    """gfx950 assembly of one csrc file (device only), compiled once per test session"""
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not present")
-    with tempfile.TemporaryDirectory() as td:
-        src = os.path.join(ROOT, "stable_ts_amd", "csrc", src_name)
-        out = os.path.join(td, "k.s")
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
-                               "--cuda-device-only", src, "-o", out], cwd=td, stderr=subprocess.DEVNULL)
-        text = open(out).read()
+    if src_name not in _ASM_CACHE:
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(ROOT, "stable_ts_amd", "csrc", src_name)
+            out = os.path.join(td, "k.s")
+            subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
+                                   "--cuda-device-only", src, "-o", out], cwd=td, stderr=subprocess.DEVNULL)
+            _ASM_CACHE[src_name] = open(out).read()
+    return _ASM_CACHE[src_name]
+
+
+def _kernel_meta(src_name):
+    """(kernel name -> dict of the metadata hipcc emits) for one csrc file, compiled for gfx950 (device only)"""
+    text = _device_asm(src_name)
     meta = {}
     for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size", text, re.S):
         blk = m.group(0)
@@ -159,13 +163,7 @@ def test_ring_gemm_k_loop_waits_are_the_counted_ones():
     the asm statements (an `s_waitcnt vmcnt` hipcc adds on its own there would drain the ring); (2) their immediates are
     exactly {(NST - 2) L, ..., L, 0}; (3) every asm wait is followed by the barrier; (4) no scratch, and the K loop holds
     2 x 4 x NJ MFMAs per step."""
-    if not os.path.exists(HIPCC):
-        pytest.skip("hipcc not present")
-    with tempfile.TemporaryDirectory() as td:
-        src = os.path.join(ROOT, "stable_ts_amd", "csrc", "swx_gemm.hip")
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
-                               "--cuda-device-only", src, "-o", os.path.join(td, "g.s")], cwd=td, stderr=subprocess.DEVNULL)
-        text = open(os.path.join(td, "g.s")).read()
+    text = _device_asm("swx_gemm.hip")
     seen = 0
     for bnt, nst in ((64, 3), (128, 3)):
         m = re.search(rf"^(_ZN\S*gemm_f16_ringILi{bnt}ELi{nst}E[^\s:]*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
@@ -202,13 +200,7 @@ def test_big_tile_gemm_k_loop():
     """gemm_f16_big (256 x 256 tile, 8 waves, two LDS-DMA stages): per K step one hand-written `vmcnt(0) lgkmcnt(0)` + barrier,
     8 DMA instructions per wave (prologue + refill = 16 in the ISA), 24 fragment reads for 64 MFMAs, no `vmcnt` wait of hipcc's
     own inside the loop, no scratch, <= 256 VGPRs (two waves per SIMD)."""
-    if not os.path.exists(HIPCC):
-        pytest.skip("hipcc not present")
-    with tempfile.TemporaryDirectory() as td:
-        src = os.path.join(ROOT, "stable_ts_amd", "csrc", "swx_gemm.hip")
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-S",
-                               "--cuda-device-only", src, "-o", os.path.join(td, "g.s")], cwd=td, stderr=subprocess.DEVNULL)
-        text = open(os.path.join(td, "g.s")).read()
+    text = _device_asm("swx_gemm.hip")
     m = re.search(r"^(_ZN\S*gemm_f16_bigE[^\s:]*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
     assert m
     lines = m.group(2).split("\n")
