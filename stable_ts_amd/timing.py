@@ -223,6 +223,28 @@ def _find_alignment_variants(model, jobs, xkv, *, medfilt_width, qk_scale, dynam
     return out
 
 
+def _word_means(pa: np.ndarray, bounds: np.ndarray) -> list:
+    """``[np.mean(pa[i:j]) for i, j in zip(bounds[:-1], bounds[1:])]`` (timing.py:292-295) without ~2 000 ``np.mean`` calls per
+    10-minute pass (5 ms of host time with the device idle).  Below 8 elements numpy's sum adds left to right starting from 0.0
+    (its pairwise blocking starts at 8), so the words of k = 1..7 tokens are summed column by column, all words of one k at a
+    time -- the same additions in the same order, bit for bit (randomised check in tests/test_host_cpu.py); longer or empty
+    words (NaN + numpy's warning, as upstream) take ``np.mean`` itself."""
+    cnt = np.diff(bounds)
+    out = [None] * len(cnt)
+    for k in range(1, 8):
+        sel = np.flatnonzero(cnt == k)
+        if sel.size:
+            base = bounds[sel]
+            acc = pa[base]                                   # 0.0 + a0 == a0
+            for t in range(1, k):
+                acc = acc + pa[base + t]
+            for i, v in zip(sel.tolist(), acc / k):
+                out[i] = v
+    for i in np.flatnonzero((cnt < 1) | (cnt >= 8)).tolist():
+        out[i] = np.mean(pa[bounds[i]:bounds[i + 1]])
+    return out
+
+
 def find_alignment_batch(model, jobs: Sequence[AlignmentJob], xkv, *, medfilt_width: int = 7, qk_scale: float = 1.0,
                          dynamic_heads=None, aligner: Union[str, dict] = "legacy", extra_models: Optional[list] = None,
                          mel=None, return_debug: bool = False, started=None) -> List[List[WordTiming]]:
@@ -259,7 +281,7 @@ def find_alignment_batch(model, jobs: Sequence[AlignmentJob], xkv, *, medfilt_wi
         starts, ends = jump_times[bounds[:-1]], jump_times[bounds[1:]]
         p = probs[w]
         pa = np.asarray(p, dtype=np.float64)         # (np.mean of a list slice converts the slice every time: same values)
-        wp = [np.mean(pa[i:j]) for i, j in zip(bounds[:-1], bounds[1:])]                # timing.py:292-295
+        wp = _word_means(pa, bounds)                                                    # timing.py:292-295
         out.append([WordTiming(a, b, c, d, e) for a, b, c, d, e in zip(job.words, job.groups, starts, ends, wp)])
         if return_debug:
             job.debug = dict(path=(text_idx, time_idx), jump_idx=jump_idx, token_probs=p)

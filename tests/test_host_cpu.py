@@ -317,3 +317,26 @@ def test_header_is_plain_c():
         assert r.returncode == 0, r.stderr
     text = open(hdr).read()
     assert "torch" not in text.lower().replace("pytorch", "") and "hipStream_t" not in text.split("*/")[-1]
+
+
+def test_word_means_equal_numpy_mean_per_word_bit_for_bit():
+    """timing._word_means groups the words of a window by token count and sums column by column instead of calling np.mean per
+    word (timing.py:292-295 upstream): same float64 additions in the same order -- equal bits, equal scalar type, NaN (and numpy's
+    warning) for an empty word, np.mean itself from 8 tokens on (numpy's pairwise blocking).  20 000 random windows."""
+    import warnings
+
+    import numpy as np
+    from stable_ts_amd.timing import _word_means
+    rng = np.random.default_rng(0)
+    for trial in range(20000):
+        cnts = rng.choice([0, 1, 1, 1, 2, 2, 3, 4, 5, 6, 7, 8, 9, 15], size=rng.integers(0, 12))
+        bounds = np.pad(np.cumsum(cnts), (1, 0)).astype(np.int64)
+        pa = rng.random(int(bounds[-1]) + rng.integers(0, 4)) * rng.choice([1.0, 1e-8, 1e-3])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = [np.mean(pa[i:j]) for i, j in zip(bounds[:-1], bounds[1:])]
+            got = _word_means(pa, bounds)
+        assert len(ref) == len(got)
+        for a, b in zip(ref, got):
+            assert type(a) is type(b) and (a == b or (np.isnan(a) and np.isnan(b))), (cnts, a, b)
+
