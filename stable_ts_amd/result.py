@@ -595,7 +595,7 @@ class WhisperResult:
         self._nonspeech_sections = list(v or [])
 
     def update_nonspeech_sections(self, silent_starts, silent_ends, overwrite: bool = True):
-        secs = [dict(start=round(s, 3), end=round(e, 3)) for s, e in zip(silent_starts, silent_ends)]
+        secs = [dict(start=round3(s), end=round3(e)) for s, e in zip(silent_starts, silent_ends)]     # (= round(x, 3), _num.py)
         if overwrite:
             self._nonspeech_sections = secs
         else:
