@@ -62,12 +62,20 @@ def _split_tokens(tokens: List[int], tokenizer):
     """timing.py:309-341: group tokens into words by decoding growing prefixes."""
     by_space = getattr(tokenizer, "language_code", tokenizer.language) not in {"zh", "ja", "th", "lo", "my"}
     remaining = tokenizer.decode_with_timestamps(tokens)
+    # most words are one or two tokens: the decoded form of a single pending token is looked up (same string as decode([t]),
+    # memoised per tokenizer) instead of going through the list filter + join of `decode` every time
+    single = tokenizer.__dict__.setdefault("_single_piece", {})
     words, groups, pending = [], [], []
     glue = False
     piece = ""
     for t in tokens:
         pending.append(t)
-        piece = tokenizer.decode(pending)
+        if len(pending) == 1 and type(t) is int:
+            piece = single.get(t)
+            if piece is None:
+                piece = single[t] = tokenizer.decode(pending)
+        else:
+            piece = tokenizer.decode(pending)
         complete = t >= tokenizer.eot
         if not complete:
             complete = remaining[:len(piece)] == piece
