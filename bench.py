@@ -9,7 +9,9 @@ Default mode (``--mode transcribe``): one "step" = one full pass of model.transc
   (20 x 30-s windows, already resident in HBM when the timed region starts), word_timestamps=True, beam_size=5,
   window-parallel batches, fixed decode budget per window (sample_len = min_tokens = 112: random weights have no
   meaningful EOT -- BASELINE.md section 3), temperature 0 without fallback thresholds.  The random weights are shaped
-  (token-embedding gain 3, timestamp rows x0.01) so that every window's transcript keeps ~100 TEXT tokens: the
+  (stable_ts_amd.BENCH_WEIGHTS: token-embedding gain 9, cross-attention score gain 8, LayerNorm jitter 0.1, timestamp rows
+  x0.01 -- the SAME recipe tests/test_gpu_f16_depth.py holds fp16 to the north-star tolerances on, at full depth, 112 steps,
+  and tests/test_gpu_batch_invariance.py chains the 20-window batch to) so that every window's transcript keeps ~111 TEXT tokens: the
   word-timestamp stage (teacher-forced scoring pass, attention weights, DTW) then runs at the length a real transcript
   has (reference: timing.py:202-306 sees ~100-225 tokens per window); ``config.words`` / ``config.text_tokens_per_window``
   report what the timed pass produced.
@@ -113,8 +115,11 @@ def main():
     ap.add_argument("--dtype", default="f16")
     # random-weight transcript shape (see the module docstring); --embed-gain 2 --ts-gain 0.5 is the round-1 workload whose
     # transcripts were almost only timestamp tokens (~1 word per window)
-    ap.add_argument("--embed-gain", type=float, default=3.0)
+    # (defaults = stable_ts_amd.BENCH_WEIGHTS, the recipe the full-depth fp16 parity tests assert on: tests/test_gpu_f16_depth.py)
+    ap.add_argument("--embed-gain", type=float, default=9.0)
     ap.add_argument("--ts-gain", type=float, default=0.01)
+    ap.add_argument("--ln-jitter", type=float, default=0.1)
+    ap.add_argument("--xattn-gain", type=float, default=8.0)
     ap.add_argument("--max-instant-words", type=float, default=1.0)
     ap.add_argument("--align-tokens-per-min", type=int, default=150, help="align mode: text tokens per minute of audio")
     ap.add_argument("--streams", type=int, default=1, help="experimental: host threads / HIP streams per batch (engine clones)")
@@ -169,7 +174,8 @@ def main():
     sd = None
     if rank == 0:
         log("generating random weights")
-        sd = sw.random_state_dict(dims, seed=1234, std=0.02, embed_gain=args.embed_gain, ts_gain=args.ts_gain)
+        sd = sw.random_state_dict(dims, seed=1234, std=0.02, embed_gain=args.embed_gain, ts_gain=args.ts_gain,
+                                  ln_jitter=args.ln_jitter, xattn_gain=args.xattn_gain)
         log("loading weights into the arena")
         model.load_state_dict(sd)
     par.broadcast_arena(model.engine.arena, src=0)        # RCCL broadcast of the packed weights (no-op at N=1)
@@ -249,7 +255,10 @@ def main():
                   f"16 kHz audio per GPU, token_step=100 (reference's sequential window state machine)")
             metric = f"real-time factor (audio-sec/wall-sec) {args.model} align()"
         else:
-            wl = (f"{args.model} (random-init), {args.minutes:g} min synthetic 16 kHz audio per GPU, "
+            recipe = dict(embed_gain=args.embed_gain, ts_gain=args.ts_gain, ln_jitter=args.ln_jitter, xattn_gain=args.xattn_gain)
+            wl = (f"{args.model} (random-init, weight recipe "
+                  + ("BENCH_WEIGHTS = the parity-pinned recipe of tests/test_gpu_f16_depth.py" if recipe == sw.BENCH_WEIGHTS else str(recipe))
+                  + f"), {args.minutes:g} min synthetic 16 kHz audio per GPU, "
                   f"word_timestamps=True, beam_size={args.beam}, {args.tokens} decode steps/window, "
                   + (f"span-parallel, {min(args.spans, args.batch)} spans in lockstep" if args.spans > 0
                      else "sequential windows (reference control flow)" if args.sequential

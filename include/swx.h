@@ -214,6 +214,23 @@ int swx_median_filter(const float *d_x, int64_t rows, int n, int width, float *d
 int swx_loudness_probe(const float *d_pcm, int64_t pcm_stride, const int32_t *d_nk, const int32_t *d_idx, int n_idx, int W,
                        float *d_out, void *stream);
 
+/* ---- f2 audio front-end: FLAC decoding on the HOST (no device work; csrc/swx_flac.hip).  The reference pipes every container
+ * through an `ffmpeg -f s16le` child process (stable_whisper/audio/utils.py:63-125); offline boxes have no ffmpeg and the
+ * reference's only real-speech fixture is test/jfk.flac, so native FLAC streams are decoded here: STREAMINFO + frames with
+ * CONSTANT / VERBATIM / FIXED / LPC subframes, Rice / Rice2 residuals with escapes, wasted bits, left-side / side-right /
+ * mid-side stereo, 4-32 bits per sample, up to 8 channels; CRC-8 and CRC-16 of every frame are verified.
+ * swx_flac_probe: STREAMINFO only.  swx_flac_decode: h_out int32 [capacity_frames][channels] interleaved (sample values at the
+ * stream's bit depth, not scaled), or NULL to count; returns the number of inter-channel sample frames decoded, or a negative
+ * error (-20 not a FLAC stream, -21 corrupt stream / CRC mismatch, -22 unsupported stream, -23 truncated stream).  The MD5 in
+ * `info` is the encoder's signature of the unencoded samples; the caller checks it (stable_ts_amd/audio_io.py::read_flac). */
+typedef struct swx_flac_info {
+    int32_t sample_rate, channels, bits_per_sample, min_block, max_block;
+    int64_t total_samples;        /* per channel; 0 = unknown */
+    uint8_t md5[16];
+} swx_flac_info;
+int swx_flac_probe(const uint8_t *h_data, size_t n_bytes, swx_flac_info *info);
+int64_t swx_flac_decode(const uint8_t *h_data, size_t n_bytes, int32_t *h_out, int64_t capacity_frames, swx_flac_info *info);
+
 /* ---- a8: DTW + backtrace (replaces whisper.timing.dtw at timing.py:195; CPU tie-break)
  * d_x f32 [W][ld_n][ld_m] (row-major; window w uses rows 0..N[w), cols 0..M[w));
  * outputs int32 [W][ld_n+ld_m] text/time indices in forward order and int32 [W] path lengths.

@@ -50,7 +50,7 @@ def record(args, path):
     dims = sw.dims_for(args.model)
     heads = LARGE_V3_HEADS if dims.n_text_layer == 32 and dims.n_text_head == 20 else None
     model = sw.Whisper(dims, device="cuda:0", dtype="f16", alignment_heads=heads, max_windows=args.batch, max_rows=args.batch * args.beam)
-    model.load_state_dict(sw.random_state_dict(dims, seed=1234, std=0.02, embed_gain=3.0, ts_gain=0.01))
+    model.load_state_dict(sw.random_state_dict(dims, seed=1234, std=0.02, **sw.BENCH_WEIGHTS))
     audio = synth_audio(args.minutes * 60.0, seed=0).cuda()
     kw = transcribe_kwargs(args)
     model.transcribe(audio, **kw)                                     # warm-up

@@ -10,7 +10,7 @@ need a GPU, using a model does, and there is no CPU fallback.
 """
 __version__ = "0.1.0"
 
-from .model import Whisper, available_models, dims_for, load_model, random_state_dict  # noqa: F401
+from .model import BENCH_WEIGHTS, Whisper, available_models, dims_for, load_model, random_state_dict  # noqa: F401
 from .engine import Engine, ModelDimensions  # noqa: F401
 from .result import Segment, WhisperResult, WordTiming  # noqa: F401
 from .decoding import DecodingOptions, DecodingResult  # noqa: F401

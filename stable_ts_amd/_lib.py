@@ -20,6 +20,11 @@ class swx_dims(Structure):
                                        "n_vocab", "n_text_ctx", "n_text_state", "n_text_head", "n_text_layer")]
 
 
+class swx_flac_info(Structure):
+    _fields_ = [("sample_rate", c_int32), ("channels", c_int32), ("bits_per_sample", c_int32), ("min_block", c_int32),
+                ("max_block", c_int32), ("total_samples", c_int64), ("md5", ctypes.c_uint8 * 16)]
+
+
 class swx_decode_cfg(Structure):
     _fields_ = [
         ("n_windows", c_int32), ("n_group", c_int32), ("beam", c_int32), ("temperature", c_float),
@@ -75,6 +80,8 @@ SYMBOLS = {
                                   c_void_p, c_size_t, c_void_p]),
     "swx_median_filter": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "swx_loudness_probe": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "swx_flac_probe": (c_int, [c_void_p, c_size_t, POINTER(swx_flac_info)]),
+    "swx_flac_decode": (c_int64, [c_void_p, c_size_t, c_void_p, c_int64, POINTER(swx_flac_info)]),
     "swx_dtw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "swx_dtw": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                         c_void_p]),

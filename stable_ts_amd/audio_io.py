@@ -4,8 +4,10 @@ Mirrors the part of ``stable_whisper/audio`` the window loop sits on:
 
 * ``load_audio`` (audio/utils.py:63-125): any source -> mono f32 waveform at 16 kHz on the s16 grid.  The reference pipes
   everything through an ``ffmpeg -f s16le -ac 1 -ar 16000`` child process; offline boxes have no ffmpeg, so RIFF/WAVE
-  files (PCM 8/16/24/32 bit, IEEE float, WAVE_FORMAT_EXTENSIBLE) are decoded here and other containers go to ffmpeg
-  with the reference's command line when it is on PATH.  A 16 kHz mono s16 WAV yields the same samples either way.
+  files (PCM 8/16/24/32 bit, IEEE float, WAVE_FORMAT_EXTENSIBLE) and native FLAC streams (``read_flac``: the host-side
+  decoder of libswx.so, ``csrc/swx_flac.hip``, with the encoder's MD5 signature checked -- the reference's real-speech
+  fixture is ``test/jfk.flac``) are decoded here and other containers go to ffmpeg with the reference's command line
+  when it is on PATH.  A 16 kHz mono s16 WAV yields the same samples either way.
 * ``resample`` (audio/utils.py:128-129 -> ``torchaudio.functional.resample`` defaults): Hann-windowed sinc
   interpolation, 6 zero crossings, roll-off 0.99, evaluated as one strided convolution.  torchaudio is not installed
   here, so its published algorithm is restated; ``resample_blocks`` is the same filter run block-wise for streaming.
@@ -134,6 +136,88 @@ def write_wav(path: str, audio: Union[np.ndarray, torch.Tensor], sr: int):
         w.writeframes(to_s16(a.T.reshape(-1)).tobytes())
 
 
+# ------------------------------------------------------------------------------------------------------ FLAC decoding
+def _source_bytes(source: Union[str, bytes]) -> bytes:
+    if isinstance(source, (bytes, bytearray)):
+        return bytes(source)
+    with open(source, "rb") as f:
+        return f.read()
+
+
+def is_flac(source: Union[str, bytes]) -> bool:
+    """native FLAC stream (an ID3v2 tag in front of the marker, which some taggers write, is skipped by ``read_flac``)"""
+    try:
+        with _open_binary(source) as f:
+            head = f.read(10)
+    except OSError:
+        return False
+    return head[:4] == b"fLaC" or (head[:3] == b"ID3" and _skip_id3(_source_bytes(source))[:4] == b"fLaC")
+
+
+def _skip_id3(data: bytes) -> bytes:
+    if data[:3] == b"ID3" and len(data) >= 10:
+        size = ((data[6] & 0x7F) << 21) | ((data[7] & 0x7F) << 14) | ((data[8] & 0x7F) << 7) | (data[9] & 0x7F)
+        return data[10 + size + (10 if data[5] & 0x10 else 0):]
+    return data
+
+
+def flac_info(source: Union[str, bytes]) -> dict:
+    """STREAMINFO of a FLAC file / bytes: dict(sr, channels, bits, frames, md5)."""
+    import ctypes
+    from . import _lib
+    data = _skip_id3(_source_bytes(source))
+    info = _lib.swx_flac_info()
+    rc = _lib.load().swx_flac_probe(data, len(data), ctypes.byref(info))
+    if rc < 0:
+        raise RuntimeError(f"Failed to load audio: {_lib.load().swx_strerror(rc).decode()}")
+    return dict(sr=info.sample_rate, channels=info.channels, bits=info.bits_per_sample, frames=int(info.total_samples),
+                md5=bytes(info.md5))
+
+
+def read_flac(source: Union[str, bytes], verify_md5: bool = True) -> Tuple[np.ndarray, int]:
+    """FLAC file or bytes -> (f32 [frames, channels] in [-1, 1), sample rate).  Decoded by ``swx_flac_decode`` (host code of
+    libswx.so: every frame's CRC-8 / CRC-16 is verified there); the MD5 signature of the unencoded samples that the
+    encoder left in STREAMINFO is checked here (all-zero = not set).  ``RuntimeError`` like the reference's loader on a
+    stream that cannot be decoded (audio/utils.py:109-121)."""
+    import ctypes
+    import hashlib
+    from . import _lib
+    lib = _lib.load()
+    data = _skip_id3(_source_bytes(source))
+    info = _lib.swx_flac_info()
+    rc = lib.swx_flac_probe(data, len(data), ctypes.byref(info))
+    if rc < 0:
+        raise RuntimeError(f"Failed to load audio: {lib.swx_strerror(rc).decode()}")
+    frames = int(info.total_samples)
+    if frames == 0:                               # a streamed encoder did not go back to fill the count in: count first
+        frames = int(lib.swx_flac_decode(data, len(data), None, 0, ctypes.byref(info)))
+        if frames < 0:
+            raise RuntimeError(f"Failed to load audio: {lib.swx_strerror(frames).decode()}")
+        total_unknown = True
+    else:
+        total_unknown = False
+    pcm = np.empty((frames, info.channels), dtype=np.int32)
+    n = int(lib.swx_flac_decode(data, len(data), pcm.ctypes.data, frames, ctypes.byref(info)))
+    if n < 0:
+        raise RuntimeError(f"Failed to load audio: {lib.swx_strerror(n).decode()}")
+    if n != frames and not total_unknown:
+        raise RuntimeError(f"Failed to load audio: FLAC stream holds {n} of the {frames} sample frames it declares")
+    pcm = pcm[:n]
+    md5 = bytes(info.md5)
+    if verify_md5 and any(md5):
+        width = (info.bits_per_sample + 7) // 8
+        raw = pcm.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :width].tobytes()
+        if hashlib.md5(raw).digest() != md5:
+            raise RuntimeError("Failed to load audio: FLAC stream does not match its MD5 signature")
+    scale = float(1 << (info.bits_per_sample - 1))
+    return (pcm.astype(np.float64) / scale).astype(np.float32), int(info.sample_rate)
+
+
+def read_pcm_file(source: Union[str, bytes]) -> Tuple[np.ndarray, int]:
+    """the containers decoded without ffmpeg: RIFF/WAVE and native FLAC -> (f32 [frames, channels], sample rate)"""
+    return read_wav(source) if is_wav(source) else read_flac(source)
+
+
 def to_s16(x: np.ndarray) -> np.ndarray:
     return np.clip(np.rint(np.asarray(x, np.float64) * 32768.0), -32768, 32767).astype("<i2")
 
@@ -252,8 +336,8 @@ def load_audio(file: Union[str, bytes], sr: int = SAMPLE_RATE, verbose: Optional
     """File path or file bytes -> f32 waveform at ``sr`` ([n] mono, [2, n] otherwise), values on the s16 grid like the
     reference's ``-f s16le`` pipe (audio/utils.py:63-125)."""
     check_source(file)
-    if is_wav(file):
-        x, in_sr = read_wav(file)
+    if is_wav(file) or is_flac(file):
+        x, in_sr = read_pcm_file(file)
         if mono:
             x = x.mean(axis=1, dtype=np.float64).astype(np.float32) if x.shape[1] > 1 else x[:, 0]
             y = resample(torch.from_numpy(np.ascontiguousarray(x)), in_sr, sr).numpy()
@@ -262,7 +346,7 @@ def load_audio(file: Union[str, bytes], sr: int = SAMPLE_RATE, verbose: Optional
             y = resample(torch.from_numpy(np.ascontiguousarray(x.T)), in_sr, sr).numpy()
         return to_s16(y).astype(np.float32) / 32768.0
     if shutil.which("ffmpeg") is None:
-        raise RuntimeError("Failed to load audio: only RIFF/WAVE sources can be decoded without ffmpeg on PATH")
+        raise RuntimeError("Failed to load audio: only RIFF/WAVE and FLAC sources can be decoded without ffmpeg on PATH")
     is_bytes = isinstance(file, (bytes, bytearray))
     try:
         out = subprocess.run(_ffmpeg_cmd("pipe:" if is_bytes else file, sr, mono), input=file if is_bytes else None,
@@ -281,6 +365,9 @@ def get_metadata(audiofile: Union[str, bytes, np.ndarray, torch.Tensor]) -> dict
         with _open_binary(audiofile) as f:
             info = _parse_wav(f)
         return dict(sr=info.sr, duration=info.n_frames / info.sr if info.sr else None)
+    if is_flac(audiofile):
+        fi = flac_info(audiofile)
+        return dict(sr=fi["sr"], duration=(fi["frames"] / fi["sr"]) if fi["frames"] else None)
     if shutil.which("ffmpeg") is None:
         return dict(sr=None, duration=None)
     import re
@@ -392,6 +479,19 @@ def _wav_pcm_stream(source: Union[str, bytes], sr: int, frames_per_read: int = 1
     return PcmStream((to_s16(b).tobytes() for b in resample_blocks(mono_blocks(), info.sr, sr)), f.close)
 
 
+def _flac_pcm_stream(source: Union[str, bytes], sr: int, frames_per_read: int = 1 << 18) -> PcmStream:
+    """a FLAC source as a pulled s16le stream: the file is decoded whole (a frame cannot be located without parsing the ones
+    before it, and decoding runs at several thousand times real time), then handed out block-wise through the streaming resampler"""
+    x, in_sr = read_flac(source)
+    mono = x.mean(axis=1, dtype=np.float64).astype(np.float32) if x.shape[1] > 1 else np.ascontiguousarray(x[:, 0])
+
+    def mono_blocks():
+        for a in range(0, len(mono), frames_per_read):
+            yield mono[a: a + frames_per_read]
+
+    return PcmStream((to_s16(b).tobytes() for b in resample_blocks(mono_blocks(), in_sr, sr)))
+
+
 def _ffmpeg_pcm_stream(source: str, sr: int) -> PcmStream:
     try:
         p = subprocess.Popen(_ffmpeg_cmd(source, sr), stdout=subprocess.PIPE)
@@ -416,10 +516,12 @@ def open_pcm_stream(source: Union[str, bytes], sr: int) -> PcmStream:
     check_source(source)
     if is_wav(source):
         return _wav_pcm_stream(source, sr)
+    if is_flac(source):
+        return _flac_pcm_stream(source, sr)
     if isinstance(source, str) and shutil.which("ffmpeg") is not None:
         return _ffmpeg_pcm_stream(source, sr)
     raise RuntimeError(f'FFmpeg failed to read "{source}".' if isinstance(source, str) else "Failed to load audio: "
-                       "only RIFF/WAVE sources can be decoded without ffmpeg on PATH")
+                       "only RIFF/WAVE and FLAC sources can be decoded without ffmpeg on PATH")
 
 
 # ------------------------------------------------------------------------------------------------------- AudioLoader

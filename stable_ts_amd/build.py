@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libswx.so")
 SOURCES = ["swx_runtime.hip", "swx_gemm.hip", "swx_norm.hip", "swx_attn.hip", "swx_decode.hip", "swx_align.hip",
-           "swx_mel.hip", "swx_dtw.hip", "swx_decstep.hip", "swx_loudness.hip", "swx_headsel.hip"]
+           "swx_mel.hip", "swx_dtw.hip", "swx_decstep.hip", "swx_loudness.hip", "swx_headsel.hip", "swx_flac.hip"]
 
 
 def _newest(paths):

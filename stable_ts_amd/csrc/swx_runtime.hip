@@ -731,6 +731,10 @@ const char *swx_strerror(int code)
         case -9: return "weights / workspace not bound";
         case -10: return "unknown tensor name";
         case -11: return "tensor size mismatch";
+        case -20: return "not a FLAC stream";
+        case -21: return "corrupt FLAC stream (bad header, reserved code or CRC mismatch)";
+        case -22: return "unsupported FLAC stream";
+        case -23: return "truncated FLAC stream";
         default: return code <= -100 ? "HIP runtime error (code = -100 - hipError_t)" : "unknown error";
     }
 }
