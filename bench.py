@@ -109,7 +109,9 @@ def main():
     ap.add_argument("--mode", default="transcribe", choices=["transcribe", "align", "sharded"])
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--minutes", type=float, default=None, help="audio per GPU (default 10 for transcribe, 30 for align)")
-    ap.add_argument("--batch", type=int, default=20, help="windows per GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU batch (default 20; 120 when --gpus > 1, see --minutes)")
+    ap.add_argument("--host-audio", action="store_true", help="hand transcribe() the recording as a HOST tensor, as the reference's "
+                    "callers do (the default keeps it resident in HBM, as the bench contract asks): the PCIe-inclusive rate")
     ap.add_argument("--beam", type=int, default=5)
     ap.add_argument("--tokens", type=int, default=112, help="fixed decode budget per window")
     ap.add_argument("--dtype", default="f16")
@@ -127,6 +129,10 @@ def main():
                     "many spans in lockstep, spans.py) instead of the fixed-stride window batches")
     ap.add_argument("--sequential", action="store_true", help="the default model.transcribe(audio): the reference's sequential "
                     "window loop (seek from the last timestamp, prompt carried over), one window per device pass")
+    ap.add_argument("--raw-seek", action="store_true", help="sequential / span modes: leave every timestamp token selectable.  By default "
+                    "these modes suppress the timestamp tokens of 0.02 .. 27.98 s through the reference's own `suppress_tokens` option, "
+                    "so that a window's last timestamp -- which the reference's seek advances by (original_whisper.py:629-633) -- lands "
+                    "at 28-30 s as it does on speech (~21 windows per 10 min); with random weights it is uniform over 0-30 s (63 windows)")
     ap.add_argument("--no-regroup", action="store_true", help="leave the default regrouping out of the timed pass (round-2 behaviour)")
     ap.add_argument("--debug-flags", type=int, default=0, help="swx_debug_flags() A/B switches (csrc/swx_kernels.h), e.g. 16384 = "
                     "decode loop without the captured step graph")
@@ -139,8 +145,14 @@ def main():
                     "boundary: wall ms per stage (host share of the pass) under \"phase_ms\"; not part of `value`")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="hard cap (s) on the CPU-baseline leg")
     args = ap.parse_args()
+    # N = 1: BASELINE.json configs[2] (10 min, 20 windows in one batch).  N > 1: one GPU's share of configs[4] (8 h over 8 GPUs =
+    # 60 min per GPU) at the batch size that amortises the decode-step launches (120 windows: 1 903x per GPU in round 3 against
+    # 1 376x at 20) -- weak scaling, every rank transcribes its own 60 minutes; compare with `bench.py --minutes 60 --batch 120` at N = 1.
+    multi = args.gpus > 1 and args.mode == "transcribe"
     if args.minutes is None:
-        args.minutes = 30.0 if args.mode == "align" else 10.0
+        args.minutes = 30.0 if args.mode == "align" else (60.0 if multi else 10.0)
+    if args.batch is None:
+        args.batch = 120 if multi else 20
 
     import stable_ts_amd as sw
     from stable_ts_amd import parallel as par
@@ -192,7 +204,9 @@ def main():
         reps = int(np.ceil(seconds * world / (base.shape[0] / 16000.0)))
         audio = base.repeat(reps)[: int(seconds * world * 16000)].to(dev)
     else:
-        audio = synth_audio(seconds, seed=rank).to(dev)
+        audio = synth_audio(seconds, seed=rank)
+        if not args.host_audio:
+            audio = audio.to(dev)
     if args.mode in ("transcribe", "sharded"):
         # regroup (the reference's default 'da' post-processing, result.py) is inside the timed pass since round 3
         kw = dict(language="en", temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None,
@@ -204,6 +218,10 @@ def main():
         if args.spans > 0 or args.sequential:
             kw.pop("batch_size")
             kw.pop("streams", None)
+            if not args.raw_seek:
+                from stable_ts_amd.tokenizer import get_tokenizer
+                tb = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language="en", task="transcribe").timestamp_begin
+                kw["suppress_tokens"] = [-1] + list(range(tb + 1, tb + 1400))
         text_tokens = None
     else:
         g = torch.Generator().manual_seed(7 + rank)
@@ -260,10 +278,13 @@ def main():
                   + ("BENCH_WEIGHTS = the parity-pinned recipe of tests/test_gpu_f16_depth.py" if recipe == sw.BENCH_WEIGHTS else str(recipe))
                   + f"), {args.minutes:g} min synthetic 16 kHz audio per GPU, "
                   f"word_timestamps=True, beam_size={args.beam}, {args.tokens} decode steps/window, "
-                  + (f"span-parallel, {min(args.spans, args.batch)} spans in lockstep" if args.spans > 0
-                     else "sequential windows (reference control flow)" if args.sequential
+                  + (f"span-parallel, {min(args.spans, args.batch)} spans in lockstep" + ("" if args.raw_seek else ", seek advance 28-30 s (suppress_tokens)")
+                     if args.spans > 0
+                     else "sequential windows (reference control flow)" + ("" if args.raw_seek else ", seek advance 28-30 s per window (timestamp tokens of 0.02-27.98 s suppressed through suppress_tokens)")
+                     if args.sequential
                      else f"window-parallel batch {args.batch}" + (f", {args.streams} streams" if args.streams > 1 else ""))
                   + (", default regrouping inside the timed pass" if kw.get("regroup") else ", regroup=False")
+                  + (", recording handed over as a HOST tensor (PCIe-inclusive)" if args.host_audio else "")
                   + (f"; ONE recording of {args.minutes * world:g} min scattered by 30-s window over {world} rank(s) "
                      f"(parallel.transcribe_sharded), segments gathered + regrouped on rank 0" if args.mode == "sharded" else ""))
             metric = f"real-time factor (audio-sec/wall-sec) {args.model} word_timestamps=True"

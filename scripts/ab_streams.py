@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--embed-gain", type=float, default=3.0)
     ap.add_argument("--ts-gain", type=float, default=0.01)
     ap.add_argument("--mode", default="streams", help="streams (transcribe(streams=n)) | pipeline (transcribe(pipeline=n))")
+    ap.add_argument("--flags", default="", help="A/B of swx_debug_flags values instead of lane counts, e.g. 0,262144")
+    ap.add_argument("--phase", action="store_true", help="print transcribe.PHASE_TIMES of one extra pass per configuration")
     ap.add_argument("--out", default="")
     args = ap.parse_args()
     import stable_ts_amd as sw
@@ -40,12 +42,17 @@ def main():
                 no_speech_threshold=None, beam_size=5, sample_len=112, min_tokens=112, word_timestamps=True, regroup=True,
                 batch_size=args.batch, max_instant_words=1.0)
     lanes = [int(x) for x in args.lanes.split(",")]
+    flags = [int(x) for x in args.flags.split(",")] if args.flags else None
+    if flags is not None:
+        lanes = flags
     ref_words = None
     times = {n: [] for n in lanes}
     for rnd in range(args.rounds + 1):
         for n in lanes:
             kw = dict(base)
-            if n > 1:
+            if flags is not None:
+                model.engine.lib.swx_debug_flags(n)
+            elif n > 1:
                 kw["streams" if args.mode == "streams" else "pipeline"] = n
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -59,6 +66,16 @@ def main():
             if rnd > 0:
                 times[n].append(dt)
             print(f"round {rnd} lanes {n}: {1000 * dt:8.1f} ms  words {len(words)} identical_to_first {same}", flush=True)
+    if args.phase:
+        from stable_ts_amd import transcribe as _tr
+        for n in lanes:
+            if flags is not None:
+                model.engine.lib.swx_debug_flags(n)
+            _tr.PHASE_TIMES = {}
+            model.transcribe(audio, **base)
+            torch.cuda.synchronize()
+            print("phase ms", n, {k: round(1000 * v, 2) for k, v in _tr.PHASE_TIMES.items()}, flush=True)
+            _tr.PHASE_TIMES = None
     summary = {str(n): dict(median_ms=round(1000 * float(np.median(v)), 1), min_ms=round(1000 * min(v), 1),
                             x_real_time=round(args.minutes * 60.0 / float(np.median(v)), 1)) for n, v in times.items()}
     print(json.dumps(dict(mode=args.mode, batch=args.batch, minutes=args.minutes, lanes=summary)))

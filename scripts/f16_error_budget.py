@@ -61,10 +61,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tokens", type=int, default=24)
     ap.add_argument("--out", default="")
+    ap.add_argument("--words", action="store_true", help="also: the word-timestamp stage (timing.py:202-306) on the decoded text "
+                    "under each variant -- DTW row starts / word times against the f32 ones")
+    ap.add_argument("--only", default="", help="comma-separated substrings: run only the variants whose name contains one")
+    ap.add_argument("--recipe", default="", help="overrides of BENCH_WEIGHTS, e.g. xattn_gain=16,ts_gain=0.1")
+    ap.add_argument("--beam", type=int, default=0)
+    ap.add_argument("--decode-check", action="store_true", help="also DECODE under the emulated fp16 mode and compare the tokens")
     args = ap.parse_args()
     torch.set_num_threads(8)
     import stable_ts_amd.model as pm
-    recipe = getattr(pm, "BENCH_WEIGHTS", dict(embed_gain=9.0, ts_gain=0.01, ln_jitter=0.1, xattn_gain=8.0))
+    recipe = dict(getattr(pm, "BENCH_WEIGHTS", dict(embed_gain=9.0, ts_gain=0.01, ln_jitter=0.1, xattn_gain=8.0)))
+    for kv in filter(None, args.recipe.split(",")):
+        k_, v_ = kv.split("=")
+        recipe[k_] = float(v_)
+    print("recipe", recipe, flush=True)
     dims = om.dims_for("large-v3")
     sd = om.random_state_dict(dims, 1234, 0.02, **recipe)
     _patch()
@@ -79,7 +89,8 @@ def main():
     with torch.no_grad():
         xa = m.encoder(mel[None])
     print(f"encoder f32: {time.time() - t0:.1f}s", flush=True)
-    opts = DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=args.tokens)
+    opts = DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=args.tokens,
+                           **(dict(beam_size=args.beam) if args.beam > 1 else {}))
     ref, _ = ost.decode_stable(m, mel, opts, audio_features=xa, min_tokens=args.tokens)
     task = ost.DecodingTaskStable(m, opts)
     seq = list(task.initial_tokens) + list(ref.tokens)
@@ -118,6 +129,40 @@ def main():
     ]
     out = dict(tokens=len(ref.tokens), token_logprob_range=[float(base_lp.min()), float(base_lp.max())], variants={})
     xa_cache = {}
+    from oracle.whisper.tokenizer import get_tokenizer
+    tok = get_tokenizer(True, num_languages=m.num_languages, language="en", task="transcribe")
+    mask = torch.zeros(dims.n_text_layer, dims.n_text_head, dtype=torch.bool)
+    for l, h in ((7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)):
+        mask[l, h] = True
+    m.set_alignment_heads_mask(mask)
+    text = [t_ for t_ in ref.tokens if t_ < tok.eot]
+
+    def words_of(xa_):
+        w, cache = ost.find_alignment(m, tok, list(text), mel, 480000, audio_features=xa_, return_cache=True)
+        i, j = cache["dtw_path"]
+        first = {int(r): int(c) for r, c in reversed(list(zip(i.tolist(), j.tolist())))}
+        return w, first
+    base_words = words_of(xa) if args.words else None
+    if args.decode_check:
+        FLAGS["enc"], FLAGS["dec"] = {"res", "act"}, {"res", "act", "ln_out"}
+        set_weights(1, 1)
+        with torch.no_grad():
+            xa16 = m.encoder(mel[None])
+        got, _ = ost.decode_stable(m, mel, opts, audio_features=xa16, min_tokens=args.tokens)
+        n_same = 0
+        for a_, b_ in zip(got.tokens, ref.tokens):
+            if a_ != b_:
+                break
+            n_same += 1
+        out["decode_check"] = dict(beam=args.beam, tokens=len(ref.tokens), identical_prefix=n_same,
+                                   first_tokens=(got.tokens[:3], ref.tokens[:3]),
+                                   d_avg_logprob=abs(got.avg_logprob - ref.avg_logprob))
+        print("decode under emulated fp16:", json.dumps(out["decode_check"]), flush=True)
+        FLAGS["enc"], FLAGS["dec"] = set(), set()
+        set_weights(0, 0)
+    if args.only:
+        variants = [(n_, v_) for n_, v_ in variants if any(o in n_ for o in args.only.split(","))]
+    print("text tokens", len(text), "logit gap min", float(np.sort(base_lg[n0 - 1: len(seq) - 1], -1)[:, -1].min()), flush=True)
     for name, v in variants:
         FLAGS["enc"], FLAGS["dec"] = set(v.get("enc", ())), set(v.get("dec", ()))
         w = v.get("w", (0, 0))
@@ -136,6 +181,13 @@ def main():
                    max_dlogit=float(np.abs(lg - base_lg)[n0 - 1: len(seq) - 1].max()),
                    argmax_same=bool((lg[n0 - 1: len(seq) - 1].argmax(-1) == base_lg[n0 - 1: len(seq) - 1].argmax(-1)).all()),
                    min_top1_top2_gap=float((top2[:, 1] - top2[:, 0]).min()))
+        if args.words:
+            w, first = words_of(xa_cache[key])
+            bw, bfirst = base_words
+            dt = np.asarray([(abs(a.start - b.start), abs(a.end - b.end)) for a, b in zip(w, bw)])
+            rec.update(words=len(bw), words_within_20ms=float(((dt[:, 0] <= 0.0201) & (dt[:, 1] <= 0.0201)).mean()),
+                       max_word_dt=float(dt.max()), dtw_row_start_max_frame_diff=int(max(abs(first[r] - bfirst[r]) for r in bfirst)),
+                       dtw_rows_moved=int(sum(first[r] != bfirst[r] for r in bfirst)))
         out["variants"][name] = rec
         print(name, json.dumps(rec), flush=True)
     if args.out:

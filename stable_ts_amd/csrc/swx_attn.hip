@@ -235,26 +235,34 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const f16 *__restrict_
 // PACKED: K and V^T come from the fragment-ordered copy (swx_xkv_pack): every MFMA operand fragment of a 32-key block is one
 // contiguous 1 KB piece, so a wave instruction reads 8 full 128-byte lines instead of 16 separate 64-byte row pieces (the
 // per-CU address path, not HBM, bounds the row-layout variant at ~4.2 TB/s: same finding as for the decode GEMM weights).
-template <bool PACKED>
+// QG: groups of 16 query rows one workgroup carries through a single pass over the head's K / V^T (1 for a decode step; up to 4
+// for a multi-token pass over many windows, where one workgroup per group would re-stream the head's 384 KB once per group --
+// 8 times for a ~113-row scoring pass: measured +14 ms per 20-window pass).  Every group's arithmetic is the one-group
+// kernel's (same key order per wave, same merge), so the result does not depend on QG.
+template <bool PACKED, int QG>
 __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
 {
     __shared__ float sm_m[4][16], sm_l[4][16];
     __shared__ float sm_o[4][DH][17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
-    // blockIdx.z = group of 16 query rows of this (window, head): a teacher-forced pass of ~100 rows over ONE window has 20
+    // blockIdx.z = QG groups of 16 query rows of this (window, head): a teacher-forced pass of ~100 rows over ONE window has 20
     // flash workgroups to offer 256 CUs; as groups of 16 rows on this kernel it has 100-160, each streaming the head's K / V^T
     // (384 KB, L2-resident after the first group) with its 4 waves splitting the keys
-    const int q_base = blockIdx.z * 16;
+    const int q_base0 = blockIdx.z * 16 * QG;
     const int qn = lane & 15, g = lane >> 4;
     const f16 *Q = (const f16 *)a.q;
     const f16 *Kp = (const f16 *)a.k + (size_t)b * a.k_bs + h * DH;
     const f16 *Vp = (const f16 *)a.v + (size_t)b * a.v_bs + (size_t)h * DH * a.vt_kp;
 
-    f32x4 o[4];
+    f32x4 o[QG][4];
+    float m_run[QG], l_run[QG];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run = -__builtin_inff(), l_run = 0.f;
+    for (int u = 0; u < QG; ++u) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[u][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        m_run[u] = -__builtin_inff(); l_run[u] = 0.f;
+    }
     const int nblk = (a.nk + 31) >> 5;
     // A-row i of S^T tile t  <->  key k0 + (i>>2)*8 + (i&3) + 4t, so that lane (q, g) owns keys k0 + g*8 + 0..7
     const int krow = (qn >> 2) * 8 + (qn & 3);
@@ -286,55 +294,59 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     f16x8 kA[4], vA[4];
     load_blk(wave, kA, vA);
 
-    f16x8 qf[2];
-    {
-        const bool qok = q_base + qn < a.nq;
-        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qok ? q_base + qn : 0)) * a.ldq + h * DH + g * 8;
-        qf[0] = qok ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
-        qf[1] = qok ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
+    f16x8 qf[QG][2];
+#pragma unroll
+    for (int u = 0; u < QG; ++u) {
+        const bool qok = q_base0 + u * 16 + qn < a.nq;
+        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qok ? q_base0 + u * 16 + qn : 0)) * a.ldq + h * DH + g * 8;
+        qf[u][0] = qok ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
+        qf[u][1] = qok ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
     }
 
     auto compute_blk = [&](int cb, const f16x8 (&kf)[4], const f16x8 (&vf)[4]) {
         const int k0 = cb << 5;
-        f32x4 s[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * t], qf[0], s[t], 0, 0, 0);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * t + 1], qf[1], s[t], 0, 0, 0);
-        }
-        float tmax = -__builtin_inff();
+        for (int u = 0; u < QG; ++u) {
+            f32x4 s[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + g * 8 + 4 * t + r;
-                const float v = (key < a.nk) ? s[t][r] * 0.125f : -__builtin_inff();
-                s[t][r] = v;
-                tmax = fmaxf(tmax, v);
+            for (int t = 0; t < 2; ++t) {
+                s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * t], qf[u][0], s[t], 0, 0, 0);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[2 * t + 1], qf[u][1], s[t], 0, 0, 0);
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __expf(m_run - m_new);
-        float psum = 0.f;
-        f16x8 pb;
+            float tmax = -__builtin_inff();
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[t][r] - m_new);
-                psum += p;
-                pb[4 * t + r] = (f16)p;
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + g * 8 + 4 * t + r;
+                    const float v = (key < a.nk) ? s[t][r] * 0.125f : -__builtin_inff();
+                    s[t][r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run[u], tmax);
+            const float alpha = __expf(m_run[u] - m_new);
+            float psum = 0.f;
+            f16x8 pb;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(s[t][r] - m_new);
+                    psum += p;
+                    pb[4 * t + r] = (f16)p;
+                }
+            psum += __shfl_xor(psum, 16, 64);
+            psum += __shfl_xor(psum, 32, 64);
+            l_run[u] = l_run[u] * alpha + psum;
+            m_run[u] = m_new;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                o[u][t][0] *= alpha; o[u][t][1] *= alpha; o[u][t][2] *= alpha; o[u][t][3] *= alpha;
+                o[u][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t], pb, o[u][t], 0, 0, 0);
             }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            o[t][0] *= alpha; o[t][1] *= alpha; o[t][2] *= alpha; o[t][3] *= alpha;
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[t], pb, o[t], 0, 0, 0);
         }
     };
     {
@@ -347,25 +359,31 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         }
     }
 
-    // merge the four partial softmaxes: o[t][r] is O^T[d = t*16 + g*4 + r][q = qn]
-    if (g == 0) { sm_m[wave][qn] = m_run; sm_l[wave][qn] = l_run; }
+    // merge the four partial softmaxes, one group at a time: o[u][t][r] is O^T[d = t*16 + g*4 + r][q = qn]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int u = 0; u < QG; ++u) {
+        const int q_base = q_base0 + u * 16;
+        if (q_base >= a.nq) break;
+        if (u > 0) __syncthreads();
+        if (g == 0) { sm_m[wave][qn] = m_run[u]; sm_l[wave][qn] = l_run[u]; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sm_o[wave][t * 16 + g * 4 + r][qn] = o[t][r];
-    __syncthreads();
-    const int nq_here = a.nq - q_base < 16 ? a.nq - q_base : 16;
-    for (int i = tid; i < nq_here * DH; i += 256) {
-        const int q = i >> 6, d = i & 63;
-        const float M = fmaxf(fmaxf(sm_m[0][q], sm_m[1][q]), fmaxf(sm_m[2][q], sm_m[3][q]));
-        float L = 0.f, O = 0.f;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float f = __expf(sm_m[w][q] - M);
-            L += sm_l[w][q] * f;
-            O += sm_o[w][d][q] * f;
+            for (int r = 0; r < 4; ++r) sm_o[wave][t * 16 + g * 4 + r][qn] = o[u][t][r];
+        __syncthreads();
+        const int nq_here = a.nq - q_base < 16 ? a.nq - q_base : 16;
+        for (int i = tid; i < nq_here * DH; i += 256) {
+            const int q = i >> 6, d = i & 63;
+            const float M = fmaxf(fmaxf(sm_m[0][q], sm_m[1][q]), fmaxf(sm_m[2][q], sm_m[3][q]));
+            float L = 0.f, O = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = __expf(sm_m[w][q] - M);
+                L += sm_l[w][q] * f;
+                O += sm_o[w][d][q] * f;
+            }
+            ((f16 *)a.o)[((size_t)b * a.q_rows_per_batch + q_base + q) * a.ldo + h * DH + d] = (f16)(O / L);
         }
-        ((f16 *)a.o)[((size_t)b * a.q_rows_per_batch + q_base + q) * a.ldo + h * DH + d] = (f16)(O / L);
     }
 }
 
@@ -744,17 +762,28 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     // the decode kernel also takes a SMALL multi-row pass (align(): one window of ~100 rows) as groups of 16 rows, when the
     // fragment-ordered K / V^T copy exists and the flash grid would be tiny
     const int ngrp = cdiv(a.nq, 16);
-    const bool small_pass = a.nq > 16 && a.nq <= 160 && a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV) &&
-                            (int64_t)a.B * a.H * ngrp <= 1024 && force_kernel == 0;
+    const bool by_batch = swx_flags() & SWX_FLAG_SCORE_TILED;       // round 3's size-dependent choice (A/B only)
+    const bool small_pass = a.nq > 16 && a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV) && force_kernel == 0 &&
+                            (!by_batch || (a.nq <= 160 && (int64_t)a.B * a.H * ngrp <= 1024));
     const bool dec = (dtype == SWX_F16) && a.vt_kp > 0 && (a.nq <= 16 || small_pass) && a.nk >= 128 && (force_kernel == 3 || force_kernel == 0);
     if (force_kernel == 3 && !dec) return -5;
     if (dec) {
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
-        dim3 gd(a.H, a.B, a.nq <= 16 ? 1 : ngrp);
-        if (a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV))
-            hipLaunchKernelGGL(attn_decode_cross_f16<true>, gd, dim3(256), 0, s, a);
-        else
-            hipLaunchKernelGGL(attn_decode_cross_f16<false>, gd, dim3(256), 0, s, a);      // row-layout K / V^T: the reference
+        // groups of 16 query rows per workgroup: one while the launch is small (a decode step; align(): one window = 100-160
+        // workgroups), up to four when many windows share the pass (the head's K / V^T is then streamed once per 64 rows)
+        const int64_t wgs1 = (int64_t)a.B * a.H * ngrp;
+        const int qg = (a.nq <= 16 || wgs1 <= 512) ? 1 : (ngrp >= 4 && wgs1 > 2048) ? 4 : 2;
+        dim3 gd(a.H, a.B, cdiv(ngrp, qg));
+        const bool packed = a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV);     // else row-layout K / V^T: the reference
+        if (packed) {
+            if (qg == 1) hipLaunchKernelGGL((attn_decode_cross_f16<true, 1>), gd, dim3(256), 0, s, a);
+            else if (qg == 2) hipLaunchKernelGGL((attn_decode_cross_f16<true, 2>), gd, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_decode_cross_f16<true, 4>), gd, dim3(256), 0, s, a);
+        } else {
+            if (qg == 1) hipLaunchKernelGGL((attn_decode_cross_f16<false, 1>), gd, dim3(256), 0, s, a);
+            else if (qg == 2) hipLaunchKernelGGL((attn_decode_cross_f16<false, 2>), gd, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((attn_decode_cross_f16<false, 4>), gd, dim3(256), 0, s, a);
+        }
     } else if (flash) {
         if (dtype != SWX_F16) return -5;
         SwxProfScope prof(PC_ATTN_FLASH, 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);

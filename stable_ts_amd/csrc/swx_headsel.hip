@@ -87,6 +87,23 @@ __device__ __forceinline__ void median_row(const float *src, float *dst, int F)
         dst[f] = v[PADW];
     }
 }
+// any odd width (the reference's median_filter takes any; the sorting networks above cover the usual 3..11): the median is the
+// value with at most width/2 smaller and more than width/2 not-larger neighbours -- a rank count, O(width^2) per output
+__device__ __forceinline__ void median_row_generic(const float *src, float *dst, int F, int width)
+{
+    const int P = width / 2;
+    for (int f = threadIdx.x; f < F; f += blockDim.x) {
+        if (F <= P) { dst[f] = src[f]; continue; }
+        float med = src[f];
+        for (int a = 0; a < width; ++a) {
+            const float va = src[reflect(f + a - P, F)];
+            int lt = 0, le = 0;
+            for (int b = 0; b < width; ++b) { const float vb = src[reflect(f + b - P, F)]; lt += vb < va; le += vb <= va; }
+            if (lt <= P && P < le) { med = va; break; }
+        }
+        dst[f] = med;
+    }
+}
 __device__ __forceinline__ void median_row_any(const float *src, float *dst, int F, int width)
 {
     switch (width) {
@@ -95,7 +112,8 @@ __device__ __forceinline__ void median_row_any(const float *src, float *dst, int
         case 5: median_row<5>(src, dst, F); break;
         case 7: median_row<7>(src, dst, F); break;
         case 9: median_row<9>(src, dst, F); break;
-        default: median_row<11>(src, dst, F); break;
+        case 11: median_row<11>(src, dst, F); break;
+        default: median_row_generic(src, dst, F, width); break;
     }
 }
 
@@ -199,7 +217,20 @@ __global__ __launch_bounds__(256) void headsel_pick_kernel(const double *__restr
         best = shv[0]; bi = shi[0];
 #pragma unroll
         for (int w = 1; w < 4; ++w) if (shv[w] < best || (shv[w] == best && shi[w] < bi)) { best = shv[w]; bi = shi[w]; }
-        if (tid == 0) { sel[(size_t)i * count + k] = bi; if (bi < LH) sc[bi] = __builtin_inf(); }
+        // no finite score left (NaN scores: an f16 q.K overflow gives a NaN softmax and `v < best` is never true): fall back to the
+        // lowest head not picked yet so that the gather kernel never sees an index outside [0, LH) (newal_pick_kernel clamps too)
+        if (tid == 0) {
+            if (bi >= LH) {
+                bi = 0;
+                for (int h = 0; h < LH; ++h) {
+                    bool used = false;
+                    for (int j = 0; j < k; ++j) used |= sel[(size_t)i * count + j] == h;
+                    if (!used) { bi = h; break; }
+                }
+            }
+            sel[(size_t)i * count + k] = bi;
+            sc[bi] = __builtin_inf();
+        }
         __syncthreads();
     }
 }
@@ -382,7 +413,7 @@ int swx_headsel_new_launch(int dtype, const void *qcap, int max_n, int d, int n,
     if (n <= 0 || n_out <= 0) return 0;
     const int LH = L * H;
     if (F <= 0 || F > HS_MAXF || topk <= 0 || topk > LH || LH > 8192 || row0 < 0 || row0 + n_out > n) return -2;
-    if (medfilt_width < 1 || medfilt_width > 11 || !(medfilt_width & 1)) return -3;
+    if (medfilt_width < 1 || medfilt_width > 2 * HS_MAXF || !(medfilt_width & 1)) return -3;
     dim3 g1(H, L);
     if (dtype == SWX_F16) {
         hipLaunchKernelGGL(newal_head_kernel<f16>, g1, dim3(256), 0, s, (const f16 *)qcap, max_n, d, n, (const f16 *)xkv, layer_stride, H,

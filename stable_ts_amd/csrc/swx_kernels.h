@@ -41,6 +41,8 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_NO_GRAPH 16384       // decode loop: launch every step eagerly instead of replaying the captured two-step graph
 #define SWX_FLAG_NO_PREFETCH 32768    // decode step: no cache prefetch of the next projection's weights (A/B; no functional effect)
 #define SWX_FLAG_NO_RING 65536        // tiled GEMM: never the ring kernel for launches with few tiles (A/B; results are bit-identical)
+#define SWX_FLAG_SCORE_TILED 262144   // multi-token decoder passes above 160 rows on the tiled GEMMs + flash attention (round 3's
+                                      // dispatch: faster at >= 2 windows, but a window's rounding then depends on its batch) -- A/B only
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

@@ -83,7 +83,8 @@ struct swx_model {
     std::vector<StepGraph> graphs;
     uint64_t graph_clock = 0;
     hipStream_t cap_stream = nullptr;   // capture happens here (the caller's stream may be the null stream, which cannot capture)
-    bool graphs_off = false;            // set when capture / replay failed once on this handle: eager from then on
+    bool graphs_off = false;            // set when capture / replay failed in three swx_decode calls of this handle: eager from then on
+    int graph_failures = 0;
     int64_t n_captures = 0, n_replays = 0, n_eager_units = 0;      // swx_graph_stats
     void drop_graphs() {
         for (auto &g : graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
@@ -272,9 +273,11 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
     L.sd = take((size_t)Bmax * (n_align > 0 ? n_align : 1) * D.n_audio_ctx * 4);
     L.suppress = take((size_t)MAX_SUPPRESS * 4);
     {
-        size_t mx = swx_dec_slab_floats(Mmax > 128 ? Mmax : 128, dt, 4 * dt);     // the K = 4d projection of the decode step
-        const size_t f4 = swx_dec_slab_floats(160, dt, 4 * dt);      // the small multi-token pass on the dec GEMMs
-        if (f4 > mx) mx = f4;
+        // f32 slabs of the one K-split projection (K = 4d): the decode step's rows, and every row of a multi-token pass
+        // (Bmax windows x n_text_ctx tokens: 9.2 MB per window for large-v3)
+        int64_t srows = Mmax > 160 ? Mmax : 160;
+        if ((int64_t)Bmax * D.n_text_ctx > srows) srows = (int64_t)Bmax * D.n_text_ctx;
+        const size_t mx = swx_dec_slab_floats((int)srows, dt, 4 * dt);
         L.slabs = take(mx * 4 + 256);
         L.slab_bytes = mx * 4;
     }
@@ -523,8 +526,14 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
 int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
 {
     const bool dec_ok = m->dtype == SWX_F16 && m->is_folded() && !(g_debug_flags & SWX_FLAG_NO_FAST_STEP);
-    if (dec_ok && f.n_new > 1 && f.W * f.rpw * f.n_new <= 160 &&
-        swx_dec_slab_floats(f.W * f.rpw * f.n_new, m->dims.n_text_state, 4 * m->dims.n_text_state) * 4 <= m->L.slab_bytes)
+    // Multi-token passes (scoring pass, prefill, refine / locate probes) take the dec GEMMs + the 16-row-group cross-attention at
+    // EVERY size since round 4: which kernels compute a row must not depend on how many windows share the launch or on the longest
+    // window of the batch -- window k of a 20-window batch is bit-identical to the same window alone
+    // (tests/test_gpu_batch_invariance.py).  SWX_FLAG_SCORE_TILED restores round 3's dispatch (tiled GEMMs + flash attention
+    // above 160 rows: ~1.5x faster per pass at 20 windows, different rounding points) for A/B runs.
+    const int64_t rows_all = (int64_t)f.W * f.rpw * f.n_new;
+    if (dec_ok && f.n_new > 1 && (rows_all <= 160 || !(g_debug_flags & SWX_FLAG_SCORE_TILED)) && rows_all <= m->L.rows_big &&
+        swx_dec_slab_floats((int)rows_all, m->dims.n_text_state, 4 * m->dims.n_text_state) * 4 <= m->L.slab_bytes)
         return decoder_forward_dec(m, f, s);
     if (dec_ok && f.n_new == 1 && f.row_mul == 1 && !f.capture && f.rpw <= 16 && m->dims.n_audio_ctx >= 128 &&
         (size_t)f.W * f.rpw <= (size_t)m->L.rows_big)
@@ -1141,13 +1150,15 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
     // One unit of the loop = [forward pass of the rows' newest tokens -> final LayerNorm -> logits] + [selection of token i].
     // Token 0 is selected from the prefill logits; after every selection the loop's exit conditions are looked at:
     // context full (decode.py:60), every window done (one host sync every CHECK steps), budget used up.
-    auto unit = [&](int cur_in, hipStream_t st) -> int {
+    auto unit = [&](int cur_in, hipStream_t st, bool capturing = false) -> int {
         FwdCfg g{};
         g.W = W; g.rpw = G; g.row_mul = 1; g.n_new = 1;
         g.tokens = b.tokens[cur_in]; g.ld_tok = b.TS; g.pos0 = b.pos0;
         g.kcache = f.kcache; g.vcache = f.vcache; g.layer_stride = layer_stride; g.cache_rows = m->max_rows;
         g.anc = use_anc ? b.anc[cur_in] : nullptr; g.xkv = (const unsigned char *)d_xkv; g.capture = false;
-        g.step_pos = n_init + steps;          // (profiler only; steps = tokens sampled so far)
+        // profiler's byte count only (steps = tokens sampled so far).  Never a captured kernel argument: a replayed graph would
+        // carry the position of the step it was captured at (the profiler is off under replay, and 0 = "unknown" there)
+        g.step_pos = capturing ? 0 : n_init + steps;
         const int fr = decoder_forward(m, g, st);
         if (fr < 0) return fr;
         unsigned char *hh = m->ws + m->L.h;
@@ -1180,12 +1191,13 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
     // to its start after two steps.  The poll above only falls after odd units, the context check is made for both units up front.
     const bool graph_ok = !g_prof_enabled && !(g_debug_flags & SWX_FLAG_NO_GRAPH) && !m->graphs_off;
     swx_model::StepGraph *sg = nullptr;
+    bool graph_failed_now = false;
     for (int i = 1; !stop; ) {
-        const bool pair = graph_ok && !m->graphs_off && i >= 2 && (i & 1) == 0 && i + 1 < cfg->sample_len && n_init + i + 1 <= D.n_text_ctx;
+        const bool pair = graph_ok && !m->graphs_off && !graph_failed_now && i >= 2 && (i & 1) == 0 && i + 1 < cfg->sample_len && n_init + i + 1 <= D.n_text_ctx;
         if (pair) {
             if (!sg) sg = step_graph(m, b, d_xkv, cur, [&](hipStream_t cs) -> int {
-                SWX_TRY(unit(cur, cs));
-                return unit(cfg->beam ? cur ^ 1 : cur, cs);
+                SWX_TRY(unit(cur, cs, true));
+                return unit(cfg->beam ? cur ^ 1 : cur, cs, true);
             });
             if (sg && hipGraphLaunch(sg->exec, s) == hipSuccess) {
                 ++m->n_replays;
@@ -1195,7 +1207,12 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
                 continue;
             }
             (void)hipGetLastError();
-            m->graphs_off = true;            // capture or replay is not available here: eager for the rest of this handle's life
+            // capture or replay failed: this call goes on eagerly; the next swx_decode tries again, and only the third failure
+            // switches replay off for the handle (swx_graph_stats reports it)
+            graph_failed_now = true;
+            if (++m->graph_failures >= 3) m->graphs_off = true;
+            if (m->graph_failures == 1)
+                fprintf(stderr, "libswx: decode-step graph capture / replay failed; launching the steps eagerly (results are identical)\n");
         }
         SWX_TRY(unit(cur, s));
         ++m->n_eager_units;
@@ -1422,7 +1439,7 @@ int swx_weighted_sum(const float *const *h_xs, const float *h_coef, int n_in, fl
 int swx_graph_stats(const swx_model *m, int64_t *out)
 {
     if (!m || !out) return -1;
-    out[0] = m->n_captures; out[1] = m->n_replays; out[2] = m->n_eager_units; out[3] = m->graphs_off ? 1 : 0;
+    out[0] = m->n_captures; out[1] = m->n_replays; out[2] = m->n_eager_units; out[3] = (m->graphs_off || m->graph_failures > 0) ? 1 : 0;
     return 0;
 }
 

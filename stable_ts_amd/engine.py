@@ -299,7 +299,7 @@ class Engine:
     def score_qk(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], *, n_sot: int, eot: int, row0: int, n_rows: int):
         """Teacher-forced pass that hands out the raw (pre-softmax) attention scores of this engine's alignment heads
         for token rows ``row0 .. row0 + n_rows - 1``: (token_probs list, f32 device tensor [W, heads, n_rows, 1500]).
-        ``all_heads()`` gives a view of the same weights that captures every head of the decoder."""
+        Test / inspection hook: the head-selection variants use ``score_q`` + ``heads_dynamic`` / ``heads_new`` instead."""
         W = len(tokens)
         n_tok = [len(t) for t in tokens]
         max_n = max(n_tok)

@@ -89,7 +89,7 @@ def _span_queue(n_items: int, step: int):
 
 
 def _first_live_window(audio: torch.Tensor, *, suppress_silence=True, q_levels=20, k_size=5, min_word_dur=None,
-                       min_silence_dur=None, nonspeech_skip=None):
+                       min_silence_dur=None, nonspeech_skip=None, suppress_ts_tokens=False):
     """The audio of the first fixed-stride 30-s window that transcribe(batch_size=N) would decode: windows the silence analysis
     marks silent are skipped, a window that opens with a non-speech section >= nonspeech_skip is skipped, a later long section
     cuts the window short (transcribe.py `window_input`, original_whisper.py:505-526)."""
@@ -97,8 +97,11 @@ def _first_live_window(audio: torch.Tensor, *, suppress_silence=True, q_levels=2
     from .audio import N_SAMPLES, SAMPLE_RATE
     from .stabilization import NonSpeechPredictor
     mwd = 0.1 if min_word_dur is None else min_word_dur
+    # the same predictor transcribe()'s `new_track` builds: with suppress_silence=False the is_silent test counts exact-zero
+    # samples, with suppress_ts_tokens it is made on the per-unit mask -- the window the language is settled on must be the one the
+    # single-GPU run settles it on
     predictor = NonSpeechPredictor(q_levels=q_levels, k_size=k_size, min_word_dur=mwd, min_silence_dur=min_silence_dur,
-                                   loudness=bool(suppress_silence))
+                                   get_mask=suppress_ts_tokens, loudness=bool(suppress_silence))
     for k in range(0, int(audio.shape[-1]), N_SAMPLES):
         seg = audio[k:k + N_SAMPLES]
         if not seg.numel():
@@ -170,7 +173,8 @@ def transcribe_sharded(model, audio: torch.Tensor, *, batch_size: int = 8, mode:
         # decode with the same tokenizer without a collective.
         first = _first_live_window(audio, suppress_silence=kw.get("suppress_silence", True), q_levels=kw.get("q_levels", 20),
                                    k_size=kw.get("k_size", 5), min_word_dur=kw.get("min_word_dur"),
-                                   min_silence_dur=kw.get("min_silence_dur"), nonspeech_skip=kw.get("nonspeech_skip"))
+                                   min_silence_dur=kw.get("min_silence_dur"), nonspeech_skip=kw.get("nonspeech_skip"),
+                                   suppress_ts_tokens=kw.get("suppress_ts_tokens", False))
         if first is not None:
             _, probs = model.detect_language(model.log_mel(first, N_SAMPLES - int(first.shape[-1])))
             kw["language"] = max(probs, key=probs.get)

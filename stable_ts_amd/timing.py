@@ -64,7 +64,9 @@ def _split_tokens(tokens: List[int], tokenizer):
     remaining = tokenizer.decode_with_timestamps(tokens)
     # most words are one or two tokens: the decoded form of a single pending token is looked up (same string as decode([t]),
     # memoised per tokenizer) instead of going through the list filter + join of `decode` every time
-    single = tokenizer.__dict__.setdefault("_single_piece", {})
+    # (a slotted or wrapped tokenizer has no instance dict: no memo, plain decode)
+    d_ = getattr(tokenizer, "__dict__", None)
+    single = d_.setdefault("_single_piece", {}) if isinstance(d_, dict) else {}
     words, groups, pending = [], [], []
     glue = False
     piece = ""

@@ -256,8 +256,53 @@ def run_sharp():
         json.dump(out, f, indent=0)
 
 
+JFK_CASE = dict(name="jfk_tiny_en", model="tiny.en", gain=2.0, ts_gain=0.5,
+                opts=dict(temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
+                          sample_len=40, suppress_silence=True), n_words=18, seed=9)
+
+
+def run_jfk():
+    """REAL SPEECH: the reference's test fixture (test/jfk.flac, 11 s of J. F. Kennedy) as this package's loader hands it over
+    (tests/golden/jfk_16k_mono.flac, made by make_jfk_fixture.py: 16 kHz mono on the s16 grid) through the reference's
+    transcribe() and align() on the oracle: the loudness-based silence analysis (stabilization/nonvad.py) now sees the pauses
+    of real speech -- the non-speech sections, the timestamp snapping and the word times are in the fixture
+    (reference_jfk.json); the weights are random (tiny.en architecture): no checkpoint exists offline."""
+    sw = import_reference()
+    from oracle.whisper.model import build_model
+    from oracle.whisper.tokenizer import get_tokenizer
+    from stable_ts_amd.audio_io import load_audio
+    c = JFK_CASE
+    audio = torch.from_numpy(load_audio(os.path.join(HERE, "jfk_16k_mono.flac")))
+    model = build_model(c["model"], seed=1234, std=0.02, embed_gain=c["gain"], ts_gain=c["ts_gain"])
+    sw.modify_model(model)
+    res = model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, regroup=False, word_timestamps=True, **c["opts"])
+    d = res.to_dict()
+    segs = [dict(start=float(s["start"]), end=float(s["end"]), seek=float(s["seek"]), tokens=[int(t) for t in s["tokens"]],
+                 words=[dict(word=w["word"], start=float(w["start"]), end=float(w["end"]), probability=float(w["probability"]),
+                             tokens=[int(t) for t in w["tokens"]]) for w in s["words"]]) for s in d["segments"]]
+    ns = [[float(a), float(b)] for a, b in zip(*res.nonspeech_sections_arrays())] if hasattr(res, "nonspeech_sections_arrays") else \
+        [[float(x["start"]), float(x["end"])] for x in (d.get("nonspeech_sections") or [])]
+    g = torch.Generator().manual_seed(c["seed"])
+    ids = (torch.randint(6, 16000, (c["n_words"],), generator=g) * 3 + 19).tolist()
+    tok = get_tokenizer(False, num_languages=model.num_languages)
+    text = tok.decode(ids)
+    al = model.align(audio, text, language="en", verbose=None, ignore_compatibility=True, regroup=False, suppress_silence=True,
+                     original_split=False)
+    words = [dict(word=w.word, start=float(w.start), end=float(w.end), probability=float(w.probability),
+                  tokens=[int(t) for t in w.tokens]) for w in al.all_words()]
+    al_ns = [[float(x["start"]), float(x["end"])] for x in (al.to_dict().get("nonspeech_sections") or [])]
+    out = dict(case=c, segments=segs, text=d["text"], nonspeech_sections=ns, align_text=text, align_ids=ids, align_words=words,
+               align_nonspeech_sections=al_ns, samples=int(audio.shape[-1]))
+    with open(os.path.join(HERE, "reference_jfk.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("jfk:", len(segs), "segments,", sum(len(s["words"]) for s in segs), "words,", len(ns), "non-speech sections;",
+          "align:", len(words), "words,", len(al_ns), "non-speech sections")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+    if len(sys.argv) > 1 and sys.argv[1] == "jfk":
+        run_jfk()
+    elif len(sys.argv) > 1 and sys.argv[1] == "variants":
         run_variants()
     elif len(sys.argv) > 1 and sys.argv[1] == "sharp":
         run_sharp()

@@ -359,3 +359,40 @@ def test_temperature_ladder_on_device():
     assert [r.tokens for r in again] == [r.tokens for r in res]
     other = model.engine.decode(sub, [list(plan.initial_tokens)], window_uid=[3001], **plan.engine_kwargs())
     assert plan.results(other, [None], ["en"])[0].tokens != r_alone.tokens      # a different window draws differently
+
+
+def test_real_speech_flac_matches_reference_glue():
+    """REAL SPEECH through the path: tests/golden/jfk_16k_mono.flac -- the reference's own fixture
+    test/jfk.flac as the loader hands it over -- given to transcribe() and align() as a FILE PATH (FLAC decoder of libswx,
+    AudioLoader, resident-PCM silence probe) against the reference's transcribe() / align() run on the CPU oracle on the same
+    samples (tests/golden/make_golden.py jfk -> reference_jfk.json): tokens identical, word times within 20 ms, and the
+    loudness-based non-speech sections of real speech (stabilization/nonvad.py) equal."""
+    import stable_ts_amd as sw
+    with open(os.path.join(HERE, "golden", "reference_jfk.json")) as f:
+        g = json.load(f)
+    case = g["case"]
+    path = os.path.join(HERE, "golden", "jfk_16k_mono.flac")
+    model = _model(case)
+    res = model.transcribe(path, language="en", regroup=False, word_timestamps=True, **case["opts"])
+    d = res.to_dict()
+    segs = d["segments"]
+    assert len(segs) == len(g["segments"])
+    for a, b in zip(segs, g["segments"]):
+        assert [int(t) for t in a["tokens"]] == b["tokens"]
+        assert abs(a["seek"] - b["seek"]) < 1e-6 and len(a["words"]) == len(b["words"])
+        for wa, wb in zip(a["words"], b["words"]):
+            assert wa["word"] == wb["word"] and wa["tokens"] == wb["tokens"]
+            assert abs(wa["start"] - wb["start"]) <= 0.02 + 1e-9 and abs(wa["end"] - wb["end"]) <= 0.02 + 1e-9, (wa, wb)
+            assert abs(wa["probability"] - wb["probability"]) <= 1e-3 * max(wb["probability"], 1e-3) + 1e-9
+    ns = [[float(x["start"]), float(x["end"])] for x in (d.get("nonspeech_sections") or [])]
+    assert len(ns) == len(g["nonspeech_sections"]) >= 10
+    assert np.allclose(np.asarray(ns), np.asarray(g["nonspeech_sections"]), atol=1e-6)
+    # forced alignment of a given text on the same real speech, silence suppression on
+    al = model.align(path, g["align_text"], language="en", regroup=False, suppress_silence=True, original_split=False)
+    words = al.all_words()
+    assert len(words) == len(g["align_words"])
+    for wa, wb in zip(words, g["align_words"]):
+        assert wa.word == wb["word"] and [int(t) for t in wa.tokens] == wb["tokens"]
+        assert abs(wa.start - wb["start"]) <= 0.02 + 1e-9 and abs(wa.end - wb["end"]) <= 0.02 + 1e-9, (wa, wb)
+    al_ns = [[float(x["start"]), float(x["end"])] for x in (al.to_dict().get("nonspeech_sections") or [])]
+    assert np.allclose(np.asarray(al_ns), np.asarray(g["align_nonspeech_sections"]), atol=1e-6)

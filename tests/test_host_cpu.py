@@ -298,6 +298,8 @@ def test_ctypes_table_matches_header_prototypes():
             assert res in (ctypes.c_char_p, ctypes.c_void_p), name
         elif rk == "size":
             assert res is ctypes.c_size_t, name
+        elif rk == "i64":
+            assert res is ctypes.c_int64, name
         else:
             assert res is ctypes.c_int, name
         checked += 1

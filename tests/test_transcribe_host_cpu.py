@@ -446,3 +446,39 @@ def test_transcribe_minimal_post_processing(models, monkeypatch):
     assert res.regroup_history != ""
     with pytest.raises(NotImplementedError):
         mine.transcribe_minimal(audio, language="en", vad=True, **BASE)
+
+
+def test_real_speech_flac_path_matches_reference(models, monkeypatch):
+    """the reference's real-speech fixture (test/jfk.flac as tests/golden/jfk_16k_mono.flac) given as a FILE PATH: FLAC decoder of
+    libswx + AudioLoader + window loop + loudness-based silence analysis on real pauses, next to the reference's transcribe() /
+    align() on the same samples -- and next to the committed golden the GPU test compares with (reference_jfk.json)"""
+    import json
+    G, ref_model, mine = models
+    from oracle_engine import install
+    from stable_ts_amd.audio_io import load_audio
+    install(monkeypatch)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "jfk_16k_mono.flac")
+    with open(os.path.join(os.path.dirname(path), "reference_jfk.json")) as f:
+        gold = json.load(f)
+    audio = torch.from_numpy(load_audio(path))
+    assert audio.shape[-1] == gold["samples"]
+    opts = dict(gold["case"]["opts"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = ref_model.transcribe(audio, language="en", verbose=None, ignore_compatibility=True, regroup=False, word_timestamps=True, **opts)
+        got = mine.transcribe(path, language="en", regroup=False, word_timestamps=True, **opts)
+        want_al = ref_model.align(audio, gold["align_text"], language="en", verbose=None, ignore_compatibility=True, regroup=False,
+                                  suppress_silence=True, original_split=False)
+        import stable_ts_amd.alignment as A
+        mine.manual_attention_encoder = True      # the reference's align encodes inside disable_sdpa() (timing.py:58-60)
+        try:
+            got_al = A.align(mine, path, gold["align_text"], language="en", regroup=False, suppress_silence=True, original_split=False)
+        finally:
+            mine.manual_attention_encoder = False
+    assert got.to_dict() == want.to_dict()
+    assert len(want.nonspeech_sections) >= 10                         # real pauses
+    assert [[float(s["start"]), float(s["end"])] for s in got.to_dict()["nonspeech_sections"]] == gold["nonspeech_sections"]
+    assert [[int(t) for t in s["tokens"]] for s in got.to_dict()["segments"]] == [s["tokens"] for s in gold["segments"]]
+    assert got_al.to_dict() == want_al.to_dict()
+    assert [(w.word, float(w.start), float(w.end)) for w in got_al.all_words()] == \
+        [(w["word"], w["start"], w["end"]) for w in gold["align_words"]]
