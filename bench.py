@@ -119,7 +119,7 @@ def main():
     # transcripts were almost only timestamp tokens (~1 word per window)
     # (defaults = stable_ts_amd.BENCH_WEIGHTS, the recipe the full-depth fp16 parity tests assert on: tests/test_gpu_f16_depth.py)
     ap.add_argument("--embed-gain", type=float, default=9.0)
-    ap.add_argument("--ts-gain", type=float, default=0.01)
+    ap.add_argument("--ts-gain", type=float, default=0.1)
     ap.add_argument("--ln-jitter", type=float, default=0.1)
     ap.add_argument("--xattn-gain", type=float, default=8.0)
     ap.add_argument("--max-instant-words", type=float, default=1.0)

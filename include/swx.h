@@ -264,7 +264,8 @@ int swx_test_gemm(int dtype, const void *d_a, int64_t lda, const void *d_w, cons
 int swx_test_gemm_plan(int M, int N, int K, int epilogue, int force_kernel, int flags);
 /* decode-step "dec" GEMM (csrc/swx_decstep.hip), f16: epilogue bits 1 = LayerNorm fold (gamma / beta given, A = raw rows, K = full
  * row), 2 = GELU, 4 = residual update of d_x in place, 8 = QKV scatter (columns >= d go to the caches at pos0[m]), 16 = K-split
- * allowed.  d_scratch: >= N*K*2 + 8N + slab bytes + 1 KiB. */
+ * allowed, 64 = a multi-token pass (from 161 rows on the launch takes the tall kernel: register-resident weights, 16-row tiles; with
+ * 8, rows are 7 tokens per sequence; bit-identical to the launch without it).  d_scratch: >= N*K*2 + 8N + slab bytes + 1 KiB. */
 int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float *d_gamma, const float *d_beta,
                       const float *d_bias, void *d_c, int64_t ldc, void *d_x, void *d_kcache, void *d_vcache,
                       const int32_t *d_pos0, int n_ctx, int d, int M, int N, int K, int epilogue, void *d_scratch,

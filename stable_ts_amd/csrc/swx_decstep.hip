@@ -263,6 +263,174 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     }
 }
 
+// ------------------------------------------------------------------------------------------------- tall variant
+// The same projection for MANY rows (a multi-token pass over a whole batch: the scoring pass of 20 windows is 2 260 rows, a
+// prefill with prompts several thousand).  The kernel above gives every 48 rows x 64 columns their own workgroup, which then
+// re-reads its 160 KB of weights and waits out one DMA round trip for 0.3 us of MFMAs; here a workgroup keeps its four waves'
+// weight fragments in REGISTERS and walks a run of 16-row tiles through two LDS buffers: the LDS-DMA of tile t + 1 (issued
+// from inline asm, so that hipcc neither sees it nor drains it) flies under the statistics, MFMAs and epilogue of tile t.
+// Per output element the arithmetic is the kernel's above, instruction for instruction -- the LayerNorm statistics from the
+// same 16-lanes-per-row dot products, the k-steps in the same order into one accumulator, the same epilogue expressions --
+// so a row's result does not depend on which of the two kernels, or how many rows, the launch had
+// (tests/hw_checks/dec_tall_check.py: bit-identical; tests/test_gpu_batch_invariance.py end to end).
+__device__ __forceinline__ void dec_glds16_asm(const void *gsrc, unsigned lds_dst)
+{
+    unsigned keep;     // M0 is the DMA's LDS base and belongs to hipcc: saved and restored inside the statement
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int NKS, int EPI>
+__global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
+{
+    constexpr bool E_LN = (EPI & DEC_LN) != 0, E_GELU = (EPI & DEC_GELU) != 0, E_RES = (EPI & DEC_RES) != 0,
+                   E_QKV = (EPI & DEC_QKV) != 0, E_SLAB = (EPI & DEC_SLAB) != 0;
+    constexpr int kslice = NKS * 32, SPR = kslice >> 3, RS = kslice * 2, TILE = 16 * RS;
+    constexpr int DMA_PER_WAVE = NKS / 4;          // 16 rows x SPR slots / 64 lanes = NKS instructions per tile, dealt over 4 waves
+    static_assert(NKS % 4 == 0, "tile = whole DMA instructions per wave");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [16][kslice] f16 | float2 stat[2][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int li = lane & 15, lg = lane >> 4;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int unit = (slot / g.n_rg) * 8 + xcd, rsplit = slot % g.n_rg;     // g.n_rg = row splits here
+    const int panels = (g.N + 63) >> 6;
+    if (unit >= panels * g.ks2) return;
+    const int panel = unit / g.ks2, ks_id = unit - panel * g.ks2;
+    const int k0 = ks_id * kslice;
+    const int n_tiles = (g.M + 15) >> 4;
+    const int t_begin = rsplit * g.tps;
+    const int t_end = t_begin + g.tps < n_tiles ? t_begin + g.tps : n_tiles;
+    if (t_begin >= t_end) return;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void *)smem;
+
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int j = 0; j < DMA_PER_WAVE; ++j) {
+            const int q = j * 4 + wave_u;
+            const int p = q * 64 + lane;
+            const int row = p / SPR, ps = p - row * SPR;
+            const int kslot = ps ^ (row & 15);
+            const int gr = tile * 16 + row < g.M ? tile * 16 + row : g.M - 1;
+            dec_glds16_asm(g.A + (size_t)gr * g.lda + k0 + kslot * 8, lds0 + buf * TILE + q * 1024);
+        }
+    };
+    stage(t_begin, 0);
+    // this wave's 16 columns of weights, resident for the whole run of tiles
+    const f16 *wp = g.W + ((size_t)(panel * 4 + wave) * (g.K >> 5) + (size_t)ks_id * NKS) * 512 + lane * 8;
+    f16x8 wf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wf[ks] = *(const f16x8 *)(wp + (size_t)ks * 512);
+    const int n = panel * 64 + wave * 16 + lg * 4;
+    const int nc = n < g.N ? n : g.N - 4;
+    f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (!E_SLAB) c2 = *(const f32x4 *)(g.c2 + nc);
+    if constexpr (E_LN) c1 = *(const f32x4 *)(g.c1 + nc);
+    float2 *stat = (float2 *)(smem + 2 * TILE);
+    const int rps = g.rps > 1 ? g.rps : 1;
+    // hipcc's waits for the loads it can see (weights, column constants) belong in FRONT of the loop: a wait placed at their first
+    // use inside the body would run every iteration and drain the next tile's DMA with it
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(wf[ks]));
+    asm volatile("" : "+v"(c1), "+v"(c2));
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        const int m = t * 16 + li, mc = m < g.M ? m : g.M - 1;
+        // tile t has landed (and, first time round, the weights; later, the previous tile's stores are out): every wave waits
+        // for its own share, the barrier makes it true for all
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // epilogue operands of this tile, requested before the next tile's DMA so that a counted wait can tell them apart
+        f16x4 xres = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        int posv = 0;
+        if constexpr (E_RES && !E_SLAB)
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xres) : "v"(g.X + (size_t)mc * g.ldx + nc) : "memory");
+        if constexpr (E_QKV) {
+            const int seq = mc / rps, crow = seq * (g.row_mul > 1 ? g.row_mul : 1);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(posv) : "v"(g.pos0 + crow) : "memory");
+        }
+        stage(t + 1 < t_end ? t + 1 : t, buf ^ 1);       // (the last tile re-stages itself into the idle buffer: never predicated)
+        const unsigned char *tile = smem + buf * TILE;
+        if constexpr (E_LN) {
+            const f16x2 one2 = {(f16)1.f, (f16)1.f};
+            const int rb = wave * 4 + lg;                 // 16 lanes per row, one row per (wave, lane group)
+            const unsigned char *rp = tile + (size_t)rb * RS + li * 16;
+            f16x8 v[SPR / 16];
+#pragma unroll
+            for (int i = 0; i < SPR / 16; ++i) v[i] = *(const f16x8 *)(rp + i * 256);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < SPR / 16; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f16x2 pr = {v[i][2 * e], v[i][2 * e + 1]};
+                    s1 = __builtin_amdgcn_fdot2(pr, one2, s1, false);
+                    s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
+                }
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            if (li == 0) {
+                const float inv = 1.0f / (float)kslice;
+                const float mean = s1 * inv;
+                float var = s2 * inv - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                stat[buf * 16 + rb] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+            }
+        }
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char *abase = tile + (size_t)li * RS;
+        constexpr int PF = 4;
+        f16x8 af[PF];
+#pragma unroll
+        for (int ks = 0; ks < PF; ++ks) af[ks] = *(const f16x8 *)(abase + (((ks * 4 + lg) ^ li) << 4));
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[ks % PF], acc, 0, 0, 0);
+            if (ks + PF < NKS) af[ks % PF] = *(const f16x8 *)(abase + ((((ks + PF) * 4 + lg) ^ li) << 4));
+        }
+        if constexpr (E_LN) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // stat[] visible to every wave
+        // the operand loads are older than the next tile's DMA: they have landed once only the DMA is pending
+        if constexpr ((E_RES && !E_SLAB) || E_QKV)
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(xres), "+v"(posv) : "n"(DMA_PER_WAVE) : "memory");
+        if (n >= g.N || m >= g.M) continue;
+        if constexpr (E_SLAB) {
+            *(f32x4 *)(g.slabs + (size_t)ks_id * g.slab_stride + (size_t)m * g.N + n) = acc;
+            continue;
+        }
+        f32x4 v = acc;
+        if constexpr (E_LN) {
+            const float2 st = stat[buf * 16 + li];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = st.y * (v[e] - st.x * c1[e]) + c2[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += c2[e];
+        }
+        if constexpr (E_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        f16 *dst;
+        if constexpr (E_RES) {
+            dst = g.X + (size_t)m * g.ldx + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)xres[e];
+        } else if (E_QKV && n >= g.d) {
+            const int seq = m / rps, crow = seq * (g.row_mul > 1 ? g.row_mul : 1), pos = posv + (m - seq * rps);
+            f16 *cache = n < 2 * g.d ? g.kcache : g.vcache;
+            dst = cache + ((size_t)crow * g.n_ctx + pos) * g.d + (n < 2 * g.d ? n - g.d : n - 2 * g.d);
+        } else {
+            dst = g.C + (size_t)m * g.ldc + n;
+        }
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+        *(f16x4 *)dst = o;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the idle re-stage of the last tile must not outlive the workgroup's LDS
+}
+
 // x[m][n] = f16(x + bias[n] + sum_k slab[k][m][n]) : the reduction of the one projection that stays K-split (K = 4d)
 template <int KS>
 __global__ __launch_bounds__(256) void dec_slab_finish(const float *__restrict__ slabs, int64_t stride, int ks2, const float *__restrict__ bias,
@@ -365,12 +533,46 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     g.slab_stride = (int64_t)g.M * g.N;
     const int nks = g.kslice / 32;
     const int units = (g.N / 64) * ks2;
+    const int epi = g.epi & (DEC_LN | DEC_GELU | DEC_RES | DEC_QKV | DEC_SLAB);
+    if (g.tall && g.M > 160 && nks % 4 == 0 && !(swx_flags() & SWX_FLAG_NO_TALL)) {
+        // tall kernel: ~two rounds of the chip's 256 CUs, every workgroup a run of `tps` 16-row tiles
+        const int n_tiles = cdiv(g.M, 16);
+        int rs = 512 / (cdiv(units, 8) * 8);
+        if (rs < 1) rs = 1;
+        if (rs > n_tiles) rs = n_tiles;
+        g.tps = cdiv(n_tiles, rs);
+        g.n_rg = cdiv(n_tiles, g.tps);
+        const int grid = cdiv(units, 8) * g.n_rg * 8;
+        const size_t lds = (size_t)2 * 16 * g.kslice * 2 + 2 * 16 * sizeof(float2);
+        SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
+#define SWX_TALL(NK_, EP_) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { \
+            hipError_t e_ = hipFuncSetAttribute((const void *)gemm_dectall_f16<NK_, EP_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            if (e_ != hipSuccess) return -100 - (int)e_; \
+            attr_done = true; \
+        } \
+        hipLaunchKernelGGL((gemm_dectall_f16<NK_, EP_>), dim3(grid), dim3(256), lds, s, g); } while (0)
+#define SWX_TALL_NK(EP_) do { switch (nks) { \
+        case 12: SWX_TALL(12, EP_); break; case 16: SWX_TALL(16, EP_); break; case 20: SWX_TALL(20, EP_); break; \
+        case 24: SWX_TALL(24, EP_); break; case 32: SWX_TALL(32, EP_); break; case 40: SWX_TALL(40, EP_); break; \
+        default: return -4; } } while (0)
+        switch (epi) {
+            case DEC_LN | DEC_QKV: SWX_TALL_NK(DEC_LN | DEC_QKV); break;
+            case DEC_RES: SWX_TALL_NK(DEC_RES); break;
+            case DEC_LN: SWX_TALL_NK(DEC_LN); break;
+            case DEC_LN | DEC_GELU: SWX_TALL_NK(DEC_LN | DEC_GELU); break;
+            case DEC_RES | DEC_SLAB: SWX_TALL_NK(DEC_RES | DEC_SLAB); break;
+            default: return -4;
+        }
+#undef SWX_TALL_NK
+#undef SWX_TALL
+    } else {
     const int grid = cdiv(units, 8) * g.n_rg * 8;
     const size_t lds = (size_t)mt * 16 * g.kslice * 2 + (size_t)mt * 16 * sizeof(float2);
     {   // (profiler scopes must not nest: each one closes the most recent record)
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
     // the epilogues the decoder step uses (compile-time): QKV, out-projections, cross-q, MLP-in, MLP-out (split / un-split)
-    const int epi = g.epi & (DEC_LN | DEC_GELU | DEC_RES | DEC_QKV | DEC_SLAB);
 #define SWX_DEC(MT_, NK_, EP_) do { \
         static bool attr_done = false; \
         if (!attr_done) { \
@@ -395,6 +597,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
 #undef SWX_DEC_NK
 #undef SWX_DEC_MT
 #undef SWX_DEC
+    }
     }
     SWX_CHECK_LAUNCH();
     if (ks2 > 1) {

@@ -43,6 +43,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_NO_RING 65536        // tiled GEMM: never the ring kernel for launches with few tiles (A/B; results are bit-identical)
 #define SWX_FLAG_SCORE_TILED 262144   // multi-token decoder passes above 160 rows on the tiled GEMMs + flash attention (round 3's
                                       // dispatch: faster at >= 2 windows, but a window's rounding then depends on its batch) -- A/B only
+#define SWX_FLAG_NO_TALL 524288       // multi-token passes: never the tall dec GEMM (register-resident weights, 16-row tiles): A/B, bit-identical
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
@@ -78,6 +79,9 @@ struct DecGemmArgs {
     int rps;                             // DEC_QKV: rows per sequence (0 / 1: one new token per row); row m = sequence m / rps, token m % rps
     int row_mul;                         // DEC_QKV: cache row (and pos0 index) of sequence q = q * row_mul (0 / 1: q itself; the prefill writes row w * G)
     int ks2, kslice, n_rg; int64_t slab_stride;   // filled by the launcher
+    int tall;                            // caller: 1 = a multi-token pass (rows may run into the thousands): from 161 rows on the launcher takes the
+                                         // kernel that keeps the weights in registers and walks 16-row tiles (same arithmetic per element)
+    int tps;                             // launcher (tall kernel): 16-row tiles per workgroup; n_rg = row splits
     DecPrefetch pf;                      // cache prefetch of the NEXT projection's weights (pf.base == null: none)
 };
 int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation

@@ -469,7 +469,7 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         const LayerW &w = m->dec[l];
         f16 *kc = (f16 *)(f.kcache + (size_t)l * f.layer_stride), *vc = (f16 *)(f.vcache + (size_t)l * f.layer_stride);
         DecGemmArgs g{};
-        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wqkv_f); g.ldw = d; g.N = 3 * d; g.K = d; g.epi = DEC_LN | DEC_QKV;
+        g.M = rows; g.tall = 1; g.A = x; g.lda = d; g.W = m->A<f16>(w.wqkv_f); g.ldw = d; g.N = 3 * d; g.K = d; g.epi = DEC_LN | DEC_QKV;
         g.c1 = m->A<float>(w.qkv_c1); g.c2 = m->A<float>(w.qkv_c2); g.C = q; g.ldc = d;
         g.kcache = kc; g.vcache = vc; g.pos0 = f.pos0; g.n_ctx = D.n_text_ctx; g.d = d; g.rps = f.n_new; g.row_mul = f.row_mul;
         g.pf = pf_of(w.wo_p, d, d, DEC_RES);
@@ -479,12 +479,12 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         sa.R = R; sa.n_new = f.n_new; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
         SWX_TRY(swx_self_attention(m->dtype, sa, f.row_mul, s));
         g = DecGemmArgs{};
-        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.M = rows; g.tall = 1; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
         g.pf = pf_of(w.wcq_f, d, d, DEC_LN);
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
-        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
+        g.M = rows; g.tall = 1; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
         g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
         g.pf = pf_of(w.wco_p, d, d, DEC_RES);
         SWX_TRY(swx_gemm_dec(g, s));
@@ -505,17 +505,17 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
                                    m->head_slot0[l], m->n_align, f.W, m->Wp<float>(m->L.cap), f.cap_ld_n, D.n_audio_ctx, s));
         }
         g = DecGemmArgs{};
-        g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
+        g.M = rows; g.tall = 1; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
         g.c2 = m->A<float>(w.bco); g.X = x; g.ldx = d;
         g.pf = pf_of(w.w1_f, 4 * d, d, DEC_LN | DEC_GELU);
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
-        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.w1_f); g.ldw = d; g.N = 4 * d; g.K = d; g.epi = DEC_LN | DEC_GELU;
+        g.M = rows; g.tall = 1; g.A = x; g.lda = d; g.W = m->A<f16>(w.w1_f); g.ldw = d; g.N = 4 * d; g.K = d; g.epi = DEC_LN | DEC_GELU;
         g.c1 = m->A<float>(w.w1_c1); g.c2 = m->A<float>(w.w1_c2); g.C = u; g.ldc = 4 * d;
         g.pf = pf_of(w.w2_p, d, 4 * d, DEC_RES | DEC_SLAB);
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
-        g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
+        g.M = rows; g.tall = 1; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
         g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
         if (l + 1 < D.n_text_layer) g.pf = pf_of(m->dec[l + 1].wqkv_f, 3 * d, d, DEC_LN | DEC_QKV);
         SWX_TRY(swx_gemm_dec(g, s));
@@ -1503,6 +1503,8 @@ int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float
     g.C = (f16 *)d_c; g.ldc = ldc; g.X = (f16 *)d_x; g.ldx = ldc; g.slabs = slabs;
     g.kcache = (f16 *)d_kcache; g.vcache = (f16 *)d_vcache; g.pos0 = d_pos0; g.n_ctx = n_ctx; g.d = d;
     g.epi = epilogue & 31;
+    g.tall = (epilogue & 64) ? 1 : 0;                 // bit 6: a multi-token pass (the tall kernel from 161 rows on)
+    g.rps = (epilogue & 64) && (epilogue & DEC_QKV) ? 7 : 0;      // (QKV scatter of the tall test: 7 rows per sequence)
     if ((epilogue & DEC_LN) && (epilogue & 32)) {     // bit 5: d_w is already folded, d_gamma / d_beta are c1 / c2 (timing runs)
         g.W = (const f16 *)d_w; g.c1 = d_gamma; g.c2 = d_beta;
     } else if (epilogue & DEC_LN) {

@@ -50,8 +50,10 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> tor
 # The random-weight recipe of the benchmark AND of the full-depth fp16 parity tests (bench.py, tests/test_gpu_f16_depth.py,
 # tests/test_gpu_batch_invariance.py): token-embedding gain 9 and cross-attention score gain 8 give the top-1 / top-2 logit gaps
 # and the peaky attention maps of a trained model, the LayerNorm jitter gives the affine parameters values other than (1, 0),
-# timestamp rows x0.01 keep ~111 text tokens per 112-step window (a transcript-like token mix).
-BENCH_WEIGHTS = dict(embed_gain=9.0, ts_gain=0.01, ln_jitter=0.1, xattn_gain=8.0)
+# timestamp rows x0.1 keep ~111 text tokens per 112-step window (a transcript-like token mix) while the timestamp logits stay
+# distinguishable (x0.01 made the 1 501 timestamp logits equal to within 0.02: the beams of a beam search then differ only in
+# a near-tied initial timestamp and fp16 rounding picks another one -- measured in round 4, scripts/f16_error_budget.py).
+BENCH_WEIGHTS = dict(embed_gain=9.0, ts_gain=0.1, ln_jitter=0.1, xattn_gain=8.0)
 
 
 def random_state_dict(dims: ModelDimensions, seed: int = 1234, std: float = 0.02, embed_gain: float = 1.0,
