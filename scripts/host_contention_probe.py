@@ -89,13 +89,13 @@ def record(args, path):
     finally:
         eng.decode, eng.score_finish, eng.dtw, E.loudness_probe = real_decode, real_finish, real_dtw, real_probe
     with open(path, "wb") as f:
-        pickle.dump(dict(tape=tape, audio=audio.cpu(), dims=dims.__dict__, is_multilingual=model.is_multilingual,
+        pickle.dump(dict(tape=tape, audio=None if args.record_only else audio.cpu(), minutes=args.minutes, dims=dims.__dict__, is_multilingual=model.is_multilingual,
                          num_languages=model.num_languages, n_words=len(res.all_words()), kw=kw), f)
     return device_pass_ms, len(res.all_words())
 
 
 # ------------------------------------------------------------------------------------------------------------------ replay
-def replay(path, passes):
+def replay(path, passes, profile=""):
     """host-only passes on the recorded tape; prints ms per pass"""
     import types
     import torch
@@ -105,6 +105,9 @@ def replay(path, passes):
     with open(path, "rb") as f:
         rec = pickle.load(f)
     tape = rec["tape"]
+    if rec.get("audio") is None:                   # a tape made with --record-only leaves the (seeded, synthetic) recording out
+        from bench import synth_audio
+        rec["audio"] = synth_audio(rec["minutes"] * 60.0, seed=0)
 
     class DeviceAudio(torch.Tensor):               # the recording's windows were resident on the GPU: the host code asks
         is_cuda = property(lambda self: True)      # `is_cuda` to choose the probe path; nothing else about it is used
@@ -168,12 +171,26 @@ def replay(path, passes):
     E.loudness_probe = lambda chunks: model.engine._next("probe")
     audio = rec["audio"].as_subclass(DeviceAudio) if tape["probe"] else rec["audio"]
     times = []
-    for _ in range(passes + 1):
+    pr = None
+    for i_ in range(passes + 1):
+        if profile and i_ == 1:
+            import cProfile
+            pr = cProfile.Profile()
+            pr.enable()
         model.engine.pos = dict(decode=0, score=0, dtw=0, probe=0)
         t0 = time.perf_counter()
         res = model.transcribe(audio, **rec["kw"])
         times.append(1000.0 * (time.perf_counter() - t0))
         assert len(res.all_words()) == rec["n_words"], (len(res.all_words()), rec["n_words"])
+    if pr is not None:
+        import io
+        import pstats
+        pr.disable()
+        buf, buf2 = io.StringIO(), io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats("tottime").print_stats(45)
+        pstats.Stats(pr, stream=buf2).sort_stats("cumulative").print_stats(70)
+        with open(profile, "w") as f:
+            f.write(f"{passes} replayed passes\n" + buf.getvalue() + "\n\n=========== cumulative\n" + buf2.getvalue())
     print(json.dumps(dict(ms=sorted(times[1:])[len(times[1:]) // 2], all=times[1:])), flush=True)
 
 
@@ -200,10 +217,15 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--replay", default="")
     ap.add_argument("--tape", default="/tmp/swx_host_tape.pkl")
+    ap.add_argument("--record-only", action="store_true", help="write the tape (without the audio) and stop: replay / profile it elsewhere")
+    ap.add_argument("--profile", default="", help="with --replay: cProfile of the replayed passes, sorted by own time, written here")
     args = ap.parse_args()
     if args.replay:
-        return replay(args.replay, args.passes)
+        return replay(args.replay, args.passes, args.profile)
     device_pass_ms, n_words = record(args, args.tape)
+    if args.record_only:
+        print(json.dumps(dict(tape=args.tape, device_pass_ms=round(device_pass_ms, 1), words=n_words)))
+        return
     alone = run_replays(args.tape, 1, args.passes)[0]
     many = sorted(run_replays(args.tape, args.procs, args.passes))
     print(json.dumps({"workload": f"{args.model}, {args.minutes:g} min, batch {args.batch}, beam {args.beam}, {n_words} words per pass",

@@ -239,11 +239,19 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const f16 *__restrict_
 // for a multi-token pass over many windows, where one workgroup per group would re-stream the head's 384 KB once per group --
 // 8 times for a ~113-row scoring pass: measured +14 ms per 20-window pass).  Every group's arithmetic is the one-group
 // kernel's (same key order per wave, same merge), so the result does not depend on QG.
-template <bool PACKED, int QG>
-__global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
+// FQ > 0 (decode step, PACKED, QG = 1): FQ = d / 32 k-steps of the cross-attention QUERY projection run inside this launch (AttnArgs::fq_*).
+// The workgroup of (window b, head h) DMAs the 16-row tile of the raw residual stream that starts at the window's first row into
+// LDS, its four waves take the head's four 16-column panels of the packed LayerNorm-folded weights (all FQ fragments of a wave in
+// flight at once, like gemm_dec_f16), compute the rows' LayerNorm statistics from the tile, run the FQ MFMAs and leave
+// f16(rstd (acc - mean c1) + c2) in a 2 KB LDS tile the attention part reads its query fragments from -- the statistics, the
+// k-step order and the epilogue expression of swx_decstep.hip::gemm_dec_f16<1, FQ, DEC_LN>, so q is bit-identical to the separate
+// launch (tests: test_decode_f16_fused_cross_query_is_bit_identical).  The first K / V^T block is requested before any of it.
+template <bool PACKED, int QG, int FQ>
+__device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
 {
     __shared__ float sm_m[4][16], sm_l[4][16];
     __shared__ float sm_o[4][DH][17];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char fq_smem[];   // FQ: [16][FQ * 32] f16 | float2 stat[16] | f16 q[16][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     // blockIdx.z = QG groups of 16 query rows of this (window, head): a teacher-forced pass of ~100 rows over ONE window has 20
@@ -295,12 +303,92 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
     load_blk(wave, kA, vA);
 
     f16x8 qf[QG][2];
+    if constexpr (FQ > 0) {
+        static_assert(QG == 1 && FQ % 4 == 0, "fused query projection: one group of <= 16 rows");
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x4v __attribute__((ext_vector_type(4)));
+        constexpr int kslice = FQ * 32, SPR = kslice >> 3, RS = kslice * 2;
+        const int li = lane & 15, lg = lane >> 4;
+        const int row0 = b * a.q_rows_per_batch;
+        // residual tile -> LDS (rows past the stream's end are clamped: their results are never read)
+#pragma unroll
+        for (int j = 0; j < FQ / 4; ++j) {
+            const int qi = j * 4 + wave;
+            const int p = qi * 64 + lane;
+            const int row = p / SPR, ps = p - row * SPR;
+            const int kslot = ps ^ (row & 15);
+            const int gr = row0 + row < a.fq_rows ? row0 + row : a.fq_rows - 1;
+            __builtin_amdgcn_global_load_lds(a.fq_x + (size_t)gr * a.fq_ldx + kslot * 8, (lds_void *)(fq_smem + qi * 1024), 16, 0, 0);
+        }
+        const f16 *wp = a.fq_w + ((size_t)(h * 4 + wave) * FQ) * 512 + lane * 8;
+        f16x8 wf[FQ];
+#pragma unroll
+        for (int ks = 0; ks < FQ; ++ks) wf[ks] = *(const f16x8 *)(wp + (size_t)ks * 512);
+        const int ncol = h * DH + wave * 16 + lg * 4;
+        const f32x4 c2 = *(const f32x4 *)(a.fq_c2 + ncol), c1 = *(const f32x4 *)(a.fq_c1 + ncol);
+        unsigned pfv = 0;
+        if (a.fq_pf) {      // cache prefetch of the next projection's weights: one 128-byte line per thread, result never read
+            int line = ((b * a.H + h) * 4 + wave) * 64 + lane;
+            line = line < a.fq_pf_lines ? line : a.fq_pf_lines - 1;
+            pfv = *(const volatile unsigned *)((const unsigned char *)a.fq_pf + (size_t)line * 128);
+        }
+        __syncthreads();                                    // tile landed (hipcc drains every load of the wave in front of it)
+        float2 *stat = (float2 *)(fq_smem + 16 * RS);
+        f16 *qt = (f16 *)(fq_smem + 16 * RS + 16 * sizeof(float2));
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const unsigned char *abase = fq_smem + (size_t)li * RS;
+#pragma unroll
+        for (int ks = 0; ks < FQ; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], *(const f16x8 *)(abase + (((ks * 4 + lg) ^ li) << 4)), acc, 0, 0, 0);
+        // (the statistics after the MFMAs: their row registers do not have to live next to the 40 weight fragments)
+        {
+            const f16x2 one2 = {(f16)1.f, (f16)1.f};
+            const int rb = wave * 4 + lg;
+            const unsigned char *rp = fq_smem + (size_t)rb * RS + li * 16;
+            f16x8 v[SPR / 16];
+#pragma unroll
+            for (int i = 0; i < SPR / 16; ++i) v[i] = *(const f16x8 *)(rp + i * 256);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < SPR / 16; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const f16x2 pr = {v[i][2 * e], v[i][2 * e + 1]};
+                    s1 = __builtin_amdgcn_fdot2(pr, one2, s1, false);
+                    s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
+                }
+#pragma unroll
+            for (int o2 = 1; o2 < 16; o2 <<= 1) { s1 += __shfl_xor(s1, o2, 64); s2 += __shfl_xor(s2, o2, 64); }
+            if (li == 0) {
+                const float inv = 1.0f / (float)kslice;
+                const float mean = s1 * inv;
+                float var = s2 * inv - mean * mean;
+                var = var > 0.f ? var : 0.f;
+                stat[rb] = make_float2(mean, 1.0f / sqrtf(var + 1e-5f));
+            }
+        }
+        __syncthreads();                                    // stat[] visible
+        {
+            const float2 st = stat[li];
+            f16x4v o4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o4[e] = (f16)(st.y * (acc[e] - st.x * c1[e]) + c2[e]);
+            *(f16x4v *)(qt + li * DH + wave * 16 + lg * 4) = o4;
+        }
+        __syncthreads();
+        const bool qok = qn < a.nq;
+        qf[0][0] = qok ? *(const f16x8 *)(qt + qn * DH + g * 8) : (f16x8)(f16)0;
+        qf[0][1] = qok ? *(const f16x8 *)(qt + qn * DH + 32 + g * 8) : (f16x8)(f16)0;
+        asm volatile("" ::"v"(pfv));
+    } else {
 #pragma unroll
     for (int u = 0; u < QG; ++u) {
         const bool qok = q_base0 + u * 16 + qn < a.nq;
         const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qok ? q_base0 + u * 16 + qn : 0)) * a.ldq + h * DH + g * 8;
         qf[u][0] = qok ? *(const f16x8 *)(qp) : (f16x8)(f16)0;
         qf[u][1] = qok ? *(const f16x8 *)(qp + 32) : (f16x8)(f16)0;
+    }
     }
 
     auto compute_blk = [&](int cb, const f16x8 (&kf)[4], const f16x8 (&vf)[4]) {
@@ -386,6 +474,13 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a)
         }
     }
 }
+
+template <bool PACKED, int QG>
+__global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a) { attn_decode_cross_body<PACKED, QG, 0>(a); }
+// with the query projection inside: the 40 weight fragments of a wave must not cost the launch its second workgroup per CU
+// (W x H = 400 workgroups stream K / V^T concurrently; at one per CU they would run in two rounds) -- two blocks per CU = 256 registers
+template <int FQ>
+__global__ __launch_bounds__(256, 2) void attn_decode_cross_xq_f16(AttnArgs a) { attn_decode_cross_body<true, 1, FQ>(a); }
 
 // ============================================================================================ dense rowwise
 constexpr int RW_QB = 8;
@@ -768,18 +863,39 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
     const bool dec = (dtype == SWX_F16) && a.vt_kp > 0 && (a.nq <= 16 || small_pass) && a.nk >= 128 && (force_kernel == 3 || force_kernel == 0);
     if (force_kernel == 3 && !dec) return -5;
     if (dec) {
-        SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
+        SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq) +
+                                               (a.fq_w ? 2.0 * a.H * 64 * a.fq_k + 2.0 * a.fq_rows * a.fq_k : 0.0), s);
         // groups of 16 query rows per workgroup: one while the launch is small (a decode step; align(): one window = 100-160
         // workgroups), up to four when many windows share the pass (the head's K / V^T is then streamed once per 64 rows)
         const int64_t wgs1 = (int64_t)a.B * a.H * ngrp;
         const int qg = (a.nq <= 16 || wgs1 <= 512) ? 1 : (ngrp >= 4 && wgs1 > 2048) ? 4 : 2;
         dim3 gd(a.H, a.B, cdiv(ngrp, qg));
         const bool packed = a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV);     // else row-layout K / V^T: the reference
-        if (packed) {
+        if (packed && a.fq_w && qg == 1 && a.nq <= 16) {
+            // fused query projection: + [16][K] residual tile, statistics, q tile in dynamic LDS
+            const int fq = a.fq_k / 32;
+            const size_t lds = (size_t)16 * a.fq_k * 2 + 16 * sizeof(float2) + 16 * DH * 2;
+#define SWX_XQ(FQ_) do { \
+            static bool attr_done = false; \
+            if (!attr_done) { \
+                hipError_t e_ = hipFuncSetAttribute((const void *)attn_decode_cross_xq_f16<FQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                if (e_ != hipSuccess) return -100 - (int)e_; \
+                attr_done = true; \
+            } \
+            hipLaunchKernelGGL((attn_decode_cross_xq_f16<FQ_>), gd, dim3(256), lds, s, a); } while (0)
+            switch (fq) {
+                case 12: SWX_XQ(12); break; case 16: SWX_XQ(16); break; case 20: SWX_XQ(20); break;
+                case 24: SWX_XQ(24); break; case 32: SWX_XQ(32); break; case 40: SWX_XQ(40); break;
+                default: return -5;
+            }
+#undef SWX_XQ
+        } else if (packed) {
+            if (a.fq_w) return -5;
             if (qg == 1) hipLaunchKernelGGL((attn_decode_cross_f16<true, 1>), gd, dim3(256), 0, s, a);
             else if (qg == 2) hipLaunchKernelGGL((attn_decode_cross_f16<true, 2>), gd, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((attn_decode_cross_f16<true, 4>), gd, dim3(256), 0, s, a);
         } else {
+            if (a.fq_w) return -5;
             if (qg == 1) hipLaunchKernelGGL((attn_decode_cross_f16<false, 1>), gd, dim3(256), 0, s, a);
             else if (qg == 2) hipLaunchKernelGGL((attn_decode_cross_f16<false, 2>), gd, dim3(256), 0, s, a);
             else hipLaunchKernelGGL((attn_decode_cross_f16<false, 4>), gd, dim3(256), 0, s, a);

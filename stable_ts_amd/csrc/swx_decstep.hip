@@ -338,9 +338,12 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         const int m = t * 16 + li, mc = m < g.M ? m : g.M - 1;
-        // tile t has landed (and, first time round, the weights; later, the previous tile's stores are out): every wave waits
-        // for its own share, the barrier makes it true for all
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // tile t has landed: every wave waits for its own share of the DMA, the barrier makes it true for all.  vmcnt(1): the one
+        // store instruction of the previous tile's epilogue is younger than this tile's DMA (vector memory operations retire in
+        // issue order on gfx9-class hardware -- what hipcc's own counted waits rely on) and may still be on its way to L2;
+        // waiting for it as well cost a write round trip per tile.  (First tile: hipcc's waits in front of the loop drained
+        // everything, so nothing is outstanding and the count is trivially met.)
+        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         // epilogue operands of this tile, requested before the next tile's DMA so that a counted wait can tell them apart
         f16x4 xres = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
         int posv = 0;

@@ -44,6 +44,8 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_SCORE_TILED 262144   // multi-token decoder passes above 160 rows on the tiled GEMMs + flash attention (round 3's
                                       // dispatch: faster at >= 2 windows, but a window's rounding then depends on its batch) -- A/B only
 #define SWX_FLAG_NO_TALL 524288       // multi-token passes: never the tall dec GEMM (register-resident weights, 16-row tiles): A/B, bit-identical
+#define SWX_FLAG_NO_FUSED_XQ 1048576  // decode step: cross-attention query projection as a launch of its own instead of inside the
+                                      // cross-attention kernel (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
@@ -130,6 +132,12 @@ struct AttnArgs {
     int q_rows_per_batch;            // rows of q per batch item (== nq unless grouped)
     const void *kv_packed;           // decode cross-attention: K and V^T of batch item 0 in MFMA fragment order (swx_xkv_pack),
                                      // batch stride k_bs; null = read a.k / a.v
+    // decode step only (nq <= 16, packed K / V^T): the cross-attention QUERY projection folded into the attention launch --
+    // q = LN(x) Wcq^T + b computed per (window, head) from the raw residual rows with the decode-step GEMM's arithmetic
+    // (packed LayerNorm-folded weights, swx_fold_ln), instead of a launch of its own; a.q is not read then.  fq_w == null: off.
+    const _Float16 *fq_x; int64_t fq_ldx; int fq_rows;      // residual stream [fq_rows][d]; window b owns rows b * q_rows_per_batch ..
+    const _Float16 *fq_w; const float *fq_c1, *fq_c2; int fq_k;   // packed folded weights [d][fq_k], column constants
+    const void *fq_pf; int fq_pf_lines;                     // weights to touch for the NEXT projection (cache prefetch), or null
 };
 // fragment-ordered copy of one layer's cross K / V^T for the decode-step cross-attention: per (window, head)
 // [K: blocks of 32 keys x 4 fragments x 64 lanes x 8 halfs | V^T: the same], zero padded past nk

@@ -411,18 +411,27 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         g.c2 = m->A<float>(w.bo); g.X = x; g.ldx = d;
         g.pf = pf_of(w.wcq_f, d, d, DEC_LN);
         SWX_TRY(swx_gemm_dec(g, s));
-        // cross-attention query = LNx(x) Wcq^T + b
-        g = DecGemmArgs{};
-        g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
-        g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
-        g.pf = pf_of(w.wco_p, d, d, DEC_RES);                // used after the cross-attention (154 MB through the cache)
-        SWX_TRY(swx_gemm_dec(g, s));
+        // cross-attention query = LNx(x) Wcq^T + b: inside the cross-attention launch (AttnArgs::fq_*) unless switched off
+        const bool fuse_xq = !(g_debug_flags & (SWX_FLAG_NO_FUSED_XQ | SWX_FLAG_NO_PACKED_XKV)) && f.rpw <= 16 && d % 128 == 0 &&
+                             (d == 384 || d == 512 || d == 640 || d == 768 || d == 1024 || d == 1280);
+        if (!fuse_xq) {
+            g = DecGemmArgs{};
+            g.M = rows; g.A = x; g.lda = d; g.W = m->A<f16>(w.wcq_f); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_LN;
+            g.c1 = m->A<float>(w.cq_c1); g.c2 = m->A<float>(w.cq_c2); g.C = q; g.ldc = d;
+            g.pf = pf_of(w.wco_p, d, d, DEC_RES);                // used after the cross-attention (154 MB through the cache)
+            SWX_TRY(swx_gemm_dec(g, s));
+        }
         const unsigned char *kl = f.xkv + (size_t)l * f.W * chunk * e;
         AttnArgs ca{};
         ca.q = q; ca.ldq = d; ca.k = kl; ca.v = kl + (size_t)D.n_audio_ctx * d * e; ca.ldkv = d;
         ca.k_bs = chunk; ca.v_bs = chunk; ca.vt_kp = SWX_VT_KP; ca.o = att; ca.ldo = d;
         ca.B = f.W; ca.H = H; ca.nq = f.rpw; ca.nk = D.n_audio_ctx; ca.q_rows_per_batch = f.rpw;
         ca.kv_packed = kl + (size_t)xkv_plain_elems(D) * e;          // fragment-ordered copy of this layer's K / V^T
+        if (fuse_xq) {
+            ca.fq_x = x; ca.fq_ldx = d; ca.fq_rows = rows; ca.fq_w = m->A<f16>(w.wcq_f); ca.fq_c1 = m->A<float>(w.cq_c1);
+            ca.fq_c2 = m->A<float>(w.cq_c2); ca.fq_k = d;
+            if (pf_on) { ca.fq_pf = m->A<f16>(w.wco_p); ca.fq_pf_lines = (int)(((int64_t)d * d * 2) >> 7); }
+        }
         SWX_TRY(swx_attention(m->dtype, ca, 0, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = att; g.lda = d; g.W = m->A<f16>(w.wco_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;

@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 DEC_LN, DEC_GELU, DEC_RES, DEC_QKV, DEC_SLAB, TALL = 1, 2, 4, 8, 16, 64
-REPS = 8
+REPS = 16
 
 
 def main() -> int:

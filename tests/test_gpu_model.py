@@ -347,6 +347,34 @@ def test_decode_f16_l2_prefetch_has_no_functional_effect(name, beam, windows):
     assert np.array_equal(np.asarray(on["sum_logprobs"]), np.asarray(off["sum_logprobs"]))
 
 
+@pytest.mark.parametrize("name,beam,windows", [("tiny.en", False, 3), ("base.en", True, 3), ("base.en", True, 11), ("tiny.en", True, 1)])
+def test_decode_f16_fused_cross_query_is_bit_identical(name, beam, windows):
+    # the decode step computes the cross-attention query projection INSIDE the cross-attention launch (AttnArgs::fq_*: the dec
+    # GEMM's statistics, k-step order and epilogue per (window, head)); flag 1048576 runs it as the separate gemm_dec_f16 launch it
+    # replaces.  Tokens, lengths and sums of log-probabilities must be IDENTICAL (1 / 5 rows per window, 1-11 windows).
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 77, B=windows)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=30,
+                                                     beam_size=5 if beam else None))
+    kw = dict(n_group=task.n_group, beam=beam, sample_len=30, sot_index=task.sot_index, min_tokens=30,
+              **_tok_cfg(task.tokenizer, task))
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    old = lib.swx_debug_flags(-1)
+    try:
+        assert not (old & 1048576)
+        on = eng.decode(xkv, [list(task.initial_tokens)] * windows, **kw)
+        lib.swx_debug_flags(old | 1048576)
+        off = eng.decode(xkv, [list(task.initial_tokens)] * windows, **kw)
+    finally:
+        lib.swx_debug_flags(old)
+    assert np.array_equal(np.asarray(on["lens"]), np.asarray(off["lens"]))
+    assert np.array_equal(np.asarray(on["tokens"]), np.asarray(off["tokens"]))
+    assert np.array_equal(np.asarray(on["sum_logprobs"]), np.asarray(off["sum_logprobs"]))
+    assert np.array_equal(np.asarray(on["no_speech_prob"]), np.asarray(off["no_speech_prob"]))
+
+
 @pytest.mark.parametrize("name,mode", [("tiny.en", "greedy"), ("tiny.en", "beam"), ("base.en", "sample"), ("base.en", "beam_masks"),
                                        ("tiny.en", "greedy_free")])
 def test_decode_select_register_kernel_is_bit_identical(name, mode):
