@@ -664,6 +664,7 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
 // shuffles).  Arithmetic order is self_attn_cached's, so both paths agree bit for bit.
 // HBM traffic: K and V of every cached position of every row once = R * (pos + 1) * d * 2 * 2 bytes per launch (57 MB at
 // position 111 for 100 rows of large-v3: at the end of a window's decode this kernel is bandwidth-, not latency-bound).
+template <bool LONG>
 __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
 {
     constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
@@ -726,19 +727,46 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
         const float sc = dot_regs(k1) * 0.125f;
         ps[j1] = sc; mx = fmaxf(mx, sc);
     }
-    for (int j = lane + 128; j <= pos; j += 64) {
-        const int pr = (anc && j < pos) ? anc[j] : r;
-        const f16 *kr = kc + ((size_t)pr * a.n_ctx + j) * d + h * DH;
-        float acc = 0.f;
-#pragma unroll 2
-        for (int d0 = 0; d0 < DH; d0 += 8) {
-            float kv[8];
-            load8<f16>(kr + d0, kv);
+    // positions >= 128 (a decode that started from a long prompt: sequential transcribe() carries up to 223 tokens over).  The
+    // plain loop here was two dependent round trips per 64 positions (ancestor id -> K row); now the ancestor ids of every
+    // remaining chunk are requested in one batch and then all K rows in one batch.  Per key the dot product is the same
+    // expression, so the scores are bit-identical (the maximum is order-independent).
+    if (LONG && pos >= 128) {
+        constexpr int KT = 6;                               // 128 + 5 * 64 = 448 = n_text_ctx (six slots: three pairs)
+        int prt[KT];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf(qs[d0 + e], kv[e], acc);
+        for (int c = 0; c < KT; ++c) {
+            const int j = lane + 128 + 64 * c;
+            const bool old = anc && j < pos;
+            const int t = ap[old ? j : 0];
+            prt[c] = old ? t : r;
         }
-        acc *= 0.125f;
-        ps[j] = acc; mx = fmaxf(mx, acc);
+#pragma unroll
+        for (int c2 = 0; c2 < KT; c2 += 2) {                // two chunks of K rows in flight at a time (64 registers, like k0 / k1)
+            if (128 + 64 * c2 <= pos) {                     // uniform
+                f16x8 kt[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = c2 + u;
+                    if (128 + 64 * c <= pos) {              // uniform: the chunk holds a cached position
+                        const int j = lane + 128 + 64 * c;
+                        const bool has = j <= pos;
+                        const f16 *kr = kc + ((size_t)(has ? prt[c] : r) * a.n_ctx + (has ? j : 0)) * d + h * DH;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) kt[u][e] = *(const f16x8 *)(kr + 8 * e);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int c = c2 + u;
+                    const int j = lane + 128 + 64 * c;
+                    if (128 + 64 * c <= pos && j <= pos) {
+                        const float sc = dot_regs(kt[u]) * 0.125f;
+                        ps[j] = sc; mx = fmaxf(mx, sc);
+                    }
+                }
+            }
+        }
     }
     mx = wave_max(mx);
     float sum = 0.f;
@@ -759,13 +787,33 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
             for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vpre[i][e], acc[e]);
         }
     }
-    for (int j = kg + 8 * PF; j <= pos; j += 8) {
-        float vv[8];
-        const int pr = (anc && j < pos) ? anc[j] : r;
-        load8<f16>(vc + ((size_t)pr * a.n_ctx + j) * d + h * DH + dc, vv);
-        const float pj = ps[j] * inv;
+    // keys >= 128: batches of 8 keys per lane group -- ancestor ids in one batch, V fragments in one batch, then the
+    // multiply-adds in ascending key order exactly as the one-key-at-a-time loop did them (bit-identical)
+    for (int jb = kg + 8 * PF; LONG && jb <= pos; jb += 64) {
+        int prv[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, vv[e], acc[e]);
+        for (int u = 0; u < 8; ++u) {
+            const int j = jb + 8 * u;
+            const bool old = anc && j < pos;
+            const int t = ap[old ? j : 0];
+            prv[u] = old ? t : r;
+        }
+        f16x8 vb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = jb + 8 * u;
+            const bool ok = j <= pos;
+            vb[u] = *(const f16x8 *)(vc + ((size_t)(ok ? prv[u] : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = jb + 8 * u;
+            if (j <= pos) {
+                const float pj = ps[j] * inv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vb[u][e], acc[e]);
+            }
+        }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -971,7 +1019,10 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
     SwxProfScope prof(PC_SELF_ATTN, (double)a.R * a.n_new * a.d * (dtype == SWX_F16 ? 2 : 4) * (2.0 * npos + 2.0), s);
     if (a.step_cached) {       // single-token step, q in a.qkv, the new K / V already in the cache
         if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.skip_append) return -5;
-        hipLaunchKernelGGL(self_attn_step_f16, dim3(a.H, a.R), dim3(64), 0, s, a);
+        // (a decode whose positions stay below 128 -- no prompt carried over -- takes the variant without the long-context code:
+        // 157 instead of 211 registers, three waves per SIMD)
+        if (a.pos_bound > 0 && a.pos_bound <= 128) hipLaunchKernelGGL(self_attn_step_f16<false>, dim3(a.H, a.R), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(self_attn_step_f16<true>, dim3(a.H, a.R), dim3(64), 0, s, a);
         SWX_CHECK_LAUNCH();
         return 0;
     }

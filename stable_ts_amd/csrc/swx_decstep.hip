@@ -267,8 +267,8 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 // The same projection for MANY rows (a multi-token pass over a whole batch: the scoring pass of 20 windows is 2 260 rows, a
 // prefill with prompts several thousand).  The kernel above gives every 48 rows x 64 columns their own workgroup, which then
 // re-reads its 160 KB of weights and waits out one DMA round trip for 0.3 us of MFMAs; here a workgroup keeps its four waves'
-// weight fragments in REGISTERS and walks a run of 16-row tiles through two LDS buffers: the LDS-DMA of tile t + 1 (issued
-// from inline asm, so that hipcc neither sees it nor drains it) flies under the statistics, MFMAs and epilogue of tile t.
+// weight fragments in REGISTERS and walks a run of 16-row tiles through three LDS buffers: the LDS-DMAs of tiles t + 1 and
+// t + 2 (issued from inline asm, so that hipcc neither sees nor drains them) fly under the statistics, MFMAs and epilogue of tile t.
 // Per output element the arithmetic is the kernel's above, instruction for instruction -- the LayerNorm statistics from the
 // same 16-lanes-per-row dot products, the k-steps in the same order into one accumulator, the same epilogue expressions --
 // so a row's result does not depend on which of the two kernels, or how many rows, the launch had
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
     constexpr int kslice = NKS * 32, SPR = kslice >> 3, RS = kslice * 2, TILE = 16 * RS;
     constexpr int DMA_PER_WAVE = NKS / 4;          // 16 rows x SPR slots / 64 lanes = NKS instructions per tile, dealt over 4 waves
     static_assert(NKS % 4 == 0, "tile = whole DMA instructions per wave");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // 2 x [16][kslice] f16 | float2 stat[2][16]
+    constexpr int NBUF = 3;                        // tile t computes while tiles t + 1 and t + 2 are on their way
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // NBUF x [16][kslice] f16 | float2 stat[NBUF][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int li = lane & 15, lg = lane >> 4;
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
         }
     };
     stage(t_begin, 0);
+    stage(t_begin + 1 < t_end ? t_begin + 1 : t_begin, 1);
     // this wave's 16 columns of weights, resident for the whole run of tiles
     const f16 *wp = g.W + ((size_t)(panel * 4 + wave) * (g.K >> 5) + (size_t)ks_id * NKS) * 512 + lane * 8;
     f16x8 wf[NKS];
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
     f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (!E_SLAB) c2 = *(const f32x4 *)(g.c2 + nc);
     if constexpr (E_LN) c1 = *(const f32x4 *)(g.c1 + nc);
-    float2 *stat = (float2 *)(smem + 2 * TILE);
+    float2 *stat = (float2 *)(smem + NBUF * TILE);
     const int rps = g.rps > 1 ? g.rps : 1;
     // hipcc's waits for the loads it can see (weights, column constants) belong in FRONT of the loop: a wait placed at their first
     // use inside the body would run every iteration and drain the next tile's DMA with it
@@ -336,14 +338,14 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
     asm volatile("" : "+v"(c1), "+v"(c2));
 
     for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
+        const int buf = (t - t_begin) % NBUF;
         const int m = t * 16 + li, mc = m < g.M ? m : g.M - 1;
-        // tile t has landed: every wave waits for its own share of the DMA, the barrier makes it true for all.  vmcnt(1): the one
-        // store instruction of the previous tile's epilogue is younger than this tile's DMA (vector memory operations retire in
-        // issue order on gfx9-class hardware -- what hipcc's own counted waits rely on) and may still be on its way to L2;
-        // waiting for it as well cost a write round trip per tile.  (First tile: hipcc's waits in front of the loop drained
-        // everything, so nothing is outstanding and the count is trivially met.)
-        asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // tile t has landed: every wave waits for its own share of the DMA, the barrier makes it true for all.  Younger than tile
+        // t's DMA in this wave's queue, and allowed to be still in flight: the previous-but-one tile's store, tile t + 1's DMA, the
+        // previous tile's store (vector memory operations retire in issue order on gfx9-class hardware -- what hipcc's own
+        // counted waits rely on); the previous tile's operand loads were waited for already.  (First tile: hipcc's waits in
+        // front of the loop drained everything, so the count is trivially met.)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(DMA_PER_WAVE + 2) : "memory");
         // epilogue operands of this tile, requested before the next tile's DMA so that a counted wait can tell them apart
         f16x4 xres = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
         int posv = 0;
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
             const int seq = mc / rps, crow = seq * (g.row_mul > 1 ? g.row_mul : 1);
             asm volatile("global_load_dword %0, %1, off" : "=v"(posv) : "v"(g.pos0 + crow) : "memory");
         }
-        stage(t + 1 < t_end ? t + 1 : t, buf ^ 1);       // (the last tile re-stages itself into the idle buffer: never predicated)
+        stage(t + 2 < t_end ? t + 2 : t_end - 1, (t - t_begin + 2) % NBUF);    // (past the end: the last tile again, into the buffer
+                                                                               //  tile t - 1 has left: never predicated, never read)
         const unsigned char *tile = smem + buf * TILE;
         if constexpr (E_LN) {
             const f16x2 one2 = {(f16)1.f, (f16)1.f};
@@ -546,7 +549,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
         g.tps = cdiv(n_tiles, rs);
         g.n_rg = cdiv(n_tiles, g.tps);
         const int grid = cdiv(units, 8) * g.n_rg * 8;
-        const size_t lds = (size_t)2 * 16 * g.kslice * 2 + 2 * 16 * sizeof(float2);
+        const size_t lds = (size_t)3 * 16 * g.kslice * 2 + 3 * 16 * sizeof(float2);
         SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
 #define SWX_TALL(NK_, EP_) do { \
         static bool attr_done = false; \

@@ -162,6 +162,8 @@ struct SelfAttnArgs {
     int step_cached;                 // n_new == 1, f16: q at a.qkv (row stride ldqkv), the new K/V already appended -> the
                                      // latency-optimised single-token kernel of the decode step
     int step_pos;                    // profiler only: position of the new token when the host knows it (decode loop), else 0
+    int pos_bound;                   // decode step: an upper bound of every row's position known to the host (initial tokens + sample
+                                     // budget), or 0 = unknown.  <= 128: the kernel variant without the code for positions >= 128
 };
 // logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);

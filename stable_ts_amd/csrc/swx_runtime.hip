@@ -357,6 +357,7 @@ struct FwdCfg {
     const unsigned char *xkv;
     bool capture; int cap_row0, cap_rows, cap_ld_n;
     int step_pos;          // decode step: position of the new token when the host knows it (profiler's byte count), else 0
+    int pos_bound;         // decode step: upper bound of every row's position (initial tokens + sample budget), 0 = unknown
     unsigned char *qcap;   // non-null: the cross-attention queries of every layer are copied here, [L][rows][d] (swx_score_q)
 };
 
@@ -403,7 +404,7 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         SelfAttnArgs sa{};
         sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1; sa.step_cached = 1;
-        sa.step_pos = f.step_pos;
+        sa.step_pos = f.step_pos; sa.pos_bound = f.pos_bound;
         SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
         // x += att Wo^T + bo
         g = DecGemmArgs{};
@@ -1168,6 +1169,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
         // profiler's byte count only (steps = tokens sampled so far).  Never a captured kernel argument: a replayed graph would
         // carry the position of the step it was captured at (the profiler is off under replay, and 0 = "unknown" there)
         g.step_pos = capturing ? 0 : n_init + steps;
+        g.pos_bound = n_init + cfg->sample_len;        // (a property of the job, not of the step: safe to bake into the graph)
         const int fr = decoder_forward(m, g, st);
         if (fr < 0) return fr;
         unsigned char *hh = m->ws + m->L.h;
@@ -1526,6 +1528,17 @@ int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float
         g.W = wf; g.c2 = d_bias;
     }
     return swx_gemm_dec(g, s);
+}
+
+int swx_test_self_attn_step(const void *d_q, void *d_kcache, void *d_vcache, const int32_t *d_anc, const int32_t *d_pos0,
+                            int R, int H, int n_ctx, int d, int variant, void *d_o, void *stream)
+{
+    SelfAttnArgs sa{};
+    sa.qkv = d_q; sa.ldqkv = d; sa.kcache = d_kcache; sa.vcache = d_vcache; sa.anc = (int32_t *)d_anc; sa.pos0 = d_pos0;
+    sa.o = d_o; sa.ldo = d; sa.R = R; sa.n_new = 1; sa.H = H; sa.n_ctx = n_ctx; sa.d = d; sa.skip_append = 1;
+    sa.step_cached = variant < 2 ? 1 : 0;
+    sa.pos_bound = variant == 0 ? 128 : 0;
+    return swx_self_attention(SWX_F16, sa, 1, S(stream));
 }
 
 int swx_test_layernorm(int dtype, const void *d_x, const float *d_g, const float *d_b, void *d_y, int rows, int d, void *stream)
