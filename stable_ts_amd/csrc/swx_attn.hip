@@ -338,9 +338,18 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
         f16 *qt = (f16 *)(fq_smem + 16 * RS + 16 * sizeof(float2));
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned char *abase = fq_smem + (size_t)li * RS;
+        {
+            constexpr int PF = 8;                           // fragment reads eight k-steps ahead of their MFMA (one MFMA per step)
+            f16x8 af[PF];
 #pragma unroll
-        for (int ks = 0; ks < FQ; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], *(const f16x8 *)(abase + (((ks * 4 + lg) ^ li) << 4)), acc, 0, 0, 0);
+            for (int ks = 0; ks < PF; ++ks) af[ks] = *(const f16x8 *)(abase + (((ks * 4 + lg) ^ li) << 4));
+#pragma unroll
+            for (int ks = 0; ks < FQ; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[ks % PF], acc, 0, 0, 0);
+                if (ks + PF < FQ) af[ks % PF] = *(const f16x8 *)(abase + ((((ks + PF) * 4 + lg) ^ li) << 4));
+                __builtin_amdgcn_sched_barrier(0);          // (the scheduler sinks each read back in front of its MFMA otherwise)
+            }
+        }
         // (the statistics after the MFMAs: their row registers do not have to live next to the 40 weight fragments)
         {
             const f16x2 one2 = {(f16)1.f, (f16)1.f};

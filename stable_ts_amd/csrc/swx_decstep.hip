@@ -188,8 +188,8 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned char *abase = smem + (size_t)li * RS;
-    constexpr int PF = 4;
-    f16x8 af[PF][MT];
+    constexpr int PF = MT == 1 ? 8 : 4;        // k-steps of fragment reads in flight: with one row tile a step is ONE MFMA (16 cycles),
+    f16x8 af[PF][MT];                          // four steps ahead do not cover an LDS round trip, eight do
     auto lds_frag = [&](int ks, int t) {
         const int phys = (ks * 4 + lg) ^ li;
         return *(const f16x8 *)(abase + (size_t)t * 16 * RS + phys * 16);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
         }
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned char *abase = tile + (size_t)li * RS;
-        constexpr int PF = 4;
+        constexpr int PF = 8;                     // one MFMA per k-step here (16 cycles): eight fragment reads ahead cover the LDS latency
         f16x8 af[PF];
 #pragma unroll
         for (int ks = 0; ks < PF; ++ks) af[ks] = *(const f16x8 *)(abase + (((ks * 4 + lg) ^ li) << 4));
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
         for (int ks = 0; ks < NKS; ++ks) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks], af[ks % PF], acc, 0, 0, 0);
             if (ks + PF < NKS) af[ks % PF] = *(const f16x8 *)(abase + ((((ks + PF) * 4 + lg) ^ li) << 4));
-        }
+            __builtin_amdgcn_sched_barrier(0);    // keeps the reads PF steps ahead (the scheduler sinks each one back in front of
+        }                                         // its MFMA otherwise: read -> wait -> mfma, 40 exposed LDS latencies per tile)
         if constexpr (E_LN) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // stat[] visible to every wave
         // the operand loads are older than the next tile's DMA: they have landed once only the DMA is pending
         if constexpr ((E_RES && !E_SLAB) || E_QKV)
