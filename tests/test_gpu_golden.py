@@ -280,8 +280,8 @@ def test_pending_device_paths_in_subprocess(inner):
 def test_refine_end_to_end_matches_reference(name):
     # model.refine() on the device (mute-and-probe bisection of refiner.py around the seam-B3 callable) against the reference's
     # refine() run on the CPU oracle (tests/golden/make_refine_e2e_golden.py), starting from the reference's own align() result.
-    # Every probe decision compares probabilities of ~1e-5 against relative thresholds, so a word may stop one precision step
-    # earlier or later than on the CPU: >= 90 % of the words within 20 ms, none further off than two precision steps.
+    # Observed on hardware for all four option sets (profiles/r04_refine_e2e_report.json): 30 of 30 words identical in time
+    # (maximum deviation 0.0 s, the same number of words moved as in the reference) -- asserted: EVERY word within 20 ms.
     from stable_ts_amd.result import WhisperResult
     with open(os.path.join(HERE, "golden", "reference_refine_e2e.json")) as f:
         g = json.load(f)
@@ -299,7 +299,17 @@ def test_refine_end_to_end_matches_reference(name):
     close = sum(d <= 0.02 + 1e-9 for d in dev)
     moved_ref = sum(abs(a["start"] - b["start"]) > 1e-9 or abs(a["end"] - b["end"]) > 1e-9 for a, b in zip(g["before"], want["words"]))
     moved_got = sum(abs(a["start"] - b.start) > 1e-9 or abs(a["end"] - b.end) > 1e-9 for a, b in zip(g["before"], got))
-    assert close >= 0.9 * len(dev) and max(dev) <= 2 * prec + 0.02, (close, len(dev), max(dev), moved_ref, moved_got)
+    rep_path = os.path.join(os.path.dirname(HERE), "gpurun_out", "refine_e2e_report.json")
+    try:
+        os.makedirs(os.path.dirname(rep_path), exist_ok=True)
+        rep = json.load(open(rep_path)) if os.path.exists(rep_path) else {}
+        rep[name] = dict(words=len(dev), within_20ms=close, max_dev=max(dev), precision=prec, moved_ref=moved_ref, moved_got=moved_got,
+                         off=[round(d, 3) for d in dev if d > 0.02 + 1e-9])
+        json.dump(rep, open(rep_path, "w"), indent=1)
+    except OSError:
+        pass
+    assert close == len(dev) and max(dev) <= 0.02 + 1e-9, (close, len(dev), max(dev), moved_ref, moved_got)
+    assert moved_got == moved_ref, (moved_got, moved_ref)
     if moved_ref == 0:
         assert moved_got == 0
 
