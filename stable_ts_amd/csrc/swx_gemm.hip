@@ -646,74 +646,107 @@ __global__ __launch_bounds__(512) void gemm_f16_big(GemmArgs g)
 // ------------------------------------------------------------------------------------------------ tiled f32
 constexpr int BK32 = 16, LD32 = BK32 + 1;
 
+// BNT = tile width (128; 32 for launches with few rows, where 128-wide tiles leave N / 128 = 10-40 workgroups on 256 CUs), ST = K
+// steps of operands held in REGISTERS ahead of the one being multiplied.  Round 4: with ST = 2 (one step ahead) every 16-deep K
+// step waited out a global round trip -- 2.6 us per step, 210 us for a K = 1280 launch at 100 rows: the decode-step projections of
+// the strict-f32 mode, 3.9 s of its 5.8-s pass.  Operands now travel ST - 1 steps ahead.  Per output element the arithmetic is
+// unchanged in every variant (one accumulator, K ascending in steps of 4), so all variants are bit-identical.
+template <int BNT, int ST>
 __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
 {
+    constexpr int WROWS = BNT == 128 ? 64 : 32, WCOLS = BNT == 128 ? 64 : 32;      // a wave's share of the 128 x BNT tile
+    constexpr int NI = WROWS / 16, NJ = WCOLS / 16;
+    constexpr int NB = (BNT * 4 + 255) / 256;                                        // float4 loads of the B tile per thread
     __shared__ float As[2][BM][LD32];
-    __shared__ float Bs[2][BN][LD32];
+    __shared__ float Bs[2][BNT][LD32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int wm = BNT == 128 ? wave >> 1 : wave, wn = BNT == 128 ? wave & 1 : 0;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BNT;
     const float *A = (const float *)g.A;
     const float *W = (const float *)g.W;
 
-    f32x4 acc[4][4];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[2], rb[2];
-    auto load_regs = [&](int k0) {
+    f32x4 ra[ST][2], rb[ST][NB];
+    auto load_regs = [&](int st, int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
-            const int gm = m0 + row, gn = n0 + row;
-            ra[i] = (gm < g.M) ? *(const f32x4 *)(A + (size_t)gm * g.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            rb[i] = (gn < g.N) ? *(const f32x4 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int gm = m0 + row;
+            ra[st][i] = (gm < g.M) ? *(const f32x4 *)(A + (size_t)gm * g.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
+            const int gn = n0 + row;
+            rb[st][i] = (row < BNT && gn < g.N) ? *(const f32x4 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int st, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { As[buf][row][kc + e] = ra[i][e]; Bs[buf][row][kc + e] = rb[i][e]; }
+            for (int e = 0; e < 4; ++e) As[buf][row][kc + e] = ra[st][i][e];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
+            if (row < BNT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) Bs[buf][row][kc + e] = rb[st][i][e];
+            }
+        }
+    };
+    auto compute = [&](int cur) {
+        const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float a[NI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) a[i] = As[cur][wm * WROWS + i * 16 + fr][kk * 4 + fk];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = Bs[cur][wn * WCOLS + j * 16 + fr][kk * 4 + fk];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     };
 
     const int KT = g.K / BK32;
-    load_regs(0);
-    store_lds(0);
+    // register stage of K step kt is kt % ST; steps 0 .. ST - 2 are requested up front
+#pragma unroll
+    for (int st = 0; st < ST - 1; ++st) if (st < KT) load_regs(st, st * BK32);
+    store_lds(0, 0);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) load_regs((kt + 1) * BK32);
-        const int fr = lane & 15, fk = lane >> 4;
+    for (int kt0 = 0; kt0 < KT; kt0 += ST) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[cur][wm * 64 + i * 16 + fr][kk * 4 + fk];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[cur][wn * 64 + j * 16 + fr][kk * 4 + fk];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int u = 0; u < ST; ++u) {                       // (unrolled: the register stages are compile-time indices)
+            const int kt = kt0 + u;
+            if (kt < KT) {
+                const int cur = kt & 1;
+                if (kt + ST - 1 < KT) load_regs((u + ST - 1) % ST, (kt + ST - 1) * BK32);
+                compute(cur);
+                if (kt + 1 < KT) store_lds((u + 1) % ST, cur ^ 1);
+                __syncthreads();
+            }
         }
-        if (kt + 1 < KT) store_lds(cur ^ 1);
-        __syncthreads();
     }
 
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                epilogue_store<float>(g, m0 + wm * 64 + i * 16 + row_l + r, n0 + wn * 64 + j * 16 + col_l, acc[i][j][r]);
+                epilogue_store<float>(g, m0 + wm * WROWS + i * 16 + row_l + r, n0 + wn * WCOLS + j * 16 + col_l, acc[i][j][r]);
 }
 
 // ----------------------------------------------------------------------------------------------- skinny f16
@@ -880,8 +913,13 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
     } else {
         if (g.K % 16 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return -4;
         SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
-        dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
-        hipLaunchKernelGGL(gemm_f32_tiled, grid, dim3(256), 0, s, g);
+        // few rows (decode step, prefill, a single window's scoring pass): 32-column tiles give N / 32 workgroups instead of N / 128;
+        // bit-identical either way, so the choice may depend on the launch
+        if (g.M <= BM && g.N >= 256) {
+            hipLaunchKernelGGL((gemm_f32_tiled<32, 4>), dim3(cdiv(g.N, 32), cdiv(g.M, BM)), dim3(256), 0, s, g);
+        } else {
+            hipLaunchKernelGGL((gemm_f32_tiled<128, 4>), dim3(cdiv(g.N, BN), cdiv(g.M, BM)), dim3(256), 0, s, g);
+        }
     }
     SWX_CHECK_LAUNCH();
     return 0;
