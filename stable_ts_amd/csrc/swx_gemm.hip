@@ -646,22 +646,25 @@ __global__ __launch_bounds__(512) void gemm_f16_big(GemmArgs g)
 // ------------------------------------------------------------------------------------------------ tiled f32
 constexpr int BK32 = 16, LD32 = BK32 + 1;
 
-// BNT = tile width (128; 32 for launches with few rows, where 128-wide tiles leave N / 128 = 10-40 workgroups on 256 CUs), ST = K
+// BMT x BNT = tile (128 x 128; 64 x 32 / 64 x 16 for launches with few rows, where 128-wide tiles leave N / 128 = 10-40 workgroups on
+// 256 CUs and one CU's exact-f32 MFMA rate bounds the launch), ST = K
 // steps of operands held in REGISTERS ahead of the one being multiplied.  Round 4: with ST = 2 (one step ahead) every 16-deep K
 // step waited out a global round trip -- 2.6 us per step, 210 us for a K = 1280 launch at 100 rows: the decode-step projections of
 // the strict-f32 mode, 3.9 s of its 5.8-s pass.  Operands now travel ST - 1 steps ahead.  Per output element the arithmetic is
 // unchanged in every variant (one accumulator, K ascending in steps of 4), so all variants are bit-identical.
-template <int BNT, int ST>
+template <int BMT, int BNT, int ST>
 __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
 {
-    constexpr int WROWS = BNT == 128 ? 64 : 32, WCOLS = BNT == 128 ? 64 : 32;      // a wave's share of the 128 x BNT tile
+    constexpr int WN = BNT >= 128 ? 2 : 1, WM = 4 / WN;                             // waves across the tile's columns / rows
+    constexpr int WROWS = BMT / WM, WCOLS = BNT / WN;                                // a wave's share of the BMT x BNT tile
     constexpr int NI = WROWS / 16, NJ = WCOLS / 16;
-    constexpr int NB = (BNT * 4 + 255) / 256;                                        // float4 loads of the B tile per thread
-    __shared__ float As[2][BM][LD32];
+    constexpr int NA = (BMT * 4 + 255) / 256, NB = (BNT * 4 + 255) / 256;            // float4 loads of the A / B tile per thread
+    static_assert(NI >= 1 && NJ >= 1, "a wave owns at least one 16 x 16 fragment");
+    __shared__ float As[2][BMT][LD32];
     __shared__ float Bs[2][BNT][LD32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = BNT == 128 ? wave >> 1 : wave, wn = BNT == 128 ? wave & 1 : 0;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BNT;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+    const int m0 = blockIdx.y * BMT, n0 = blockIdx.x * BNT;
     const float *A = (const float *)g.A;
     const float *W = (const float *)g.W;
 
@@ -671,13 +674,13 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    f32x4 ra[ST][2], rb[ST][NB];
+    f32x4 ra[ST][NA], rb[ST][NB];
     auto load_regs = [&](int st, int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
             const int gm = m0 + row;
-            ra[st][i] = (gm < g.M) ? *(const f32x4 *)(A + (size_t)gm * g.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            ra[st][i] = (row < BMT && gm < g.M) ? *(const f32x4 *)(A + (size_t)gm * g.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -688,10 +691,12 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
     };
     auto store_lds = [&](int st, int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
+            if (row < BMT) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) As[buf][row][kc + e] = ra[st][i][e];
+                for (int e = 0; e < 4; ++e) As[buf][row][kc + e] = ra[st][i][e];
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -913,12 +918,14 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
     } else {
         if (g.K % 16 != 0 || g.lda % 4 != 0 || g.ldw % 4 != 0) return -4;
         SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
-        // few rows (decode step, prefill, a single window's scoring pass): 32-column tiles give N / 32 workgroups instead of N / 128;
-        // bit-identical either way, so the choice may depend on the launch
+        // few rows (decode step, prefill, a single window's scoring pass): 64 x 32 or 64 x 16 tiles spread the launch over
+        // 160-320 workgroups instead of N / 128 = 10-40 (one CU's exact-f32 MFMA rate is 0.6 TFLOP/s); bit-identical either way,
+        // so the choice may depend on the launch
         if (g.M <= BM && g.N >= 256) {
-            hipLaunchKernelGGL((gemm_f32_tiled<32, 4>), dim3(cdiv(g.N, 32), cdiv(g.M, BM)), dim3(256), 0, s, g);
+            if (g.N >= 2560) hipLaunchKernelGGL((gemm_f32_tiled<64, 32, 4>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((gemm_f32_tiled<64, 16, 4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64)), dim3(256), 0, s, g);
         } else {
-            hipLaunchKernelGGL((gemm_f32_tiled<128, 4>), dim3(cdiv(g.N, BN), cdiv(g.M, BM)), dim3(256), 0, s, g);
+            hipLaunchKernelGGL((gemm_f32_tiled<128, 128, 4>), dim3(cdiv(g.N, BN), cdiv(g.M, BM)), dim3(256), 0, s, g);
         }
     }
     SWX_CHECK_LAUNCH();
