@@ -9,12 +9,15 @@
 //   * gemm_f16_glds_128 / _64      the same tile filled by LDS-DMA, one operand buffer, three workgroups per CU overlap each other
 //   * gemm_f16_ring<64|128, 3>     launches with <= 1 workgroup per CU: three LDS stages, LDS-DMA from inline asm, counted waits
 //   * gemm_f16_big                 256x256 tile, 8 waves, two LDS-DMA stages: launches that fill whole rounds of the 256 CUs
+//   * gemm_f16_big8                the same tile on a ring of eight half-tile slots, four phases per K tile, the two row groups of
+//                                  waves half a phase apart (SWX_FLAG_BIG8)
 //   * tiled f32                    the 128x128 tiling on v_mfma_f32_16x16x4_f32 (exact f32 fma chain)     (strict-parity mode)
 //   * skinny f16                   M <= 128 rows: one 16-column weight panel per workgroup, K split over its 4 waves, weights
 //                                  streamed straight from HBM into MFMA fragments (no LDS), LDS reduction
 // Epilogue (f32): +bias, GELU(erf), +f32 residual indexed by row % res_mod (positional embedding), +T residual,
 // store as T or f32.
 #include <cstdlib>
+#include <type_traits>
 #include <array>
 #include <vector>
 #include <cstdio>
@@ -507,6 +510,71 @@ constexpr int BG = 256;                                   // tile edge
 constexpr int BG_STAGE = 2 * BG * 128;                    // bytes per stage: A 256 rows x 64 halfs | B the same
 constexpr int BG_CLD = BG + 4;                            // f32 epilogue row
 
+// Epilogue of the 256 x 256 kernels: four passes of 64 rows through a f32 tile in LDS, 16-byte row-contiguous stores
+// (tile_epilogue_f16's plain path).  acc[i][j] = rows wm * 128 + i * 16 + ..., columns wn * 64 + j * 16 + ... of the tile.
+__device__ __forceinline__ void big_tile_epilogue(const GemmArgs &g, unsigned char *ring, f32x4 (&acc)[8][4], int m0, int n0, int tid,
+                                                  int lane, int wm, int wn)
+{
+    float (*Cs)[BG_CLD] = (float (*)[BG_CLD])ring;
+    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+    const int c8 = (tid & 31) * 8, rb = tid >> 5, gn = n0 + c8;
+    const bool col_ok = gn < g.N, full = gn + 8 <= g.N;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = ((g.epi & EPI_BIAS) && gn + e < g.N) ? g.bias[gn + e] : 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f16x8 rv[4];
+        if (g.epi & EPI_RES) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int gm = m0 + p * 64 + it * 16 + rb;
+                rv[it] = (gm < g.M && full) ? *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn) : (f16x8)(f16)0;
+            }
+        }
+        if (wm == (p >> 1)) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Cs[ii * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[(p & 1) * 4 + ii][j][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 16 + rb, gm = m0 + p * 64 + row;
+            if (gm >= g.M || !col_ok) continue;
+            const f32x4 lo = *(const f32x4 *)&Cs[row][c8], hi = *(const f32x4 *)&Cs[row][c8 + 4];
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[e];
+            if (g.epi & EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+            }
+            f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
+            if (full) {
+                if (g.epi & EPI_RES) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[it][e];
+                }
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+                *(f16x8 *)cp = o;
+            } else {
+                for (int e = 0; e < 8 && gn + e < g.N; ++e) {
+                    float t = v[e];
+                    if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
+                    cp[e] = (f16)t;
+                }
+            }
+        }
+        if (p < 3) __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(512) void gemm_f16_big(GemmArgs g)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];     // 2 stages = 128 KB; the epilogue's 64 x 260 f32 after
@@ -582,65 +650,187 @@ __global__ __launch_bounds__(512) void gemm_f16_big(GemmArgs g)
     }
     __syncthreads();
 
-    // epilogue: four passes of 64 rows through a f32 tile in LDS, 16-byte row-contiguous stores (tile_epilogue_f16's plain path)
-    float (*Cs)[BG_CLD] = (float (*)[BG_CLD])ring;
-    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
-    const int c8 = (tid & 31) * 8, rb = tid >> 5, gn = n0 + c8;
-    const bool col_ok = gn < g.N, full = gn + 8 <= g.N;
-    float bv[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = ((g.epi & EPI_BIAS) && gn + e < g.N) ? g.bias[gn + e] : 0.f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        f16x8 rv[4];
-        if (g.epi & EPI_RES) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int gm = m0 + p * 64 + it * 16 + rb;
-                rv[it] = (gm < g.M && full) ? *(const f16x8 *)((const f16 *)g.R + (size_t)gm * g.ldr + gn) : (f16x8)(f16)0;
-            }
-        }
-        if (wm == (p >> 1)) {
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Cs[ii * 16 + row_l + r][wn * 64 + j * 16 + col_l] = acc[(p & 1) * 4 + ii][j][r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 16 + rb, gm = m0 + p * 64 + row;
-            if (gm >= g.M || !col_ok) continue;
-            const f32x4 lo = *(const f32x4 *)&Cs[row][c8], hi = *(const f32x4 *)&Cs[row][c8 + 4];
-            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += bv[e];
-            if (g.epi & EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-            }
-            f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
-            if (full) {
-                if (g.epi & EPI_RES) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[it][e];
-                }
-                f16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-                *(f16x8 *)cp = o;
-            } else {
-                for (int e = 0; e < 8 && gn + e < g.N; ++e) {
-                    float t = v[e];
-                    if (g.epi & EPI_RES) t += (float)((const f16 *)g.R)[(size_t)gm * g.ldr + gn + e];
-                    cp[e] = (f16)t;
-                }
-            }
-        }
-        if (p < 3) __syncthreads();
+    big_tile_epilogue(g, ring, acc, m0, n0, tid, lane, wm, wn);
+}
+
+// ------------------------------------------------------ tiled f16, 256 x 256 tile, 8 waves, half-tile ring, staggered wave groups
+// gemm_f16_big leaves the MFMA pipe idle twice per K step: its one LDS-DMA stage in flight is issued at the start of the step
+// whose MFMAs (2 048 clocks for 64 KB) are shorter than a loaded fabric round trip, and its eight waves read fragments and
+// multiply in lockstep (1 536 clocks of LDS reads per step that no MFMA covers).  This kernel keeps the tile, the swizzle, the
+// wave -> accumulator map and the MFMA order per accumulator (bit-identical results) and changes the schedule
+// (cdna_hip_programming.md, "The 256^2 8-phase template"):
+//  * the two 64 KB operand buffers are eight HALF-TILE slots (A0 A1 B0 B1 of an even and an odd K tile).  Half h of A = the 64
+//    rows each row group of waves multiplies in its phases with that half (tile rows wm * 128 + h * 64 + ..), half h of B = the
+//    32 columns of each column group (wn * 64 + h * 32 + ..): a phase needs whole halves, and a slot is refilled as soon as its
+//    last fragment read has retired.  Loads are issued in consumption order S_k = A0 B0 B1 A1 of tile k / 4; phase P issues
+//    S_(P+7), so four to five half-tiles (64 - 80 KB per CU) are in flight at any time instead of 0 - 64 KB;
+//  * a K tile is four phases = the four quadrants of a wave's 8 x 4 accumulators, (A0,B0) (A0,B1) (A1,B1) (A1,B0): 12 / 4 / 8 / 0
+//    fragment reads (B0 stays in registers) for 16 MFMAs each.  Phase P of a wave:
+//        R_P  fragment reads            W_P  s_waitcnt vmcnt(8): the halves phase P + 1 reads have landed (this wave's part)
+//        X_P  barrier                   s_waitcnt lgkmcnt(0)     I_P  issue S_(P+7)          M_P  16 MFMAs          Y_P  barrier
+//  * the row groups wm = 0 / 1 (the two waves of every SIMD) run half a phase apart: group 1 passes one extra barrier before
+//    its first phase, so its R / W section runs under group 0's MFMAs and the other way round.
+// Ordering, by construction (nothing here is "seen to work"): RAW -- a half read in R_(P+1) was retired by EVERY wave's W_P
+// before that wave's X_P; a reader passes its Y_P first, which completes only after all waves of the other group called X_P
+// (group 0 reads) or X_(P+1) (group 1 reads).  WAR -- I_P rewrites the slot of S_(P-1), whose last fragment reads are in
+// R_(P-1) or earlier (A0: R_(P-1); B0, B1, A1: R_(P-2)); every wave retires its reads (lgkmcnt(0)) before its M of the same
+// phase, i.e. before its Y_(P-1), and I_P follows X_P, which completes after the other group called Y_(P-1) (group 0 issues) or
+// Y_P (group 1 issues).  The last tile's waits count what is really in flight (4, 2, 0).  K >= 128.
+constexpr int B8_HALF = 128 * 128;                        // bytes per half-tile: 128 rows x 64 halfs
+constexpr int B8_BUF = 4 * B8_HALF;                       // A0 | A1 | B0 | B1 of one K tile
+
+template <int N>
+__device__ __forceinline__ void b8_wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void b8_barrier()
+{
+    asm volatile("s_barrier" ::: "memory");
+}
+__device__ __forceinline__ void b8_wait_lds()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void gemm_f16_big8(GemmArgs g)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];     // 2 x 4 half-tiles = 128 KB; the epilogue's f32 tile after
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wm_u = wave_u >> 2;
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+        bx = wg % gx; by = wg / gx;
     }
+    const int m0 = by * BG, n0 = bx * BG;
+    const f16 *A = (const f16 *)g.A;
+    const f16 *W = (const f16 *)g.W;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // a wave stages two 8-row chunks of a half-tile (local rows lr = (wave * 2 + c) * 8 + lane / 8; rows past M / N clamped)
+    const f16 *sA[2][2], *sB[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int lr = (wave * 2 + c) * 8 + (lane >> 3);
+            const int slot = (lane & 7) ^ ((lr >> 1) & 7);
+            const int ra = (lr >> 6) * 128 + h * 64 + (lr & 63);
+            const int rb = (lr >> 5) * 64 + h * 32 + (lr & 31);
+            const int gm = m0 + ra < g.M ? m0 + ra : g.M - 1;
+            const int gn = n0 + rb < g.N ? n0 + rb : g.N - 1;
+            sA[h][c] = A + (size_t)gm * g.lda + slot * 8;
+            sB[h][c] = W + (size_t)gn * g.ldw + slot * 8;
+        }
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned ring0 = (unsigned)(uintptr_t)(lds_void *)ring;
+    // half-tile `which` (0 A0, 1 B0, 2 B1, 3 A1: the consumption order) of K tile kt into its slot
+    auto issue = [&](int kt, auto which_c) {
+        constexpr int which = decltype(which_c)::value;
+        constexpr bool isA = which == 0 || which == 3;
+        constexpr int h = which >= 2 ? 1 : 0;
+        constexpr int off = (isA ? 0 : 2 * B8_HALF) + h * B8_HALF;
+        const unsigned dst = ring0 + (kt & 1) * B8_BUF + off + wave_u * 2048;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) glds16_asm((isA ? sA[h][c] : sB[h][c]) + kt * 64, dst + c * 1024);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    const int KT = g.K / 64;                              // the launcher guarantees KT >= 2
+    const int fr = lane & 15, fs = lane >> 4;
+    f16x8 fa[4][2], fb0[2][2], fb1[2][2];                 // [fragment][kk]: the current A half, B0, B1
+    auto read_a = [&](int buf, int h) {
+        const unsigned char *t = ring + buf * B8_BUF + h * B8_HALF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int lr = wm * 64 + i * 16 + fr;
+                fa[i][kk] = *(const f16x8 *)(t + lr * 128 + (((kk * 4 + fs) ^ ((lr >> 1) & 7)) << 4));
+            }
+    };
+    auto read_b = [&](int buf, int h, f16x8 (&fb)[2][2]) {
+        const unsigned char *t = ring + buf * B8_BUF + 2 * B8_HALF + h * B8_HALF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int lr = wn * 32 + j * 16 + fr;
+                fb[j][kk] = *(const f16x8 *)(t + lr * 128 + (((kk * 4 + fs) ^ ((lr >> 1) & 7)) << 4));
+            }
+    };
+    // 16 MFMAs of quadrant (ih, jh); per accumulator kk = 0 then 1, K tiles ascending: gemm_f16_big's order
+    auto quad = [&](auto ih_c, auto jh_c, const f16x8 (&fb)[2][2]) {
+        constexpr int ih = decltype(ih_c)::value, jh = decltype(jh_c)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[ih * 4 + i][jh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][kk], fb[j][kk], acc[ih * 4 + i][jh * 2 + j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // MODE 0: a tile with at least two tiles after it; 1: the second-last tile; 2: the last tile
+    auto tile = [&](auto mode_c, int t) {
+        constexpr int MODE = decltype(mode_c)::value;
+        const int buf = t & 1;
+        // phase 1: (A0, B0)
+        read_a(buf, 0);
+        read_b(buf, 0, fb0);
+        b8_wait_vm<MODE == 2 ? 2 : 8>();                  // B1 of this tile
+        b8_barrier();
+        b8_wait_lds();
+        if (MODE < 2) issue(t + 1, I3());                 // A1 of tile t + 1 (slot last read in phase 3 of tile t - 1)
+        quad(I0(), I0(), fb0);
+        b8_barrier();
+        // phase 2: (A0, B1)
+        read_b(buf, 1, fb1);
+        b8_wait_vm<MODE == 2 ? 0 : 8>();                  // A1 of this tile
+        b8_barrier();
+        b8_wait_lds();
+        if (MODE == 0) issue(t + 2, I0());                // A0 of tile t + 2 (slot last read in phase 1 of this tile)
+        quad(I0(), I1(), fb1);
+        b8_barrier();
+        // phase 3: (A1, B1)
+        read_a(buf, 1);
+        b8_barrier();
+        b8_wait_lds();
+        if (MODE == 0) issue(t + 2, I1());                // B0 of tile t + 2 (slot last read in phase 1 of this tile)
+        quad(I1(), I1(), fb1);
+        b8_barrier();
+        // phase 4: (A1, B0)
+        if (MODE == 0) b8_wait_vm<8>();                   // A0, B0 of tile t + 1
+        if (MODE == 1) b8_wait_vm<4>();
+        b8_barrier();
+        if (MODE == 0) issue(t + 2, I2());                // B1 of tile t + 2 (slot last read in phase 2 of this tile)
+        quad(I1(), I0(), fb0);
+        b8_barrier();
+    };
+
+    issue(0, I0()); issue(0, I1()); issue(0, I2()); issue(0, I3());
+    issue(1, I0()); issue(1, I1()); issue(1, I2());
+    b8_wait_vm<10>();                                     // A0, B0 of tile 0
+    b8_barrier();
+    if (wm_u == 1) b8_barrier();                          // row group 1 runs half a phase behind
+    int t = 0;
+    for (; t < KT - 2; ++t) tile(I0(), t);
+    tile(I1(), t);
+    tile(I2(), t + 1);
+    if (wm_u == 0) b8_barrier();                          // pairs with row group 1's last barrier: every wave is done with the ring
+    big_tile_epilogue(g, ring, acc, m0, n0, tid, lane, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------ tiled f32
@@ -842,7 +1032,8 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
 // Which f16 kernel a launch gets.  One pure function (no device state) so that the rule is testable without a GPU
 // (tests/test_gemm_plan_cpu.py restates the benchmarked shapes) and is what swx_gemm executes.  `ptr16` = A, W (and C / R for
 // the big kernel's vector epilogue) are 16-byte aligned; `force_kernel`: 0 dispatch, 1 register-staged, 2 skinny, 7 direct-to-LDS
-// with occupancy overlap (8 / 9: its 64-column tiles always / never), 10 / 11 ring at 64 / 128 columns, 12 the 256 x 256 kernel.
+// with occupancy overlap (8 / 9: its 64-column tiles always / never), 10 / 11 ring at 64 / 128 columns, 12 the 256 x 256 kernel,
+// 13 its half-tile-ring generation (gemm_f16_big8; SWX_FLAG_BIG8 puts it wherever the dispatch takes 12).
 int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bool ptr16, int force_kernel, int flags)
 {
     if (K % 32 != 0) return -4;                                            // tiled: K % 32, skinny: K % 128
@@ -862,11 +1053,12 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
     // (profiles/r03_kb_gemm_big.txt)
     const bool big_ok = !(epi & ~(EPI_BIAS | EPI_GELU | EPI_RES)) && ldc % 8 == 0 && (!(epi & EPI_RES) || ldr % 8 == 0);
     if (force_kernel == 12) return big_ok ? SWX_GEMM_BIG : -4;
+    if (force_kernel == 13) return big_ok && K >= 128 ? SWX_GEMM_BIG8 : -4;
     const int64_t t256 = (int64_t)cdiv(M, BG) * cdiv(N, BG);
     const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     if (force_kernel == 0 && big_ok && t256 >= 200 && K >= 512 && (fill >= 0.9 || (fill >= 0.75 && K >= 2560)) &&
         !(flags & SWX_FLAG_NO_BIG_TILE))
-        return SWX_GEMM_BIG;
+        return (flags & SWX_FLAG_BIG8) ? SWX_GEMM_BIG8 : SWX_GEMM_BIG;
     // the ring kernel for launches of at most one workgroup per CU (the encoder / cross-K/V at one window: 64-column tiles when
     // `narrow`, else 128-column ones up to 256 tiles); from ~1.5 workgroups per CU on, gemm_f16_glds -- three resident
     // workgroups, epilogues overlapped with the neighbours' MFMAs -- is as fast or faster (N = 3840 / 5120 at M = 1500: 29.3 /
@@ -908,6 +1100,8 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             switch (plan) {
                 case SWX_GEMM_BIG:
                     hipLaunchKernelGGL(gemm_f16_big, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * BG_STAGE, s, g); break;
+                case SWX_GEMM_BIG8:
+                    hipLaunchKernelGGL(gemm_f16_big8, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * B8_BUF, s, g); break;
                 case SWX_GEMM_RING64: launch_ring<64, 3>(g, s); break;
                 case SWX_GEMM_RING128: launch_ring<128, 3>(g, s); break;
                 case SWX_GEMM_GLDS64: hipLaunchKernelGGL(gemm_f16_glds_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g); break;

@@ -220,7 +220,72 @@ def test_big_tile_gemm_k_loop():
             assert in_asm and "vmcnt(0) lgkmcnt(0)" in ln and "s_barrier" in lines[i + 1], ln
             waits += 1
     assert waits == 1
-    meta = {n: v for n, v in _kernel_meta("swx_gemm.hip").items() if "gemm_f16_big" in n}
+    meta = {n: v for n, v in _kernel_meta("swx_gemm.hip").items() if "gemm_f16_bigE" in n}
+    assert len(meta) == 1
+    for n, v in meta.items():
+        assert v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (n, v)
+
+
+def test_big8_gemm_phases():
+    """gemm_f16_big8 (256 x 256 tile on a ring of eight half-tile slots, csrc/swx_gemm.hip): the compiled ISA must hold the schedule
+    the ordering argument in the source is made for.  Three copies of a K tile (steady, second-last, last), each four phases of
+    [fragment reads -> counted vmcnt -> barrier -> lgkmcnt(0) -> DMA issue -> 16 MFMAs -> barrier] with 12 / 4 / 8 / 0 reads; every
+    `vmcnt` wait is one of the hand-written ones (10 after the prologue's 14 DMA instructions; 8, 8, -, 8 in the steady tile;
+    8, 8, -, 4 and 2, 0, -, - in the last two); the DMA instructions of a phase come AFTER its first barrier (a slot is rewritten
+    only once every wave has retired its reads of it) and its fragment reads BEFORE it; no scratch, <= 256 VGPRs."""
+    text = _device_asm("swx_gemm.hip")
+    m = re.search(r"^(_ZN\S*gemm_f16_big8E[^\s:]*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    assert m
+    lines = [ln.strip() for ln in m.group(2).split("\n")]
+    ev, in_asm = [], False                     # the K loop as a string of events
+    for ln in lines:
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
+        w = re.search(r"s_waitcnt.*vmcnt\((\d+)\)", ln)
+        if w:
+            ev.append(("vm", int(w.group(1)), in_asm))
+        elif ln.startswith("s_barrier"):
+            ev.append(("bar", 0, in_asm))
+        elif ln.startswith("global_load_lds_dwordx4"):
+            ev.append(("dma", 0, in_asm))
+        elif ln.startswith("ds_read_b128"):
+            ev.append(("rd", 0, in_asm))
+        elif ln.startswith("v_mfma_f32_16x16x32_f16"):
+            ev.append(("mfma", 0, in_asm))
+        elif ln.startswith(("global_load_", "global_store_", "ds_write")) :
+            ev.append(("epi", 0, in_asm))
+    first_epi = next(i for i, e in enumerate(ev) if e[0] == "epi")
+    loop = ev[:first_epi]
+    assert all(e[2] for e in loop if e[0] in ("vm", "bar", "dma")), "a wait / barrier / DMA of hipcc's own inside the K loop"
+    # run-length encode
+    rle = []
+    for k, v, _ in loop:
+        if k == "vm":
+            rle.append(("vm", v))
+        elif rle and rle[-1][0] == k and k != "bar":
+            rle[-1] = (k, rle[-1][1] + 1)
+        else:
+            rle.append((k, 1))
+    def phase(reads, wait, dma):
+        out = []
+        if reads:
+            out.append(("rd", reads))
+        if wait is not None:
+            out.append(("vm", wait))
+        out.append(("bar", 1))
+        if dma:
+            out.append(("dma", 2))
+        out += [("mfma", 16), ("bar", 1)]
+        return out
+    def tile(waits, dmas):
+        return phase(12, waits[0], dmas[0]) + phase(4, waits[1], dmas[1]) + phase(8, None, dmas[2]) + phase(0, waits[2], dmas[3])
+    want = [("dma", 14), ("vm", 10), ("bar", 1), ("bar", 1)]                     # prologue, barrier, row group 1's extra barrier
+    want += tile((8, 8, 8), (1, 1, 1, 1)) + tile((8, 8, 4), (1, 0, 0, 0)) + tile((2, 0, None), (0, 0, 0, 0))
+    want += [("bar", 1)]                                                         # row group 0's extra barrier: the ring is the epilogue's now
+    assert rle == want, [(a, b) for a, b in zip(rle, want) if a != b][:4]
+    meta = {n: v for n, v in _kernel_meta("swx_gemm.hip").items() if "gemm_f16_big8" in n}
     assert len(meta) == 1
     for n, v in meta.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (n, v)
