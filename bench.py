@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--no-regroup", action="store_true", help="leave the default regrouping out of the timed pass (round-2 behaviour)")
     ap.add_argument("--debug-flags", type=int, default=0, help="swx_debug_flags() A/B switches (csrc/swx_kernels.h), e.g. 16384 = "
                     "decode loop without the captured step graph")
+    ap.add_argument("--ab-flags", type=int, default=0, help="A/B inside ONE process (GPU boxes differ by up to 40 %): after the timed "
+                    "steps, three more passes each with and without these swx_debug_flags() bits, alternating; reported as `ab`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the strict-f32 leg")
@@ -254,6 +256,20 @@ def main():
     dt = par.max_over_ranks(time.perf_counter() - t0, device=dev if _dist.is_initialized() else None)
 
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
+    ab = None
+    if args.ab_flags and world == 1:
+        lib_ = model.engine.lib
+        ab = {"flags": args.ab_flags, "off_ms": [], "on_ms": []}
+        for _ in range(3):
+            for name, fl in (("off_ms", args.debug_flags & ~args.ab_flags), ("on_ms", args.debug_flags | args.ab_flags)):
+                lib_.swx_debug_flags(fl)
+                torch.cuda.synchronize()
+                t_ab = time.perf_counter()
+                step(model)
+                torch.cuda.synchronize()
+                ab[name].append(round(1000.0 * (time.perf_counter() - t_ab), 2))
+        lib_.swx_debug_flags(args.debug_flags)
+        ab["off_min_ms"], ab["on_min_ms"] = min(ab["off_ms"]), min(ab["on_ms"])
     graph_stats = model.engine.graph_stats()
     n_words = len(res.all_words()) if res is not None else 0
     n_segs = len(res.segments) if res is not None else 0
@@ -293,7 +309,7 @@ def main():
             "value": round(value, 2), "unit": "x real time", "n_gpus": world, "n_gpus_measured": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", **({"debug_flags": args.debug_flags} if args.debug_flags else {}),
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", **({"debug_flags": args.debug_flags} if args.debug_flags else {}), **({"ab": ab} if ab else {}),
             "latency_ms_per_window": round(1000.0 * dt / args.steps / max(n_windows, 1), 3),
             "config": {"workload": wl, "mode": "spans" if args.spans > 0 else ("sequential" if args.sequential else args.mode),
                        "windows_per_gpu": n_windows, "segments": n_segs, "words": n_words,

@@ -126,6 +126,13 @@ typedef struct swx_decode_cfg {
                                      but NOT the reference's (framework Philox) random stream: a T > 0 retry is reproducible for a given (seed, uid)
                                      whatever the batch it is decoded in, and is not token-identical with the reference's.
                                      NULL: the window's index in this job is its uid. */
+    const float *noise;           /* DEVICE array [sample_len][W * G][n_vocab] f32 or NULL.  Non-NULL (greedy decoder, temperature > 0):
+                                     the draw of row r at step t is argmax_i(logits[i] / T - log(noise[t][r][i])): upstream's
+                                     Categorical(logits / T).sample() is a multinomial draw of one sample, which the framework
+                                     computes as argmax(p / q) with q ~ Exp(1).  When the caller fills the array from the
+                                     framework's generator -- one exponential call per step on [W * G][n_vocab], as the
+                                     reference's decoding loop makes them -- the sampled tokens are the reference's for the
+                                     same seed; the counter-based hash above is not used. */
 } swx_decode_cfg;
 
 /* runs the whole loop; outputs (device):

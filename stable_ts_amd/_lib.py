@@ -32,7 +32,7 @@ class swx_decode_cfg(Structure):
         ("suppress_blank", c_int32), ("apply_timestamp_rules", c_int32), ("max_initial_timestamp_index", c_int32),
         ("eot", c_int32), ("sot", c_int32), ("no_timestamps", c_int32), ("timestamp_begin", c_int32),
         ("no_speech", c_int32), ("blank_token", c_int32), ("n_suppress", c_int32), ("min_tokens", c_int32),
-        ("seed", c_uint64), ("window_uid", POINTER(c_int32)),
+        ("seed", c_uint64), ("window_uid", POINTER(c_int32)), ("noise", c_void_p),
     ]
 
 

@@ -235,8 +235,10 @@ __global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int 
             // keyed on the window's stable identity, not on its row in this batch (fallback retries are decoded in
             // whatever batch the pending windows form)
             const unsigned row_uid = b.win_uid ? (unsigned)b.win_uid[r / b.G] * 0x9E3779B1u + (unsigned)(r % b.G) : (unsigned)r;
+            // c.noise: the caller's Exp(1) variates of this step and row (the framework generator's stream: swx.h)
+            const float *qn = c.noise ? c.noise + ((size_t)step * b.M + r) * V : nullptr;
             for (int i = tid; i < V; i += SEL_T) {
-                ArgMax x; x.v = lg[i] * invT + gumbel(c.seed, row_uid, (unsigned)step, (unsigned)i); x.i = i;
+                ArgMax x; x.v = lg[i] * invT + (qn ? -logf(qn[i]) : gumbel(c.seed, row_uid, (unsigned)step, (unsigned)i)); x.i = i;
                 best = argmax_combine(best, x);
             }
         }
@@ -382,11 +384,12 @@ __global__ __launch_bounds__(SEL_T) void decode_select_reg_kernel(DecodeBufs b, 
         } else {
             const float invT = 1.0f / c.temperature;
             const unsigned row_uid = b.win_uid ? (unsigned)b.win_uid[r / b.G] * 0x9E3779B1u + (unsigned)(r % b.G) : (unsigned)r;
+            const float *qn = c.noise ? c.noise + ((size_t)step * b.M + r) * V : nullptr;
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int i = tid + k * SEL_T;
                 if (i < V) {
-                    ArgMax x; x.v = v[k] * invT + gumbel(c.seed, row_uid, (unsigned)step, (unsigned)i); x.i = i;
+                    ArgMax x; x.v = v[k] * invT + (qn ? -logf(qn[i]) : gumbel(c.seed, row_uid, (unsigned)step, (unsigned)i)); x.i = i;
                     const ArgMax nb = argmax_combine(best, x);
                     if (nb.i != best.i) raw_own = v[k];
                     best = nb;

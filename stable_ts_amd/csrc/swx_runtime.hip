@@ -622,7 +622,8 @@ swx_model::StepGraph *step_graph(swx_model *m, const DecodeBufs &b, const void *
         (uint64_t)c.eot, (uint64_t)c.sot, (uint64_t)(int64_t)c.no_timestamps, (uint64_t)c.timestamp_begin, (uint64_t)(int64_t)c.no_speech,
         (uint64_t)(int64_t)c.blank_token, (uint64_t)c.n_suppress, (uint64_t)c.min_tokens, (uint64_t)c.seed,
         (uint64_t)(uintptr_t)b.ts_mask, (uint64_t)(uintptr_t)b.win_uid, (uint64_t)(uintptr_t)d_xkv, (uint64_t)(uintptr_t)m->arena,
-        (uint64_t)(uintptr_t)m->ws, (uint64_t)m->ws_bytes, (uint64_t)g_debug_flags, (uint64_t)cur, (uint64_t)m->is_folded()};
+        (uint64_t)(uintptr_t)m->ws, (uint64_t)m->ws_bytes, (uint64_t)g_debug_flags, (uint64_t)cur, (uint64_t)m->is_folded(),
+        (uint64_t)(uintptr_t)c.noise};
     ++m->graph_clock;
     for (auto &g : m->graphs) if (g.key == key) { g.used = m->graph_clock; return &g; }
     if (!m->cap_stream && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) { m->cap_stream = nullptr; return nullptr; }
@@ -1091,6 +1092,7 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
 
     DecodeBufs b{};
     b.cfg = *cfg;
+    if (cfg->beam || cfg->temperature == 0.f) b.cfg.noise = nullptr;      // only the sampling decoder draws
     b.W = W; b.G = G; b.M = M; b.V = D.n_vocab; b.TS = D.n_text_ctx + 1; b.n_ctx = D.n_text_ctx; b.n_init = n_init;
     const float pat = cfg->patience > 0.f ? cfg->patience : 1.0f;
     b.max_cand = cfg->beam ? (int)lrintf((float)G * pat) : 0;

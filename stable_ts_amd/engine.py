@@ -33,6 +33,15 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def reference_loop_iterations(lens, n_init: int, sample_len: int, n_ctx: int) -> int:
+    """How many iterations upstream's ``DecodingTask._main_loop`` makes for a job whose sequences came out with these lengths
+    (``lens`` = tokens up to, excluding, the first EOT, initial tokens included): iteration i appends token i to every
+    sequence; the loop ends after the first iteration at which every sequence has ended, the context is exceeded
+    (``tokens.shape[-1] > n_ctx``, decode.py:60) or ``sample_len`` iterations were made.  One sampling draw per iteration."""
+    longest = int(np.max(np.asarray(lens))) - int(n_init)        # a sequence of k sampled tokens drew its EOT at iteration k
+    return max(1, min(longest + 1, int(sample_len), int(n_ctx) - int(n_init) + 1))
+
+
 def _i32arr(vals: Sequence[int]):
     return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
 
@@ -223,7 +232,14 @@ class Engine:
                max_initial_timestamp_index: Optional[int] = None, eot: int = 0, sot: int = 0, no_timestamps: int = -1,
                timestamp_begin: int = 0, no_speech: int = -1, blank_token: int = -1,
                suppress_tokens: Sequence[int] = (), ts_mask: Optional[torch.Tensor] = None, min_tokens: int = 0,
-               seed: int = 0, window_uid: Optional[Sequence[int]] = None):
+               seed: int = 0, window_uid: Optional[Sequence[int]] = None, torch_rng: bool = False):
+        """``torch_rng`` (sampling decoder, ``temperature > 0``): draw from torch's generator of this device exactly as the
+        reference's loop does -- upstream ``GreedyDecoder.update`` samples ``Categorical(logits / T)``, which is
+        ``argmax(p / q)`` with ``q = empty_like(p).exponential_()``: ONE generator call per step on ``[W * G, n_vocab]``.  The
+        variates of every possible step are drawn up front (the same calls, so the same numbers), the device loop reads
+        them (``swx_decode_cfg.noise``), and the generator is left where the reference leaves it: after as many draws as its
+        loop makes iterations.  With the same seed the sampled tokens are then the reference's (up to f32 near-ties of
+        ``p / q``).  False: the counter-based hash keyed on ``(seed, window_uid)``, which does not depend on the batch."""
         W = len(init_tokens)
         n_init = len(init_tokens[0])
         assert all(len(t) == n_init for t in init_tokens), "all windows of a job share the initial length"
@@ -235,6 +251,9 @@ class Engine:
         if window_uid is not None:
             assert len(window_uid) == W
             uid = _i32arr([int(u) & 0x7FFFFFFF for u in window_uid])
+        noise = rng = None
+        if torch_rng and temperature > 0 and not beam:
+            noise, rng = self._draw_noise(int(sample_len), W * n_group)
         cfg = swx_decode_cfg(
             n_windows=W, n_group=n_group, beam=int(beam), temperature=float(temperature),
             patience=float(patience or 0.0), sample_len=int(sample_len), sample_begin=n_init, sot_index=int(sot_index),
@@ -242,7 +261,7 @@ class Engine:
             max_initial_timestamp_index=-1 if max_initial_timestamp_index is None else int(max_initial_timestamp_index),
             eot=eot, sot=sot, no_timestamps=no_timestamps, timestamp_begin=timestamp_begin, no_speech=no_speech,
             blank_token=blank_token, n_suppress=len(suppress_tokens), min_tokens=int(min_tokens), seed=int(seed),
-            window_uid=uid)
+            window_uid=uid, noise=_ptr(noise))
         g_out = self.lib.swx_decode_gout(ctypes.byref(cfg))
         TS = self.dims.n_text_ctx + 1
         d_init = torch.tensor(np.asarray(init_tokens, dtype=np.int32), device=self.device)
@@ -257,8 +276,29 @@ class Engine:
         nosp = torch.empty(W, dtype=torch.float32, device=self.device)
         steps = check(self.lib.swx_decode(self.h, ctypes.byref(cfg), _ptr(d_init), _ptr(d_sup), _ptr(d_mask), _ptr(xkv),
                                           _ptr(toks), _ptr(lens), _ptr(sumlp), _ptr(nosp), self.stream), "swx_decode")
-        return dict(tokens=toks.cpu().numpy(), lens=lens.cpu().numpy(), sum_logprobs=sumlp.cpu().numpy(),
-                    no_speech_prob=nosp.cpu().numpy(), steps=steps, sample_begin=n_init)
+        out = dict(tokens=toks.cpu().numpy(), lens=lens.cpu().numpy(), sum_logprobs=sumlp.cpu().numpy(),
+                   no_speech_prob=nosp.cpu().numpy(), steps=steps, sample_begin=n_init)
+        if rng is not None:
+            gen, off0, inc = rng
+            gen.set_offset(off0 + inc * reference_loop_iterations(out["lens"], n_init, int(sample_len), self.dims.n_text_ctx))
+        return out
+
+    def _draw_noise(self, steps: int, rows: int):
+        """[steps][rows][n_vocab] Exp(1) variates from torch's generator of this device, one ``exponential_()`` call per step
+        (what ``torch.multinomial(p, 1)`` draws inside the reference's ``Categorical.sample()``), and what is needed to put
+        the generator back: (generator, offset before, offset consumed per call)."""
+        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None else torch.cuda.current_device()]
+        buf = getattr(self, "_noise_buf", None)
+        if buf is None or buf.shape[0] < steps or buf.shape[1] != rows:
+            buf = self._noise_buf = torch.empty(steps, rows, self.dims.n_vocab, dtype=torch.float32, device=self.device)
+        off0 = gen.get_offset()
+        inc = 0
+        for t in range(steps):
+            buf[t].exponential_()
+            if t == 0:
+                inc = gen.get_offset() - off0
+        assert inc > 0 and gen.get_offset() == off0 + inc * steps, "torch generator offsets are not linear in the calls"
+        return buf, (gen, off0, inc)
 
     # ------------------------------------------------------------------ a6/a7 score
     def score(self, xkv: torch.Tensor, tokens: Sequence[Sequence[int]], n_frames: Sequence[int], n_sot: int, eot: int,

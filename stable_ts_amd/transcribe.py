@@ -85,9 +85,11 @@ def _xkv_select(model, xkv, idx: Sequence[int]):
 
 def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float], prompts, ts_masks,
                           compression_ratio_threshold, logprob_threshold, no_speech_threshold,
-                          uids: Optional[Sequence[int]] = None) -> List[DecodingResult]:
+                          uids: Optional[Sequence[int]] = None, torch_rng: bool = False) -> List[DecodingResult]:
     """original_whisper.py:349-393, for W windows: every window walks the temperature ladder independently; the ones that
-    still need a fallback are re-decoded together at the next temperature."""
+    still need a fallback are re-decoded together at the next temperature.  ``torch_rng`` (the sequential driver, one window
+    per call): sampled retries draw from torch's generator call for call like the reference's loop (Engine.decode), so with
+    the same ``torch.manual_seed`` they are the reference's tokens; otherwise the draws are keyed on ``uids``."""
     W = xkv.n_windows
     results: List[Optional[DecodingResult]] = [None] * W
     pending = list(range(W))
@@ -113,6 +115,7 @@ def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float],
             # sampling draws are keyed on the window's identity (its seek position), not on its row in this batch
             out = model.engine.decode(sub_k, [list(plans[k].initial_tokens) for k in ks], ts_mask=masks,
                                       window_uid=None if uids is None else [uids[pending[k]] for k in ks],
+                                      **(dict(torch_rng=True) if torch_rng and t > 0 and W == 1 else {}),
                                       **plans[ks[0]].engine_kwargs())
             for k, r in zip(ks, plans[ks[0]].results(out, [None] * len(ks), [options.language or "en"] * len(ks))):
                 outs[k] = r
@@ -221,7 +224,8 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict, pre: Optional[d
         ts_masks = [torch.zeros(1501, dtype=torch.bool) if m is None else m for m in ts_masks]
     results = _decode_with_fallback(model, xkv, o["decode_options"], o["temperatures"], [b["prompt"] for b in batch],
                                     ts_masks, o["compression_ratio_threshold"], o["logprob_threshold"],
-                                    o["no_speech_threshold"], uids=[int(b["seek_sample"]) // 160 for b in batch])
+                                    o["no_speech_threshold"], uids=[int(b["seek_sample"]) // 160 for b in batch],
+                                    torch_rng=bool(o.get("torch_sampling")))
     t_ph = _phase("decode (device loop + result copy)", t_ph)
     time_precision = (N_FRAMES // model.dims.n_audio_ctx) * HOP_LENGTH / SAMPLE_RATE
     punct = o["prepend_punctuations"] + o["append_punctuations"]
@@ -415,7 +419,10 @@ def transcribe_stable(model, audio, *, verbose: Optional[bool] = False,
              append_punctuations=APPEND_PUNCTUATIONS if append_punctuations is None else append_punctuations,
              min_word_dur=0.1 if min_word_dur is None else min_word_dur, split_callback=split_callback,
              gap_padding=gap_padding, max_instant_words=max_instant_words, avg_prob_threshold=avg_prob_threshold,
-             suppress_ts_tokens=suppress_ts_tokens, extra_models=extra_models, dynamic_heads=dynamic_heads, aligner=aligner)
+             suppress_ts_tokens=suppress_ts_tokens, extra_models=extra_models, dynamic_heads=dynamic_heads, aligner=aligner,
+             # the reference's own control flow (one track, one window per decode call) samples from torch's generator like the
+             # reference; window-parallel / span modes decode several windows per call and key the draws on the window instead
+             torch_sampling=not batch_size and not _span_bounds)
 
     def host_copy(seg: torch.Tensor) -> torch.Tensor:
         return seg.detach().float().cpu()                       # silence analysis is host-side vector code (CPU)

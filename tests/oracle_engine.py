@@ -49,7 +49,8 @@ class OracleEngine:
     def decode(self, xkv, init_tokens, *, n_group=1, beam=False, temperature=0.0, patience=None, sample_len=224,
                sot_index=0, suppress_blank=True, apply_timestamp_rules=True, max_initial_timestamp_index=None, eot=0, sot=0,
                no_timestamps=-1, timestamp_begin=0, no_speech=-1, blank_token=-1, suppress_tokens=(), ts_mask=None,
-               min_tokens=0, seed=0, window_uid=None):
+               min_tokens=0, seed=0, window_uid=None, torch_rng=False):
+        # (torch_rng: this stand-in always samples through upstream's Categorical, i.e. from torch's generator)
         self.n_decode_calls += 1
         W = xkv.n_windows
         TS = self.dims.n_text_ctx + 1

@@ -264,9 +264,78 @@ def test_inner_locate_matches_reference_glue():
         close(got, want, str(kw))
 
 
+@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
+def test_inner_sampled_decoding_follows_torch_generator():
+    """temperature > 0 in the reference's own control flow (one window per decode call) is SAMPLE-exact, not only
+    distribution-equal: upstream GreedyDecoder.update draws Categorical(logits / T).sample() = argmax(p / q), q = one
+    exponential_() call of torch's generator on [best_of, n_vocab] per loop iteration (decode.py:58).  Engine.decode(torch_rng=True)
+    makes the same generator calls, the selection kernel takes argmax(logits / T - log q), and the generator is left after as many
+    draws as the reference's loop makes iterations.  Checked against the CPU oracle whose sampler gets the logits where the
+    reference has them when the model is on the GPU (a CUDA tensor, i.e. the SAME generator): two windows decoded one after the
+    other from one seed -- tokens identical, avg_logprob within 1e-3, generator offset identical after each window -- and the
+    temperature ladder of decode_with_fallback (original_whisper.py:349-393) on top."""
+    from stable_ts_amd.decoding import DecodingOptions, DecodingPlan
+    from stable_ts_amd import transcribe as T
+    from oracle import stable as ost
+    from oracle.whisper import decoding as od
+    from oracle.whisper import model as om
+    from oracle.whisper.decoding import DecodingOptions as ODO
+    case = dict(model="tiny.en", gain=2.0, ts_gain=0.5)
+    model = _model(case)
+    ref = om.build_model("tiny.en", seed=1234, std=0.02, embed_gain=2.0, ts_gain=0.5)
+    audio = _synth_audio(60.0, 11)
+    segs = [audio[k * 480000:(k + 1) * 480000] for k in range(2)]
+    mel = model.log_mel_batch(segs, [0, 0])
+    xkv = model.cross_kv(model.encoder(mel))
+    base = dict(language="en", sample_len=24, max_initial_timestamp=None, fp16=False)
+    gen = torch.cuda.default_generators[torch.cuda.current_device()]
+
+    class OnDevice:                       # upstream's sampler, logits on the GPU like the reference's
+        def __init__(self, logits):
+            self.d = torch.distributions.Categorical(logits=logits.to("cuda"))
+
+        def sample(self):
+            return self.d.sample().cpu()
+    real = od.Categorical
+    od.Categorical = OnDevice
+    try:
+        for temp, best_of in ((0.4, 5), (0.8, 3), (1.0, 1)):
+            torch.manual_seed(4321)
+            want, off_want = [], []
+            for w in range(2):
+                r, _ = ost.decode_stable(ref, mel[w].cpu(), ODO(temperature=temp, best_of=best_of if best_of > 1 else None, **base))
+                want.append(r)
+                off_want.append(gen.get_offset())
+            torch.manual_seed(4321)
+            plan = DecodingPlan(model, DecodingOptions(temperature=temp, best_of=best_of if best_of > 1 else None, **base))
+            for w in range(2):
+                out = model.engine.decode(T._xkv_select(model, xkv, [w]), [list(plan.initial_tokens)], torch_rng=True, **plan.engine_kwargs())
+                got = plan.results(out, [None], ["en"])[0]
+                assert got.tokens == want[w].tokens, (temp, w, got.tokens, want[w].tokens)
+                assert abs(got.avg_logprob - want[w].avg_logprob) < 1e-3
+                assert gen.get_offset() == off_want[w], (temp, w, gen.get_offset(), off_want[w])
+        # the ladder: every attempt fails the log-probability threshold (random weights), so T = 0, 0.4 and 0.8 are all decoded
+        kw = dict(compression_ratio_threshold=None, logprob_threshold=-0.5, no_speech_threshold=None)
+        temps = [0.0, 0.4, 0.8]
+        torch.manual_seed(99)
+        for t in temps:
+            r, _ = ost.decode_stable(ref, mel[1].cpu(), ODO(temperature=t, best_of=3 if t > 0 else None, **base))
+            if not r.avg_logprob < -0.5:
+                break
+        off = gen.get_offset()
+        torch.manual_seed(99)
+        res = T._decode_with_fallback(model, T._xkv_select(model, xkv, [1]), dict(base, best_of=3), temps, [None], None, uids=[3000],
+                                      torch_rng=True, **kw)[0]
+        assert res.temperature == r.temperature and res.tokens == r.tokens and abs(res.avg_logprob - r.avg_logprob) < 1e-3
+        assert gen.get_offset() == off
+    finally:
+        od.Categorical = real
+
+
 @pytest.mark.parametrize("inner", ["test_inner_transcribe_spans_equals_sequential_per_span",
                                    "test_inner_transcribe_variants_match_reference_glue",
-                                   "test_inner_locate_matches_reference_glue"])
+                                   "test_inner_locate_matches_reference_glue",
+                                   "test_inner_sampled_decoding_follows_torch_generator"])
 def test_pending_device_paths_in_subprocess(inner):
     import subprocess
     import sys
