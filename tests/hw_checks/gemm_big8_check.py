@@ -31,7 +31,7 @@ def main() -> int:
     g = torch.Generator(device="cpu").manual_seed(7)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     side = torch.cuda.Stream()
-    junk_a, junk_b = torch.empty(64 << 20, dtype=torch.uint8, device=dev), torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    junk_a, junk_b = torch.empty(256 << 20, dtype=torch.uint8, device=dev), torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
     bad = 0
     shapes = [(30000, 3840, 1280, EPI_BIAS), (30000, 5120, 1280, EPI_BIAS | EPI_GELU), (30000, 1280, 5120, EPI_BIAS | EPI_RES),
@@ -59,7 +59,7 @@ def main() -> int:
         torch.cuda.synchronize()
         wrong = 0
         with torch.cuda.stream(side):                                    # background traffic for the whole repetition loop
-            for _ in range(4 * args.reps):
+            for _ in range(15 * args.reps):
                 junk_b.copy_(junk_a, non_blocking=True)
         for rep in range(args.reps):
             rc13, c13 = run(13)
