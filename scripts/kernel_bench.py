@@ -85,10 +85,9 @@ def main():
             print(f"  M={M:6d} N={N:6d} K={K:5d}:" + "".join(f"{u:9.1f}" for u in row))
 
     if args.only in ("gemm_big",):
-        # the encoder at 20 / 8 / 4 windows: 7 = 128 x 128 tiles overlapped through occupancy, 12 = 256 x 256 two-stage kernel,
-        # 13 = the same tile on the half-tile ring (gemm_f16_big8)
+        # the encoder at 20 / 8 / 4 windows: 7 = 128 x 128 tiles overlapped through occupancy, 12 = the 256 x 256 kernel (gemm_f16_big8)
         print("-- tiled MFMA GEMM at large M: us per launch (TFLOP/s) by force_kernel")
-        codes = [7, 12, 13, 0]
+        codes = [7, 12, 0]
         print("  " + " " * 28 + "".join(f"{c:>18d}" for c in codes))
         for M, N, K in [(30000, 1280, 1280), (30000, 3840, 1280), (30000, 5120, 1280), (30000, 1280, 5120), (30000, 2560, 1280),
                         (12000, 1280, 1280), (12000, 3840, 1280), (12000, 5120, 1280), (12000, 1280, 5120),

@@ -8,9 +8,8 @@
 //                                  bit-identity reference of the four below
 //   * gemm_f16_glds_128 / _64      the same tile filled by LDS-DMA, one operand buffer, three workgroups per CU overlap each other
 //   * gemm_f16_ring<64|128, 3>     launches with <= 1 workgroup per CU: three LDS stages, LDS-DMA from inline asm, counted waits
-//   * gemm_f16_big                 256x256 tile, 8 waves, two LDS-DMA stages: launches that fill whole rounds of the 256 CUs
-//   * gemm_f16_big8                the same tile on a ring of eight half-tile slots, four phases per K tile, the two row groups of
-//                                  waves half a phase apart (SWX_FLAG_BIG8)
+//   * gemm_f16_big8                256x256 tile, 8 waves, LDS-DMA into a ring of eight half-tile slots, four phases per K tile, the
+//                                  two row groups of waves half a phase apart: launches that fill whole rounds of the 256 CUs
 //   * tiled f32                    the 128x128 tiling on v_mfma_f32_16x16x4_f32 (exact f32 fma chain)     (strict-parity mode)
 //   * skinny f16                   M <= 128 rows: one 16-column weight panel per workgroup, K split over its 4 waves, weights
 //                                  streamed straight from HBM into MFMA fragments (no LDS), LDS reduction
@@ -497,17 +496,16 @@ static void launch_ring(const GemmArgs &g, hipStream_t s)
     hipLaunchKernelGGL((gemm_f16_ring<BNT, NST>), dim3(cdiv(g.N, BNT), cdiv(g.M, BM)), dim3(256), lds, s, g);
 }
 
-// ---------------------------------------------------------------------- tiled f16, 256 x 256 tile, 8 waves, two stages
+// ------------------------------------------------------------------------------------ tiled f16, 256 x 256 tile, 8 waves
 // The large-M shapes (encoder at 20 windows: M = 30 000).  The 128 x 128 tile above reads 16 KB of fragments from LDS per wave
 // and K step for 32 MFMAs -- 64 KB per workgroup against an LDS port of 128 B/clk: exactly as many LDS cycles as MFMA cycles,
 // which is what holds that kernel at 0.29-0.34 of the MFMA peak however it is scheduled.  Here a wave owns 128 x 64 of a
 // 256 x 256 tile (8 waves as 2 x 4): 24 fragment reads feed 64 MFMAs, 0.75 LDS cycles per MFMA cycle.  One workgroup per CU
-// (two waves per SIMD, 128 accumulator registers each), two 64 KB operand stages filled by the ring kernel's asm LDS-DMA:
-// K step kt + 1 lands while step kt computes; one `vmcnt(0)` + raw barrier per step.  Plain epilogues only (bias, GELU, f16
-// residual, f16 rows with 16-byte aligned leading dimensions): the encoder's four projections; everything else stays on the
-// kernels above.  Same MFMA order per accumulator: bit-identical results (tests/hw_checks/gemm_glds_check.py).
+// (two waves per SIMD, 128 accumulator registers each), 128 KB of operand stages filled by the ring kernel's asm LDS-DMA.  Plain
+// epilogues only (bias, GELU, f16 residual, f16 rows with 16-byte aligned leading dimensions): the encoder's four projections;
+// everything else stays on the kernels above.  Same MFMA order per accumulator: bit-identical results
+// (tests/hw_checks/gemm_glds_check.py, gemm_big8_check.py).
 constexpr int BG = 256;                                   // tile edge
-constexpr int BG_STAGE = 2 * BG * 128;                    // bytes per stage: A 256 rows x 64 halfs | B the same
 constexpr int BG_CLD = BG + 4;                            // f32 epilogue row
 
 // Epilogue of the 256 x 256 kernels: four passes of 64 rows through a f32 tile in LDS, 16-byte row-contiguous stores
@@ -575,90 +573,17 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmArgs &g, unsigned ch
     }
 }
 
-__global__ __launch_bounds__(512) void gemm_f16_big(GemmArgs g)
-{
-    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];     // 2 stages = 128 KB; the epilogue's 64 x 260 f32 after
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const int wm = wave >> 2, wn = wave & 3;
-    int bx = blockIdx.x, by = blockIdx.y;
-    {
-        const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = wg % gx; by = wg / gx;
-    }
-    const int m0 = by * BG, n0 = bx * BG;
-    const f16 *A = (const f16 *)g.A;
-    const f16 *W = (const f16 *)g.W;
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // a wave stages four 8-row chunks of each operand per K step (chunk = wave * 4 + c; rows past M / N clamped)
-    const f16 *srcA[4], *srcW[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int r = (wave * 4 + c) * 8 + (lane >> 3);
-        const int slot = (lane & 7) ^ ((r >> 1) & 7);
-        const int gm = m0 + r < g.M ? m0 + r : g.M - 1;
-        const int gn = n0 + r < g.N ? n0 + r : g.N - 1;
-        srcA[c] = A + (size_t)gm * g.lda + slot * 8;
-        srcW[c] = W + (size_t)gn * g.ldw + slot * 8;
-    }
-    typedef __attribute__((address_space(3))) void lds_void;
-    const unsigned ring0 = (unsigned)(uintptr_t)(lds_void *)ring;
-    auto stage = [&](int kt, int buf) {
-        const unsigned ta = ring0 + buf * BG_STAGE, tb = ta + BG * 128;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) glds16_asm(srcA[c] + kt * 64, ta + (wave_u * 4 + c) * 1024);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) glds16_asm(srcW[c] + kt * 64, tb + (wave_u * 4 + c) * 1024);
-    };
-    const int KT = g.K / 64;
-    const int fr = lane & 15, fs = lane >> 4;
-    auto compute = [&](int buf) {
-        const unsigned char *ta = ring + buf * BG_STAGE, *tb = ta + BG * 128;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            f16x8 a[8], b[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + fr;
-                b[j] = *(const f16x8 *)(tb + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = wm * 128 + i * 16 + fr;
-                a[i] = *(const f16x8 *)(ta + row * 128 + (((kk * 4 + fs) ^ ((row >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-    };
-    stage(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        ring_wait_barrier<0>();                          // stage kt landed for every wave; every wave is done with stage kt - 1
-        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
-        compute(kt & 1);
-    }
-    __syncthreads();
-
-    big_tile_epilogue(g, ring, acc, m0, n0, tid, lane, wm, wn);
-}
-
 // ------------------------------------------------------ tiled f16, 256 x 256 tile, 8 waves, half-tile ring, staggered wave groups
-// gemm_f16_big leaves the MFMA pipe idle twice per K step: its one LDS-DMA stage in flight is issued at the start of the step
-// whose MFMAs (2 048 clocks for 64 KB) are shorter than a loaded fabric round trip, and its eight waves read fragments and
-// multiply in lockstep (1 536 clocks of LDS reads per step that no MFMA covers).  This kernel keeps the tile, the swizzle, the
-// wave -> accumulator map and the MFMA order per accumulator (bit-identical results) and changes the schedule
-// (cdna_hip_programming.md, "The 256^2 8-phase template"):
+// Generation 1 of this kernel (round 3: two 64 KB K-step stages, one `vmcnt(0)` + barrier per step; deleted in round 4) left the
+// MFMA pipe idle twice per K step: its one LDS-DMA stage in flight was issued at the start of the step whose MFMAs (2 048 clocks
+// for 64 KB) are shorter than a loaded fabric round trip, and its eight waves read fragments and multiplied in lockstep (1 536
+// clocks of LDS reads per step that no MFMA covered).  This generation keeps the tile, the swizzle, the wave -> accumulator map
+// and the MFMA order per accumulator (bit-identical results) and changes the schedule (cdna_hip_programming.md, "The 256^2
+// 8-phase template").  Measured against generation 1 (profiles/r04_kb_gemm_big8.txt, M = 30 000, TFLOP/s): N = 3840: 962 -> 1 039;
+// N = 5120 + GELU: 840 -> 882; K = 5120: 919 -> 1 044; N = 2560: 974 -> 1 035; in the headline pass 562 / 428 / 297 -> 545 / 388 /
+// 280 us per launch (profiles/r04_big8_pass_kernels.csv).  Still 0.35 - 0.42 of the MFMA peak: four to five half-tiles in flight
+// per CU (16 MB over the chip) cover ~2 us of fabric latency at the 7.8 TB/s of operand traffic 1 000 TFLOP/s needs -- LDS
+// capacity (128 of 160 KB), not the schedule, bounds the depth.
 //  * the two 64 KB operand buffers are eight HALF-TILE slots (A0 A1 B0 B1 of an even and an odd K tile).  Half h of A = the 64
 //    rows each row group of waves multiplies in its phases with that half (tile rows wm * 128 + h * 64 + ..), half h of B = the
 //    32 columns of each column group (wn * 64 + h * 32 + ..): a phase needs whole halves, and a slot is refilled as soon as its
@@ -770,7 +695,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big8(GemmArgs g)
                 fb[j][kk] = *(const f16x8 *)(t + lr * 128 + (((kk * 4 + fs) ^ ((lr >> 1) & 7)) << 4));
             }
     };
-    // 16 MFMAs of quadrant (ih, jh); per accumulator kk = 0 then 1, K tiles ascending: gemm_f16_big's order
+    // 16 MFMAs of quadrant (ih, jh); per accumulator kk = 0 then 1, K tiles ascending: the order of every tiled f16 kernel
     auto quad = [&](auto ih_c, auto jh_c, const f16x8 (&fb)[2][2]) {
         constexpr int ih = decltype(ih_c)::value, jh = decltype(jh_c)::value;
         __builtin_amdgcn_s_setprio(1);
@@ -1032,8 +957,7 @@ __global__ __launch_bounds__(256) void gemm_f16_skinny(GemmArgs g)
 // Which f16 kernel a launch gets.  One pure function (no device state) so that the rule is testable without a GPU
 // (tests/test_gemm_plan_cpu.py restates the benchmarked shapes) and is what swx_gemm executes.  `ptr16` = A, W (and C / R for
 // the big kernel's vector epilogue) are 16-byte aligned; `force_kernel`: 0 dispatch, 1 register-staged, 2 skinny, 7 direct-to-LDS
-// with occupancy overlap (8 / 9: its 64-column tiles always / never), 10 / 11 ring at 64 / 128 columns, 12 the 256 x 256 kernel,
-// 13 its half-tile-ring generation (gemm_f16_big8; SWX_FLAG_BIG8 puts it wherever the dispatch takes 12).
+// with occupancy overlap (8 / 9: its 64-column tiles always / never), 10 / 11 ring at 64 / 128 columns, 12 the 256 x 256 kernel.
 int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bool ptr16, int force_kernel, int flags)
 {
     if (K % 32 != 0) return -4;                                            // tiled: K % 32, skinny: K % 128
@@ -1052,13 +976,12 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
     // a long K to amortise prologue and epilogue (M = 30 000, N = 1280, K = 5120: 590 tiles, 979 against 892); not for K < 512
     // (profiles/r03_kb_gemm_big.txt)
     const bool big_ok = !(epi & ~(EPI_BIAS | EPI_GELU | EPI_RES)) && ldc % 8 == 0 && (!(epi & EPI_RES) || ldr % 8 == 0);
-    if (force_kernel == 12) return big_ok ? SWX_GEMM_BIG : -4;
-    if (force_kernel == 13) return big_ok && K >= 128 ? SWX_GEMM_BIG8 : -4;
+    if (force_kernel == 12) return big_ok && K >= 128 ? SWX_GEMM_BIG : -4;      // (its prologue keeps two K tiles in flight)
     const int64_t t256 = (int64_t)cdiv(M, BG) * cdiv(N, BG);
     const double fill = (double)t256 / (double)(((t256 + 255) / 256) * 256);
     if (force_kernel == 0 && big_ok && t256 >= 200 && K >= 512 && (fill >= 0.9 || (fill >= 0.75 && K >= 2560)) &&
         !(flags & SWX_FLAG_NO_BIG_TILE))
-        return (flags & SWX_FLAG_BIG8) ? SWX_GEMM_BIG8 : SWX_GEMM_BIG;
+        return SWX_GEMM_BIG;
     // the ring kernel for launches of at most one workgroup per CU (the encoder / cross-K/V at one window: 64-column tiles when
     // `narrow`, else 128-column ones up to 256 tiles); from ~1.5 workgroups per CU on, gemm_f16_glds -- three resident
     // workgroups, epilogues overlapped with the neighbours' MFMAs -- is as fast or faster (N = 3840 / 5120 at M = 1500: 29.3 /
@@ -1099,8 +1022,6 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             const dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
             switch (plan) {
                 case SWX_GEMM_BIG:
-                    hipLaunchKernelGGL(gemm_f16_big, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * BG_STAGE, s, g); break;
-                case SWX_GEMM_BIG8:
                     hipLaunchKernelGGL(gemm_f16_big8, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * B8_BUF, s, g); break;
                 case SWX_GEMM_RING64: launch_ring<64, 3>(g, s); break;
                 case SWX_GEMM_RING128: launch_ring<128, 3>(g, s); break;

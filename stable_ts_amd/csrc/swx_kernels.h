@@ -26,7 +26,7 @@ struct GemmArgs {
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 // the f16 kernel a launch gets (swx_gemm.hip; a pure function of the shape, the epilogue and the switches)
 enum { SWX_GEMM_TILED_REG = 0, SWX_GEMM_SKINNY = 1, SWX_GEMM_GLDS128 = 2, SWX_GEMM_GLDS64 = 3, SWX_GEMM_RING64 = 4, SWX_GEMM_RING128 = 5,
-       SWX_GEMM_BIG = 6, SWX_GEMM_BIG8 = 7 };
+       SWX_GEMM_BIG = 6 };
 int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bool ptr16, int force_kernel, int flags);
 
 // ---- run-time A/B switches (swx_debug_flags(); tests and scripts only -- no environment variable reads them).  Each one
@@ -47,8 +47,6 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_NO_FUSED_XQ 1048576  // decode step: cross-attention query projection as a launch of its own instead of inside the
                                       // cross-attention kernel (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
-#define SWX_FLAG_BIG8 2097152         // tiled GEMM: gemm_f16_big8 (half-tile ring, staggered wave groups) wherever the dispatch takes the
-                                      // 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
 

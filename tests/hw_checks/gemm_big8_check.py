@@ -1,6 +1,6 @@
-"""Hardware check of gemm_f16_big8 (csrc/swx_gemm.hip: the 256 x 256 tile on a ring of eight half-tile slots, force_kernel 13)
-against gemm_f16_big (12) and the register-staged gemm_f16_tiled (1): the same MFMA sequence per accumulator, so all three must
-agree BIT FOR BIT.  The kernel orders its LDS-DMA by counted waits and raw barriers between two staggered groups of waves; a
+"""Hardware check of gemm_f16_big8 (csrc/swx_gemm.hip: the 256 x 256 tile on a ring of eight half-tile slots, force_kernel 12)
+against the register-staged gemm_f16_tiled (1): the same MFMA sequence per accumulator, so both must agree BIT FOR BIT (first
+hardware run, with the two-stage generation it replaced as a third party: profiles/r04_big8_check.txt).  The kernel orders its LDS-DMA by counted waits and raw barriers between two staggered groups of waves; a
 misplaced wait would show as a rare wrong tile, not as a wrong kernel, so every shape is repeated REPS times on fresh NaN-filled
 outputs while a second stream keeps the memory system busy (a copy loop), and compared each time.  Shapes: the encoder's
 projections at 20 windows (the launches the dispatch gives this kernel), M / N tails (clamped rows), two and three K tiles
@@ -55,21 +55,20 @@ def main() -> int:
             rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), p(r), p(c), ldc, M, N, K, epi, force, st)
             return rc, c
         rc1, c1 = run(1)
-        rc12, c12 = run(12)
         torch.cuda.synchronize()
         wrong = 0
         with torch.cuda.stream(side):                                    # background traffic for the whole repetition loop
             for _ in range(15 * args.reps):
                 junk_b.copy_(junk_a, non_blocking=True)
         for rep in range(args.reps):
-            rc13, c13 = run(13)
+            rc13, c13 = run(12)
             same = rc13 == 0 and torch.equal(c13[:, :N], c1[:, :N])
             wrong += not same
         torch.cuda.synchronize()
-        ok = rc1 == 0 and rc12 == 0 and torch.equal(c12[:, :N], c1[:, :N]) and wrong == 0
+        ok = rc1 == 0 and wrong == 0
         nan_left = bool(torch.isnan(c13[:, :N]).any()) if rc13 == 0 else True
-        print(("ok   " if ok and not nan_left else "FAIL ") + f"M={M} N={N} K={K} epi={epi}: rc tiled/big/big8 = {rc1},{rc12},{rc13}; "
-              f"big == tiled: {rc12 == 0 and torch.equal(c12[:, :N], c1[:, :N])}; big8 != tiled in {wrong} of {args.reps} runs; NaN left: {nan_left}")
+        print(("ok   " if ok and not nan_left else "FAIL ") + f"M={M} N={N} K={K} epi={epi}: rc tiled / big8 = {rc1},{rc13}; "
+              f"big8 != tiled in {wrong} of {args.reps} runs; NaN left: {nan_left}")
         bad += not (ok and not nan_left)
     return 1 if bad else 0
 

@@ -1,6 +1,6 @@
 """Hardware check of the direct-to-LDS tiled GEMM (gemm_f16_glds_128 / _64; force_kernel 7 = the default dispatch, which picks
 64-column tiles for shapes with few tiles, 8 / 9 = 64-column tiles always / never): each runs the same MFMA sequence per
-accumulator as the register-staged gemm_f16_tiled (force_kernel = 1), so all must agree BIT FOR BIT; they are also held to a CPU float64 reference.  The ring kernel (gemm_f16_ring, force_kernel 10 / 11 = 64 / 128 columns) and the 256 x 256 kernels (gemm_f16_big, 12; gemm_f16_big8, 13 = its half-tile-ring generation) (all: LDS-DMA from inline asm, counted waits, raw barriers) is held to the same bit-identity, repeated REPS times per shape: a misplaced wait shows as a rare wrong tile, not as a wrong kernel.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
+accumulator as the register-staged gemm_f16_tiled (force_kernel = 1), so all must agree BIT FOR BIT; they are also held to a CPU float64 reference.  The ring kernel (gemm_f16_ring, force_kernel 10 / 11 = 64 / 128 columns) and the 256 x 256 kernel (gemm_f16_big8, 12) (both: LDS-DMA from inline asm, counted waits, raw barriers) is held to the same bit-identity, repeated REPS times per shape: a misplaced wait shows as a rare wrong tile, not as a wrong kernel.  Covers M / N tails (clamped rows), every fused epilogue, and K up to 5120.  Exit code 0 = all shapes agree.
 
     python tests/hw_checks/gemm_glds_check.py
 """
@@ -36,8 +36,8 @@ def main() -> int:
         bias = torch.randn(N, generator=g).float().to(dev)
         res = torch.randn(M, N, generator=g).half().to(dev)
         outs = []
-        for force in (1, 7, 8, 9, 10, 11, 12, 13, 0):
-            for rep in range(REPS if force in (10, 11, 12, 13) and (M * N <= 8_000_000 or force == 13) else 1):
+        for force in (1, 7, 8, 9, 10, 11, 12, 0):
+            for rep in range(REPS if force in (10, 11, 12) and (M * N <= 8_000_000 or force == 12) else 1):
                 c = torch.full((M, N), float("nan"), dtype=torch.half, device=dev)
                 rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), p(res) if epi & EPI_RES else None, p(c), N, M, N, K, epi, force, st)
                 torch.cuda.synchronize()
@@ -58,10 +58,10 @@ def main() -> int:
                 ref = torch.nn.functional.gelu(ref)
             if epi & EPI_RES:
                 ref = ref + res.cpu().double()
-        # 7 / 8 / 9: the direct-to-LDS kernel at both tile widths; 10 / 11: the ring kernel (-4 = K < 128, not offered); 12: the 256 x 256 two-stage kernel; 13: its half-tile ring (-4 = K < 128); 0: dispatch
-        codes = (1, 7, 8, 9, 10, 11, 12, 13, 0)
+        # 7 / 8 / 9: the direct-to-LDS kernel at both tile widths; 10 / 11: the ring kernel (-4 = K < 128, not offered); 12: the 256 x 256 kernel (-4 = K < 128); 0: dispatch
+        codes = (1, 7, 8, 9, 10, 11, 12, 0)
         differ = [codes[i] for i, (rc, c) in enumerate(outs[1:], 1)
-                  if not ((rc == 0 and torch.equal(c1, c)) or (rc == -4 and i in (4, 5, 7) and K < 128))]
+                  if not ((rc == 0 and torch.equal(c1, c)) or (rc == -4 and i in (4, 5, 6) and K < 128))]
         same = rc1 == 0 and not differ
         err = ((c4.cpu().double() - ref).abs() / (ref.abs() + 1.0)).max().item() if rc4 == 0 else float("inf")
         ok = same and err < 4e-3

@@ -4,9 +4,9 @@ r03_kb_gemm_big.txt): large-v3 / base.en encoder and cross-K/V projections at 1,
 decode-step shapes, and every `force_kernel` code the hardware checks use."""
 import pytest
 
-TILED, SKINNY, GLDS128, GLDS64, RING64, RING128, BIG, BIG8 = range(8)
+TILED, SKINNY, GLDS128, GLDS64, RING64, RING128, BIG = range(7)
 BIAS, GELU, RES, OUT_F32 = 1, 2, 4, 8
-NO_RING, NO_BIG, USE_BIG8 = 65536, 131072, 2097152
+NO_RING, NO_BIG = 65536, 131072
 
 
 @pytest.fixture(scope="module")
@@ -43,18 +43,12 @@ def test_switches_and_forced_kernels(plan):
     assert plan(1500, 2560, 1280, flags=NO_RING) == GLDS128
     assert plan(30000, 3840, 1280, flags=NO_BIG) == GLDS128
     assert plan(30000, 3840, 1280, flags=NO_BIG | NO_RING) == GLDS128
-    # the half-tile-ring generation of the 256 x 256 kernel: exactly where the dispatch takes that kernel, nowhere else
-    assert plan(30000, 3840, 1280, flags=USE_BIG8) == BIG8 and plan(30000, 1280, 5120, BIAS | RES, flags=USE_BIG8) == BIG8
-    assert plan(30000, 1280, 1280, BIAS | RES, flags=USE_BIG8) == GLDS128 and plan(1500, 1280, 1280, flags=USE_BIG8) == RING64
-    assert plan(30000, 3840, 1280, flags=USE_BIG8 | NO_BIG) == GLDS128
-    assert plan(4500, 3840, 1280, force=13) == BIG8 and plan(1500, 1280, 64, force=13) == -4      # two K tiles at least
-    assert plan(3000, 1280, 1280, BIAS | OUT_F32, force=13) == -4
     for force, want in ((1, TILED), (7, GLDS128), (8, GLDS64), (9, GLDS128), (10, RING64), (11, RING128), (12, BIG)):
         assert plan(4500, 3840, 1280, force=force) == want, force
     assert plan(1500, 1280, 1280, force=7) == GLDS64 and plan(1500, 1280, 1280, force=9) == GLDS128
     assert plan(100, 1280, 1280, force=2) == SKINNY and plan(1500, 1280, 1280, force=2) == -4
     assert plan(1500, 1280, 64, force=10) == -4                            # the ring needs two K steps
-    assert plan(1500, 1280, 64, force=12) == BIG
+    assert plan(1500, 1280, 64, force=12) == -4 and plan(1500, 1280, 128, force=12) == BIG     # two K tiles in flight at least
     assert plan(3000, 1280, 1280, BIAS | OUT_F32, force=12) == -4          # not a plain epilogue
     assert plan(1500, 384, 288, force=7) == -4 and plan(1500, 384, 100) == -4
 

@@ -1,6 +1,6 @@
 """Batch invariance of the benchmarked configuration: large-v3 at full depth (32 + 32 layers), fp16,
 stable_ts_amd.BENCH_WEIGHTS, 20 windows x 5 beams x 112 decode steps -- the launch shapes bench.py times (M = 100 rows in
-gemm_dec_f16<3,40,*>, gemm_f16_big / attn_flash2_f16<.,4> in the encoder) -- against the SAME window run alone (M = 5 rows,
+gemm_dec_f16<3,40,*>, gemm_f16_big8 / attn_flash2_f16<.,4> in the encoder) -- against the SAME window run alone (M = 5 rows,
 ring / 128-tile GEMMs, 32 queries per wave), which is the shape tests/test_gpu_f16_depth.py pins to the f32 CPU oracle.
 Window k of the batch must equal window k alone: encoder output, decoded tokens of every beam, sum_logprobs, no-speech
 probability, token probabilities of the scoring pass, DTW path, word times -- bit for bit (every kernel variant computes an

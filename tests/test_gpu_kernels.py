@@ -306,9 +306,9 @@ def test_attention_decode_cross_kernel(B, H, nq, nk):
     assert err < 6e-3, err
 
 
-@pytest.mark.parametrize("check", ["gemm_glds_check.py", "mel_ragged_check.py", "score_qk_check.py"])
+@pytest.mark.parametrize("check", ["gemm_glds_check.py", "gemm_big8_check.py", "mel_ragged_check.py", "score_qk_check.py"])
 def test_new_kernel_paths_in_subprocess(check):
-    # gemm_f16_glds / gemm_f16_ring / gemm_f16_big (the direct-to-LDS tiled GEMMs vs the register-staged kernel: bit-identical) and
+    # gemm_f16_glds / gemm_f16_ring / gemm_f16_big8 (the direct-to-LDS tiled GEMMs vs the register-staged kernel: bit-identical) and
     # swx_log_mel_ragged (the un-padded spectrogram of refine / locate; index logic CPU-checked in test_mel_ragged_cpu),
     # swx_score_qk (raw per-head scores for the dynamic-heads / 'new' aligner variants; host logic CPU-checked).  Own
     # process: a first-ever hardware run of new device code must not be able to disturb this process's GPU context.
