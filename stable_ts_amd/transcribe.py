@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .stabilization import host_single_thread
-from .audio import HOP_LENGTH, N_FRAMES, N_SAMPLES, N_SAMPLES_PER_TOKEN, SAMPLE_RATE
+from .audio import CHUNK_LENGTH, HOP_LENGTH, N_FRAMES, N_SAMPLES, N_SAMPLES_PER_TOKEN, SAMPLE_RATE
 from .audio_io import AudioLoader, audioloader_not_supported, prep_audio
 from .decoding import DecodingOptions, DecodingPlan, DecodingResult
 from .result import WhisperResult
@@ -83,9 +83,19 @@ def _xkv_select(model, xkv, idx: Sequence[int]):
     return sel
 
 
+def _scaled_budget(options: DecodingOptions, seconds: Optional[float]) -> DecodingOptions:
+    """`min_tokens_follow_audio` (synthetic-weight benchmarking, decoding.py): the fixed decode length of a window of `seconds`
+    of audio, rounded up to a multiple of 8 so that the remainder windows of one round still form one lockstep job."""
+    if not (options.min_tokens and options.min_tokens_follow_audio) or seconds is None or seconds >= CHUNK_LENGTH:
+        return options
+    n = min(options.min_tokens, max(8, -(-int(np.ceil(options.min_tokens * max(seconds, 0.0) / CHUNK_LENGTH)) // 8) * 8))
+    return replace(options, min_tokens=n, sample_len=min(options.sample_len or n, n))
+
+
 def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float], prompts, ts_masks,
                           compression_ratio_threshold, logprob_threshold, no_speech_threshold,
-                          uids: Optional[Sequence[int]] = None, torch_rng: bool = False) -> List[DecodingResult]:
+                          uids: Optional[Sequence[int]] = None, torch_rng: bool = False,
+                          durations: Optional[Sequence[float]] = None) -> List[DecodingResult]:
     """original_whisper.py:349-393, for W windows: every window walks the temperature ladder independently; the ones that
     still need a fallback are re-decoded together at the next temperature.  ``torch_rng`` (the sequential driver, one window
     per call): sampled retries draw from torch's generator call for call like the reference's loop (Engine.decode), so with
@@ -102,10 +112,11 @@ def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float],
             kw.pop("best_of", None)
         options = DecodingOptions(**kw, temperature=t)
         sub = _xkv_select(model, xkv, pending)
-        plans = [DecodingPlan(model, replace(options, prompt=(list(prompts[w]) if prompts[w] else None))) for w in pending]
+        plans = [DecodingPlan(model, _scaled_budget(replace(options, prompt=(list(prompts[w]) if prompts[w] else None)),
+                                                    None if durations is None else durations[w])) for w in pending]
         groups = {}
         for k, p in enumerate(plans):
-            groups.setdefault(p.sample_begin, []).append(k)
+            groups.setdefault((p.sample_begin, p.sample_len, p.options.min_tokens), []).append(k)
         outs: List[Optional[DecodingResult]] = [None] * len(pending)
         for _, ks in groups.items():       # one lockstep job per distinct initial length
             sub_k = _xkv_select(model, sub, ks)
@@ -225,7 +236,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict, pre: Optional[d
     results = _decode_with_fallback(model, xkv, o["decode_options"], o["temperatures"], [b["prompt"] for b in batch],
                                     ts_masks, o["compression_ratio_threshold"], o["logprob_threshold"],
                                     o["no_speech_threshold"], uids=[int(b["seek_sample"]) // 160 for b in batch],
-                                    torch_rng=bool(o.get("torch_sampling")))
+                                    torch_rng=bool(o.get("torch_sampling")), durations=[n / SAMPLE_RATE for n in seg_samples])
     t_ph = _phase("decode (device loop + result copy)", t_ph)
     time_precision = (N_FRAMES // model.dims.n_audio_ctx) * HOP_LENGTH / SAMPLE_RATE
     punct = o["prepend_punctuations"] + o["append_punctuations"]
