@@ -83,13 +83,20 @@ def _xkv_select(model, xkv, idx: Sequence[int]):
     return sel
 
 
-def _scaled_budget(options: DecodingOptions, seconds: Optional[float]) -> DecodingOptions:
-    """`min_tokens_follow_audio` (synthetic-weight benchmarking, decoding.py): the fixed decode length of a window of `seconds`
-    of audio, rounded up to a multiple of 8 so that the remainder windows of one round still form one lockstep job."""
-    if not (options.min_tokens and options.min_tokens_follow_audio) or seconds is None or seconds >= CHUNK_LENGTH:
-        return options
-    n = min(options.min_tokens, max(8, -(-int(np.ceil(options.min_tokens * max(seconds, 0.0) / CHUNK_LENGTH)) // 8) * 8))
-    return replace(options, min_tokens=n, sample_len=min(options.sample_len or n, n))
+def _scaled_budgets(options: DecodingOptions, seconds: Optional[Sequence[float]]) -> List[DecodingOptions]:
+    """`min_tokens_follow_audio` (synthetic-weight benchmarking, decoding.py): the fixed decode length of every window of one call.
+    Windows of at least half a chunk keep the full length (one lockstep job, as without the switch -- spans cut at quiet places
+    are 25-35 s long); the shorter ones -- the remainders the sequential / span drivers leave behind a seek advance -- share ONE
+    job whose length is the longest remainder's pro-rata share, rounded up to a multiple of 8."""
+    n_win = 0 if seconds is None else len(seconds)
+    if not (options.min_tokens and options.min_tokens_follow_audio) or not n_win:
+        return [options] * max(n_win, 1)
+    short = [s_ for s_ in seconds if s_ < CHUNK_LENGTH / 2]
+    if not short:
+        return [options] * n_win
+    n = min(options.min_tokens, max(8, -(-int(np.ceil(options.min_tokens * max(max(short), 0.0) / CHUNK_LENGTH)) // 8) * 8))
+    small = replace(options, min_tokens=n, sample_len=min(options.sample_len or n, n))
+    return [small if s_ < CHUNK_LENGTH / 2 else options for s_ in seconds]
 
 
 def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float], prompts, ts_masks,
@@ -112,8 +119,9 @@ def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float],
             kw.pop("best_of", None)
         options = DecodingOptions(**kw, temperature=t)
         sub = _xkv_select(model, xkv, pending)
-        plans = [DecodingPlan(model, _scaled_budget(replace(options, prompt=(list(prompts[w]) if prompts[w] else None)),
-                                                    None if durations is None else durations[w])) for w in pending]
+        budgets = _scaled_budgets(options, None if durations is None else [durations[w] for w in pending])
+        plans = [DecodingPlan(model, replace(budgets[k] if durations is not None else options,
+                                             prompt=(list(prompts[w]) if prompts[w] else None))) for k, w in enumerate(pending)]
         groups = {}
         for k, p in enumerate(plans):
             groups.setdefault((p.sample_begin, p.sample_len, p.options.min_tokens), []).append(k)

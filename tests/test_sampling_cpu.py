@@ -76,17 +76,20 @@ def test_cuda_generator_offsets_are_available():
 
 def test_min_tokens_follow_audio_scales_the_fixed_decode_length():
     """DecodingOptions.min_tokens_follow_audio (synthetic-weight benchmarking, like min_tokens): the fixed decode length is per 30 s
-    of audio; windows of a round are grouped into lockstep jobs by that length."""
+    of audio for the REMAINDER windows of a call (shorter than half a chunk), which share one lockstep job; the others keep the
+    full length."""
     from stable_ts_amd.decoding import DecodingOptions
-    from stable_ts_amd.transcribe import _scaled_budget
+    from stable_ts_amd.transcribe import _scaled_budgets
     o = DecodingOptions(sample_len=112, min_tokens=112, min_tokens_follow_audio=True)
-    assert _scaled_budget(o, 30.0) is o and _scaled_budget(o, None) is o
-    for sec, want in ((0.0, 8), (0.4, 8), (2.0, 8), (2.2, 16), (15.0, 56), (28.0, 112), (29.9, 112)):
-        got = _scaled_budget(o, sec)
-        assert (got.min_tokens, got.sample_len) == (want, want), (sec, got.min_tokens, got.sample_len)
+    assert _scaled_budgets(o, [30.0, 26.0, 15.0]) == [o, o, o] and _scaled_budgets(o, None) == [o]
+    got = _scaled_budgets(o, [30.0, 0.4, 27.5, 6.1, 2.0])
+    assert [g.min_tokens for g in got] == [112, 24, 112, 24, 24] and [g.sample_len for g in got] == [112, 24, 112, 24, 24]
+    for sec, want in ((0.0, 8), (2.0, 8), (2.2, 16), (14.9, 56)):
+        g = _scaled_budgets(o, [sec])[0]
+        assert (g.min_tokens, g.sample_len) == (want, want), (sec, g.min_tokens)
     plain = DecodingOptions(sample_len=112, min_tokens=112)
-    assert _scaled_budget(plain, 1.0) is plain                          # without the switch nothing changes
-    assert _scaled_budget(DecodingOptions(sample_len=40, min_tokens=112, min_tokens_follow_audio=True), 29.0).sample_len == 40
+    assert _scaled_budgets(plain, [1.0, 30.0]) == [plain, plain]          # without the switch nothing changes
+    assert _scaled_budgets(DecodingOptions(sample_len=40, min_tokens=112, min_tokens_follow_audio=True), [14.0])[0].sample_len == 40
 
 
 def test_remainder_windows_decode_pro_rata(monkeypatch):
