@@ -10,7 +10,7 @@ Default mode (``--mode transcribe``): one "step" = one full pass of model.transc
   window-parallel batches, fixed decode budget per window (sample_len = min_tokens = 112: random weights have no
   meaningful EOT -- BASELINE.md section 3), temperature 0 without fallback thresholds.  The random weights are shaped
   (stable_ts_amd.BENCH_WEIGHTS: token-embedding gain 9, cross-attention score gain 8, LayerNorm jitter 0.1, timestamp rows
-  x0.01 -- the SAME recipe tests/test_gpu_f16_depth.py holds fp16 to the north-star tolerances on, at full depth, 112 steps,
+  x0.1 -- the SAME recipe tests/test_gpu_f16_depth.py holds fp16 to the north-star tolerances on, at full depth, 112 steps,
   and tests/test_gpu_batch_invariance.py chains the 20-window batch to) so that every window's transcript keeps ~111 TEXT tokens: the
   word-timestamp stage (teacher-forced scoring pass, attention weights, DTW) then runs at the length a real transcript
   has (reference: timing.py:202-306 sees ~100-225 tokens per window); ``config.words`` / ``config.text_tokens_per_window``

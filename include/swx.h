@@ -132,7 +132,8 @@ typedef struct swx_decode_cfg {
                                      computes as argmax(p / q) with q ~ Exp(1).  When the caller fills the array from the
                                      framework's generator -- one exponential call per step on [W * G][n_vocab], as the
                                      reference's decoding loop makes them -- the sampled tokens are the reference's for the
-                                     same seed; the counter-based hash above is not used. */
+                                     same seed; the counter-based hash above is not used.  HBM cost: sample_len * W * G * n_vocab
+                                     * 4 bytes (232 MB for large-v3 at sample_len 224, best_of 5), read once per step. */
 } swx_decode_cfg;
 
 /* runs the whole loop; outputs (device):
@@ -260,7 +261,8 @@ int swx_prof_enable(int on);
 int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);
 /* how swx_decode ran on this handle so far: out[0] = two-step graphs captured, out[1] = graph replays (2 decode steps each),
- * out[2] = decode steps launched eagerly, out[3] = 1 if capture / replay failed once (the handle then launches eagerly) */
+ * out[2] = decode steps launched eagerly, out[3] = 1 if a capture / replay failed at least once on this handle (that job ran
+ * eagerly; the handle keeps trying graphs for later jobs and switches replay off for good after the third failure) */
 int swx_graph_stats(const swx_model *m, int64_t *out);
 
 /* ---- building blocks exported for the parity tests (same kernels the calls above launch) */

@@ -145,19 +145,30 @@ def _source_bytes(source: Union[str, bytes]) -> bytes:
 
 
 def is_flac(source: Union[str, bytes]) -> bool:
-    """native FLAC stream (an ID3v2 tag in front of the marker, which some taggers write, is skipped by ``read_flac``)"""
+    """native FLAC stream (an ID3v2 tag in front of the marker, which some taggers write, is skipped by ``read_flac``).
+    Reads 10 bytes, and 4 more behind an ID3v2 tag: never the whole file (most MP3s start with such a tag)."""
     try:
         with _open_binary(source) as f:
             head = f.read(10)
-    except OSError:
+            if head[:4] == b"fLaC":
+                return True
+            if head[:3] != b"ID3" or len(head) < 10:
+                return False
+            f.seek(10 + _id3_size(head))
+            return f.read(4) == b"fLaC"
+    except (OSError, ValueError):
         return False
-    return head[:4] == b"fLaC" or (head[:3] == b"ID3" and _skip_id3(_source_bytes(source))[:4] == b"fLaC")
+
+
+def _id3_size(head: bytes) -> int:
+    """bytes of an ID3v2 tag behind its 10-byte header (sync-safe size + the optional footer)"""
+    size = ((head[6] & 0x7F) << 21) | ((head[7] & 0x7F) << 14) | ((head[8] & 0x7F) << 7) | (head[9] & 0x7F)
+    return size + (10 if head[5] & 0x10 else 0)
 
 
 def _skip_id3(data: bytes) -> bytes:
     if data[:3] == b"ID3" and len(data) >= 10:
-        size = ((data[6] & 0x7F) << 21) | ((data[7] & 0x7F) << 14) | ((data[8] & 0x7F) << 7) | (data[9] & 0x7F)
-        return data[10 + size + (10 if data[5] & 0x10 else 0):]
+        return data[10 + _id3_size(data):]
     return data
 
 
@@ -196,7 +207,14 @@ def read_flac(source: Union[str, bytes], verify_md5: bool = True) -> Tuple[np.nd
         total_unknown = True
     else:
         total_unknown = False
-    pcm = np.empty((frames, info.channels), dtype=np.int32)
+    # STREAMINFO is untrusted: a frame holds at most 65 535 samples per channel and takes at least 11 bytes (sync + header +
+    # CRCs + one constant subframe per channel), so a stream of len(data) bytes cannot hold more than this many sample frames
+    if frames > (len(data) // 11 + 1) * 65535:
+        raise RuntimeError(f"Failed to load audio: FLAC header declares {frames} sample frames in a {len(data)}-byte stream")
+    try:
+        pcm = np.empty((frames, info.channels), dtype=np.int32)
+    except MemoryError as e:
+        raise RuntimeError(f"Failed to load audio: {frames} sample frames do not fit in memory") from e
     n = int(lib.swx_flac_decode(data, len(data), pcm.ctypes.data, frames, ctypes.byref(info)))
     if n < 0:
         raise RuntimeError(f"Failed to load audio: {lib.swx_strerror(n).decode()}")

@@ -281,6 +281,9 @@ class Engine:
         if rng is not None:
             gen, off0, inc = rng
             gen.set_offset(off0 + inc * reference_loop_iterations(out["lens"], n_init, int(sample_len), self.dims.n_text_ctx))
+            # [sample_len][W * G][n_vocab] f32 = 232 MB for large-v3 at best_of 5: back to torch's caching allocator (the next
+            # sampled retry gets the same block without a hipMalloc; other tensors may use it in between)
+            self._noise_buf = None
         return out
 
     def _draw_noise(self, steps: int, rows: int):

@@ -1,7 +1,7 @@
 """fp16 -- the dtype bench.py times and the reference itself runs on a GPU (whisper_word_level/original_whisper.py:250-259) --
 pinned against the f32 CPU ORACLE at the FULL depth of the benchmarked model (large-v3: 32 + 32 layers, d = 1280, 20 heads,
 128 mels, 51 866 tokens) ON THE WEIGHTS bench.py TIMES (stable_ts_amd.BENCH_WEIGHTS -- one recipe for the benchmark and for
-these tests since round 4: token-embedding gain 9, cross-attention score gain 8, LayerNorm jitter 0.1, timestamp rows x0.01)
+these tests since round 4: token-embedding gain 9, cross-attention score gain 8, LayerNorm jitter 0.1, timestamp rows x0.1)
 and AT THE BENCHMARK'S LENGTH (112 decode steps, beam 5: VERDICT r3 item 1).  Rounding accumulates over 64 layers and over
 112 steps of beam bookkeeping; the 2-layer tests of test_gpu_largev3.py cannot see that.
 

@@ -11,9 +11,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
-# tests named test_inner_* exercise device paths that have not run on hardware yet; they run in a child pytest process
-# (test_pending_device_paths_in_subprocess) so that a device fault there cannot take the validated tests down with it
-INNER = os.environ.get("SWX_INNER_TESTS") == "1"
+# tests named test_inner_* ran in a child pytest process while their device paths were new (rounds 3-4); validated on hardware
+# since (GPUTEST_r03 / r04), they are ordinary tests now
 
 
 def _golden():
@@ -177,7 +176,6 @@ def test_refinement_func_matches_reference_seam_b3():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
 def test_inner_transcribe_spans_equals_sequential_per_span():
     # transcribe_spans (the sequential algorithm on several spans in lockstep batches, spans.py) == model.transcribe on
     # each span separately: the property SURVEY.md 8e states for the span-sharded mode, through the C ABI, no oracle
@@ -207,7 +205,6 @@ def test_inner_transcribe_spans_equals_sequential_per_span():
             assert abs(wa["start"] - wb["start"]) < 2e-3 and abs(wa["end"] - wb["end"]) < 2e-3
 
 
-@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
 @pytest.mark.parametrize("name", ["tiny_en_dynamic_heads", "tiny_en_new_aligner"])
 def test_inner_transcribe_variants_match_reference_glue(name):
     # dynamic heads / the 'new' aligner (timing.py:87-103, 115-163): the reference's transcribe on the oracle
@@ -230,7 +227,6 @@ def test_inner_transcribe_variants_match_reference_glue(name):
             assert abs(wa["probability"] - wb["probability"]) <= 1e-3 * max(wb["probability"], 1e-3) + 1e-9
 
 
-@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
 def test_inner_locate_matches_reference_glue():
     # the reference's locate (alignment.py:756-1116, modes 2 / 1 / 0) on the oracle model vs this package on the device
     import importlib.util
@@ -264,7 +260,6 @@ def test_inner_locate_matches_reference_glue():
         close(got, want, str(kw))
 
 
-@pytest.mark.skipif(not INNER, reason="first hardware run pending: runs inside test_pending_device_paths_in_subprocess")
 def test_inner_sampled_decoding_follows_torch_generator():
     """temperature > 0 in the reference's own control flow (one window per decode call) is SAMPLE-exact, not only
     distribution-equal: upstream GreedyDecoder.update draws Categorical(logits / T).sample() = argmax(p / q), q = one
@@ -330,19 +325,6 @@ def test_inner_sampled_decoding_follows_torch_generator():
         assert gen.get_offset() == off
     finally:
         od.Categorical = real
-
-
-@pytest.mark.parametrize("inner", ["test_inner_transcribe_spans_equals_sequential_per_span",
-                                   "test_inner_transcribe_variants_match_reference_glue",
-                                   "test_inner_locate_matches_reference_glue",
-                                   "test_inner_sampled_decoding_follows_torch_generator"])
-def test_pending_device_paths_in_subprocess(inner):
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, "-m", "pytest", f"{os.path.abspath(__file__)}::{inner}", "-q", "-x", "-m", "gpu",
-                        "-p", "no:cacheprovider"], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, SWX_INNER_TESTS="1"), cwd=os.path.dirname(HERE))
-    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1500:])
 
 
 @pytest.mark.parametrize("name", ["default_thresholds", "both_ends", "coarse_rel", "starts_only"])
