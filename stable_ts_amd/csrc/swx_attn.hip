@@ -491,6 +491,221 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a) { attn_
 template <int FQ>
 __global__ __launch_bounds__(256, 2) void attn_decode_cross_xq_f16(AttnArgs a) { attn_decode_cross_body<true, 1, FQ>(a); }
 
+// ================================================================================================ flash f32 (round 5)
+// Strict-f32 mode on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32: f32 operands, f32 accumulate).  Until round 5 every
+// f32 attention ran on the VALU kernel below -- 23.8 ms per encoder layer at 20 windows (9.7 TFLOP/s) and 118 us per decode-step
+// cross-attention (2.6 TB/s): 1.2 s of the 3.1-s strict pass (profiles/r05_c1_f32pass_kernels.csv).  Same structure as the f16
+// kernel: swapped QK^T (S^T = K.Q^T: a lane's four accumulator values belong to ONE query, row statistics = lane-local + two
+// shuffles, the exponentiated tile is already the B operand of O^T += V^T.P^T), K / V tiles of 64 keys double-buffered in LDS,
+// the next tile's global loads in registers under the current tile's MFMAs.  The k index of a 16 x 16 x 4 instruction is a
+// summation index: k-slot g of step (t, e) stands for d = 16 g + 4 t + e (QK^T: one 16-byte LDS read per lane and t) and for
+// key 4 g + e of the 16-key block (PV: the S^T accumulator element e IS that key's probability).
+//   SPLIT = false: a wave owns 32 queries (two 16-query blocks), the workgroup 128; every wave walks all four 16-key blocks.
+//   SPLIT = true (nq <= 16: the decode step's cross-attention, HBM-bound): the four waves share ONE 16-query block and take one
+//   16-key block of every tile each; the four partial (max, sum, O) states are merged through LDS at the end.
+// V row-major [key][d] (encoder: the fused QKV buffer) or transposed [d][key] (VT: the cross-K/V layout, keys zero padded).
+constexpr int F32_KT = 64;           // keys per tile
+constexpr int F32_LD = 68;           // floats per LDS row: 16-byte fragment reads of 16 consecutive rows cover all 64 banks
+constexpr size_t F32_LDS_BYTES = (size_t)4 * F32_KT * F32_LD * sizeof(float);
+
+template <bool VT, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void attn_flash_f32(AttnArgs a)
+{
+    constexpr int QB = SPLIT ? 1 : 2;            // 16-query blocks per wave
+    constexpr int KB = SPLIT ? 1 : 4;            // 16-key blocks of a tile per wave
+    extern __shared__ __attribute__((aligned(16))) float f32_smem[];
+    float (*Ks)[F32_KT][F32_LD] = (float (*)[F32_KT][F32_LD])f32_smem;                                   // [buf][key][d]
+    float (*Vs)[F32_KT][F32_LD] = (float (*)[F32_KT][F32_LD])(f32_smem + 2 * F32_KT * F32_LD);           // [buf][key][d] or, VT, [buf][d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = SPLIT ? blockIdx.x * 16 : blockIdx.x * 128 + wave * 32;
+    const int qn = lane & 15, g = lane >> 4;
+    const float *Q = (const float *)a.q;
+    const float *K = (const float *)a.k + (size_t)b * a.k_bs + h * DH;
+    const float *V = (const float *)a.v + (size_t)b * a.v_bs + (VT ? (size_t)h * DH * a.vt_kp : (size_t)h * DH);
+
+    f32x4 qf[QB][4];                              // Q[query qn][d = 16 g + 4 t + e]
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + qb * 16 + qn;
+        const float *qp = Q + ((size_t)b * a.q_rows_per_batch + (qi < a.nq ? qi : a.nq - 1)) * a.ldq + h * DH + g * 16;   // clamped
+#pragma unroll
+        for (int t = 0; t < 4; ++t) qf[qb][t] = *(const f32x4 *)(qp + 4 * t);
+    }
+    f32x4 o[QB][4];
+    float m_run[QB], l_run[QB];                   // l_run: this LANE's share of the row sum (its four keys per block), reduced at the end
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -__builtin_inff(); l_run[qb] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[qb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    // staging registers of one tile: thread -> rows (tid >> 4) + 16 i, floats (tid & 15) * 4 .. + 3
+    const int sr = tid >> 4, sc4 = (tid & 15) * 4;
+    f32x4 rk[4], rv[4];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = sr + 16 * i;
+            const int kg = kt0 + r;
+            const int kgc = kg < a.nk ? kg : a.nk - 1;                      // clamped, never predicated
+            rk[i] = *(const f32x4 *)(K + (size_t)kgc * a.ldkv + sc4);
+            if (kg >= a.nk) rk[i] = zero4;
+            if constexpr (VT) {
+                rv[i] = *(const f32x4 *)(V + (size_t)r * a.vt_kp + kt0 + sc4);          // row = d; zero padded past nk in the source
+            } else {
+                rv[i] = *(const f32x4 *)(V + (size_t)kgc * a.ldkv + sc4);
+                if (kg >= a.nk) rv[i] = zero4;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4 *)&Ks[buf][sr + 16 * i][sc4] = rk[i];
+            *(f32x4 *)&Vs[buf][sr + 16 * i][sc4] = rv[i];
+        }
+    };
+
+    const int ntile = (a.nk + F32_KT - 1) / F32_KT;
+    const bool active = SPLIT || q0 < a.nq;       // wave-uniform: a wave without queries only stages tiles
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int cur = t & 1, kt0 = t * F32_KT;
+        if (t + 1 < ntile) load_tile(kt0 + F32_KT);
+        if (active) {
+            f32x4 sc[QB][KB];
+#pragma unroll
+            for (int kbi = 0; kbi < KB; ++kbi) {
+                const int kb = SPLIT ? wave : kbi;
+                f32x4 kf[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) kf[tt] = *(const f32x4 *)&Ks[cur][kb * 16 + qn][g * 16 + 4 * tt];
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[tt][e], qf[qb][tt][e], acc, 0, 0, 0);
+                    sc[qb][kbi] = acc;             // S^T[key kb*16 + 4 g + r][query qn], r = 0..3
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                float tmax = -__builtin_inff();
+#pragma unroll
+                for (int kbi = 0; kbi < KB; ++kbi) {
+                    const int kb = SPLIT ? wave : kbi;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = sc[qb][kbi][r] * 0.125f;
+                        if (kt0 + kb * 16 + g * 4 + r >= a.nk) v = -__builtin_inff();
+                        sc[qb][kbi][r] = v;
+                        tmax = fmaxf(tmax, v);
+                    }
+                }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float m_new = fmaxf(m_run[qb], tmax);
+                const float m_use = m_new == -__builtin_inff() ? 0.f : m_new;      // a wave whose keys are all masked so far (SPLIT)
+                const float alpha = expf(m_run[qb] - m_use);                        // m_run = -inf -> 0
+                float psum = 0.f;
+#pragma unroll
+                for (int kbi = 0; kbi < KB; ++kbi)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = expf(sc[qb][kbi][r] - m_use);
+                        sc[qb][kbi][r] = p;
+                        psum += p;
+                    }
+                l_run[qb] = l_run[qb] * alpha + psum;
+                m_run[qb] = m_new;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) { o[qb][tt][0] *= alpha; o[qb][tt][1] *= alpha; o[qb][tt][2] *= alpha; o[qb][tt][3] *= alpha; }
+            }
+            // O^T[d][query] += V^T[d][key] P^T[key][query]: k-slot g of step r <-> key kb*16 + 4 g + r
+#pragma unroll
+            for (int kbi = 0; kbi < KB; ++kbi) {
+                const int kb = SPLIT ? wave : kbi;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    f32x4 vf;
+                    if constexpr (VT) {
+                        vf = *(const f32x4 *)&Vs[cur][tt * 16 + qn][kb * 16 + g * 4];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vf[r] = Vs[cur][kb * 16 + g * 4 + r][tt * 16 + qn];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int qb = 0; qb < QB; ++qb)
+                            o[qb][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[r], sc[qb][kbi][r], o[qb][tt], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < ntile) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    if constexpr (!SPLIT) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            float l = l_run[qb];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const int qi = q0 + qb * 16 + qn;
+            if (active && qi < a.nq) {
+                const float inv = 1.0f / l;
+                float *op = (float *)a.o + ((size_t)b * a.q_rows_per_batch + qi) * a.ldo + h * DH;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = o[qb][t][r] * inv;
+                    *(f32x4 *)(op + t * 16 + g * 4) = ov;          // O^T[d = 16 t + 4 g + r][query qn]
+                }
+            }
+        }
+    } else {
+        // merge the four waves' states (the loop's last barrier has passed: the tiles are dead) -- [wave][18][64]: max, lane sum, O
+        float *sm = f32_smem;
+        sm[(wave * 18 + 0) * 64 + lane] = m_run[0];
+        sm[(wave * 18 + 1) * 64 + lane] = l_run[0];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sm[(wave * 18 + 2 + t * 4 + r) * 64 + lane] = o[0][t][r];
+        __syncthreads();
+        float mw[4], M = -__builtin_inff();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { mw[w] = sm[(w * 18 + 0) * 64 + lane]; M = fmaxf(M, mw[w]); }
+        float l = 0.f;
+        f32x4 ov = (f32x4){0.f, 0.f, 0.f, 0.f};                    // this wave finishes d-tile `wave`
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float sc_w = expf(mw[w] - M);                     // -inf (nothing seen) -> 0
+            l += sm[(w * 18 + 1) * 64 + lane] * sc_w;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] += sm[(w * 18 + 2 + wave * 4 + r) * 64 + lane] * sc_w;
+        }
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int qi = q0 + qn;
+        if (qi < a.nq) {
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] *= inv;
+            *(f32x4 *)((float *)a.o + ((size_t)b * a.q_rows_per_batch + qi) * a.ldo + h * DH + wave * 16 + g * 4) = ov;
+        }
+    }
+}
+
 // ============================================================================================ dense rowwise
 constexpr int RW_QB = 8;
 constexpr int RW_MAXK = 1536;
@@ -970,7 +1185,26 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         else if (qb == 4) hipLaunchKernelGGL((attn_flash2_f16<true, 4>), g, dim3(256), 0, s, a);
         else if (qb == 3) hipLaunchKernelGGL((attn_flash2_f16<true, 3>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_flash2_f16<true, 2>), g, dim3(256), 0, s, a);
+    } else if (dtype == SWX_F32 && (force_kernel == 0 || force_kernel == 7) && a.vt_kp % F32_KT == 0) {
+        // strict f32 on the exact-f32 matrix instruction: queries <= 16 per batch item (decode step: HBM-bound, the four waves split
+        // the keys) or blocks of 128 queries (encoder self-attention, scoring pass: MFMA-bound)
+        const bool split = a.nq <= 16;
+        SwxProfScope prof(split ? PC_ATTN_ROWWISE : PC_ATTN_FLASH,
+                          split ? (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq) : 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
+        dim3 gd(split ? 1 : cdiv(a.nq, 128), a.H, a.B);
+#define SWX_F32_FLASH(VT_, SP_) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { \
+            hipError_t e_ = hipFuncSetAttribute((const void *)attn_flash_f32<VT_, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F32_LDS_BYTES); \
+            if (e_ != hipSuccess) return -100 - (int)e_; \
+            attr_done = true; \
+        } \
+        hipLaunchKernelGGL((attn_flash_f32<VT_, SP_>), gd, dim3(256), F32_LDS_BYTES, s, a); } while (0)
+        if (a.vt_kp) { if (split) SWX_F32_FLASH(true, true); else SWX_F32_FLASH(true, false); }
+        else { if (split) SWX_F32_FLASH(false, true); else SWX_F32_FLASH(false, false); }
+#undef SWX_F32_FLASH
     } else {
+        if (force_kernel == 7) return -5;
         // algorithmic bytes: K and V of every (window, head) once + q in + o out
         SwxProfScope prof(PC_ATTN_ROWWISE, (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq), s);
         dim3 g(cdiv(a.nq, RW_QB), a.H, a.B);

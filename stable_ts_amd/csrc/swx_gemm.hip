@@ -869,6 +869,92 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
                 epilogue_store<float>(g, m0 + wm * WROWS + i * 16 + row_l + r, n0 + wn * WCOLS + j * 16 + col_l, acc[i][j][r]);
 }
 
+// ------------------------------------------------------------------------------------------------ f32, few rows (round 5)
+// The strict-f32 launches with at most 128 rows (decode step at 100 rows, prefill, one window's scoring pass) on 64 x 16 NJ tiles:
+// the arithmetic of gemm_f32_tiled element for element (one accumulator, K ascending in steps of 4, k-slot g of step s = k 4 s + g:
+// bit-identical, tests/test_gpu_kernels.py), restaged.  gemm_f32_tiled<64, 16 | 32> spent a barrier, a scalar LDS round trip and
+// 17-word rows on every 16-deep K step (4 MFMAs = 128 MFMA clocks per ~1 000-clock step: 36-64 us for a K = 1280 launch, 1.2 s of
+// the 3.1-s strict pass, profiles/r05_c1_f32pass_kernels.csv).  Here a K chunk is 64 deep (16 NJ MFMAs per wave and barrier), a
+// thread stages 16 consecutive k of one row (four 16-byte loads, two chunks ahead in registers) and writes them TRANSPOSED 4 x 4
+// in registers -- LDS position 16 t + 4 g + e holds k = 16 t + 4 e + g -- so that the four steps 4 t .. 4 t + 3 of a lane's k-slot
+// are ONE 16-byte LDS read; rows of 68 words keep those reads and the 16-byte writes conflict-free.
+constexpr int R64_LD = 68;
+template <int NJ>
+__global__ __launch_bounds__(256) void gemm_f32_rows64(GemmArgs g)
+{
+    constexpr int BNT = 16 * NJ;
+    __shared__ __attribute__((aligned(16))) float As[2][64][R64_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BNT][R64_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BNT;
+    const float *A = (const float *)g.A;
+    const float *W = (const float *)g.W;
+    // staging: thread -> (row = tid >> 2, 16-k group = tid & 3) of the A tile and, the first 4 BNT threads, of the B tile
+    const int srow = tid >> 2, sgrp = tid & 3;
+    const bool a_ok = m0 + srow < g.M;
+    const bool b_thr = tid < 4 * BNT, b_ok = b_thr && n0 + srow < g.N;
+    const float *ap = A + (size_t)(a_ok ? m0 + srow : 0) * g.lda + sgrp * 16;
+    const float *wp = W + (size_t)(b_ok ? n0 + srow : 0) * g.ldw + sgrp * 16;
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = zero4;
+    f32x4 ra[2][4], rb[2][4];
+    auto load_regs = [&](int st, int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ra[st][e] = a_ok ? *(const f32x4 *)(ap + k0 + 4 * e) : zero4;
+            rb[st][e] = b_ok ? *(const f32x4 *)(wp + k0 + 4 * e) : zero4;
+        }
+    };
+    auto store_lds = [&](int st, int buf) {
+        // registers hold k = 16 sgrp + 4 e + i as ra[st][e][i]; LDS position 16 sgrp + 4 i + e
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4 *)&As[buf][srow][16 * sgrp + 4 * i] = (f32x4){ra[st][0][i], ra[st][1][i], ra[st][2][i], ra[st][3][i]};
+            if (b_thr) *(f32x4 *)&Bs[buf][srow][16 * sgrp + 4 * i] = (f32x4){rb[st][0][i], rb[st][1][i], rb[st][2][i], rb[st][3][i]};
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 a4 = *(const f32x4 *)&As[buf][wave * 16 + fr][16 * t + 4 * fg];
+            f32x4 b4[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b4[j] = *(const f32x4 *)&Bs[buf][j * 16 + fr][16 * t + 4 * fg];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[j][e], acc[j], 0, 0, 0);
+        }
+    };
+
+    const int KC = g.K / 64;
+    load_regs(0, 0);
+    if (KC > 1) load_regs(1, 64);
+    store_lds(0, 0);
+    __syncthreads();
+    for (int c0 = 0; c0 < KC; c0 += 2) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                       // (unrolled: the register stages are compile-time indices)
+            const int c = c0 + u;
+            if (c < KC) {
+                if (c + 2 < KC) load_regs(u, (c + 2) * 64);          // stage u went to LDS at the end of step c - 1
+                compute(c & 1);
+                if (c + 1 < KC) store_lds(u ^ 1, (c + 1) & 1);
+                __syncthreads();
+            }
+        }
+    }
+    const int col_l = lane & 15, row_l = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) epilogue_store<float>(g, m0 + wave * 16 + row_l + r, n0 + j * 16 + col_l, acc[j][r]);
+}
+
 // ----------------------------------------------------------------------------------------------- skinny f16
 // HBM-bound weight streaming for the decode steps.  Workgroup = one 16-column weight panel, its 4 waves split K.
 // Per wave the K slice is walked in chunks of CH k-steps with a two-deep register pipeline: the 16-byte weight
@@ -1036,7 +1122,11 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
         // few rows (decode step, prefill, a single window's scoring pass): 64 x 32 or 64 x 16 tiles spread the launch over
         // 160-320 workgroups instead of N / 128 = 10-40 (one CU's exact-f32 MFMA rate is 0.6 TFLOP/s); bit-identical either way,
         // so the choice may depend on the launch
-        if (g.M <= BM && g.N >= 256) {
+        if (g.M <= BM && g.N >= 256 && g.K % 64 == 0 && force_kernel != 8) {
+            // (round 5) the same tiles on 64-deep K chunks; force_kernel 8 keeps the 16-deep generation as its bit-identity reference
+            if (g.N >= 2560) hipLaunchKernelGGL((gemm_f32_rows64<2>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(256), 0, s, g);
+            else hipLaunchKernelGGL((gemm_f32_rows64<1>), dim3(cdiv(g.N, 16), cdiv(g.M, 64)), dim3(256), 0, s, g);
+        } else if (g.M <= BM && g.N >= 256) {
             if (g.N >= 2560) hipLaunchKernelGGL((gemm_f32_tiled<64, 32, 4>), dim3(cdiv(g.N, 32), cdiv(g.M, 64)), dim3(256), 0, s, g);
             else hipLaunchKernelGGL((gemm_f32_tiled<64, 16, 4>), dim3(cdiv(g.N, 16), cdiv(g.M, 64)), dim3(256), 0, s, g);
         } else {

@@ -214,6 +214,26 @@ def test_gemm_f32_exact_mode(M, N, K):
     assert ((c.double() - ref).abs() <= 3e-6 * bound + 1e-6).all()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(100, 1280, 1280, 1), (100, 5120, 1280, 1 | 2), (100, 1280, 5120, 1 | 4), (5, 3840, 1280, 1),
+                                       (128, 256, 64, 0), (37, 2570, 384, 1), (65, 300, 192, 1), (100, 51866, 128, 1)])
+def test_gemm_f32_few_rows_is_bit_identical_to_the_16_deep_generation(M, N, K, epi):
+    # gemm_f32_rows64 (64-deep K chunks, 4 x 4 register transpose, 16-byte LDS reads; round 5) vs gemm_f32_tiled<64, .> (force 8): the
+    # same accumulator order element for element, so EQUAL bits -- with bias / GELU / residual, ragged N and M, 1-3 row blocks
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a = torch.randn(M, K, generator=g).cuda()
+    w = torch.randn(N, K, generator=g).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).cuda() if epi & 4 else None
+    new = _gemm(0, a, w, bias=bias if epi & 1 else None, res=res, epi=epi)
+    old = _gemm(0, a, w, bias=bias if epi & 1 else None, res=res, epi=epi, force=8)
+    assert torch.equal(new, old), (new - old).abs().max().item()
+    ref = a.double() @ w.double().T + (bias.double() if epi & 1 else 0)
+    if not epi & 2:
+        ref = ref + (res.double() if epi & 4 else 0)
+        bound = a.double().abs() @ w.double().abs().T + bias.double().abs() + 1
+        assert ((new.double() - ref).abs() <= 3e-6 * bound + 1e-6).all()
+
+
 def test_gemm_epilogues():
     g = torch.Generator().manual_seed(3)
     M, N, K = 200, 256, 128
@@ -291,6 +311,12 @@ def test_attention_kernels(B, H, nq, nk):
             assert err < 6e-3, (force, kp, err)
     o = _attn(0, q.cuda(), k.cuda(), v.cuda(), 1, 1536)
     assert (o.cpu().double() - ref).abs().max().item() < 2e-5
+    # f32 on the exact-f32 matrix instruction (round 5: the strict mode's default; 7 pins it): row-major V and the cross-K/V layout
+    for force in (7, 0):
+        for kp in (0, 1536):
+            o = _attn(0, q.cuda(), k.cuda(), v.cuda(), force, kp)
+            err = (o.cpu().double() - ref).abs().max().item()
+            assert err < 2e-5, (force, kp, err)
 
 
 @pytest.mark.parametrize("B,H,nq,nk", [(1, 1, 1, 1500), (3, 4, 5, 1500), (2, 2, 16, 1500), (1, 3, 7, 333)])
@@ -304,6 +330,30 @@ def test_attention_decode_cross_kernel(B, H, nq, nk):
     o = _attn(1, q.cuda(), k.cuda(), v.cuda(), 3, 1536)
     err = (o.cpu().double() - ref).abs().max().item()
     assert err < 6e-3, err
+    # strict f32: <= 16 queries take the key-split form of the exact-f32 MFMA kernel (four waves, one 16-key block of a tile each)
+    qf, kf, vf = q.float(), k.float(), v.float()
+    for kp in (0, 1536):
+        o = _attn(0, qf.cuda(), kf.cuda(), vf.cuda(), 7, kp)
+        err = (o.cpu().double() - ref).abs().max().item()
+        assert err < 2e-5, (kp, err)
+
+
+@pytest.mark.parametrize("B,H,nq,nk", [(2, 2, 3, 7), (1, 2, 16, 70), (2, 1, 5, 130), (1, 2, 33, 9), (1, 1, 129, 200), (2, 1, 300, 64)])
+def test_attention_f32_mfma_edges(B, H, nq, nk):
+    # the exact-f32 MFMA kernel at the edges: fewer keys than one 16-key block per wave (key-split form: waves that see no key at
+    # all), ragged last tiles, query blocks that end inside a wave / inside a workgroup -- vs the f64 reference and the VALU kernel
+    g = torch.Generator().manual_seed(B * 1000 + nq * 10 + nk)
+    q = torch.randn(B, nq, H * 64, generator=g) * 2
+    k = torch.randn(B, nk, H * 64, generator=g) * 2
+    v = torch.randn(B, nk, H * 64, generator=g)
+    ref = _attn_ref(q, k, v)
+    for kp in (0, 256):
+        o = _attn(0, q.cuda(), k.cuda(), v.cuda(), 7, kp)
+        assert torch.isfinite(o).all(), kp
+        err = (o.cpu().double() - ref).abs().max().item()
+        assert err < 3e-5, (kp, err)
+        o1 = _attn(0, q.cuda(), k.cuda(), v.cuda(), 1, kp)
+        assert (o.cpu() - o1.cpu()).abs().max().item() < 3e-5, kp
 
 
 @pytest.mark.parametrize("check", ["gemm_glds_check.py", "gemm_big8_check.py", "mel_ragged_check.py", "score_qk_check.py"])
