@@ -56,7 +56,9 @@ template <int MT, int NKS, int EPI>
 __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 {
     constexpr bool E_LN = (EPI & DEC_LN) != 0, E_GELU = (EPI & DEC_GELU) != 0, E_RES = (EPI & DEC_RES) != 0,
-                   E_QKV = (EPI & DEC_QKV) != 0, E_SLAB = (EPI & DEC_SLAB) != 0;
+                   E_QKV = (EPI & DEC_QKV) != 0, E_SLAB = (EPI & DEC_SLAB) != 0, E_TICKET = (EPI & DEC_TICKET) != 0;
+    static_assert(!E_TICKET || (E_SLAB && E_RES && !E_LN), "the ticket reduction finishes x += bias + sum of slabs");
+    constexpr bool E_FIN = !E_SLAB || E_TICKET;      // this launch finishes outputs itself: bias / residual operands are loaded
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [MT*16][kslice] f16 | float2 stat[MT*16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -107,14 +109,14 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     for (int ks = 0; ks < NKS; ++ks)
         asm volatile("global_load_dwordx4 %0, %1, off offset:%2" SWX_DEC_W_POLICY : "=v"(wf[ks]) : "v"(wp + (ks >> 2) * 2048), "n"((ks & 3) * 1024) : "memory");
     // ---- epilogue operands (clamped addresses, never predicated): column constants and the residual rows
-    constexpr int N_EPI = (E_SLAB ? 0 : 1) + (E_LN ? 1 : 0) + ((E_RES && !E_SLAB) ? MT : 0);   // loads younger than the weights
+    constexpr int N_EPI = (E_FIN ? 1 : 0) + (E_LN ? 1 : 0) + ((E_RES && E_FIN) ? MT : 0);   // loads younger than the weights
     const int n = panel * 64 + wave * 16 + lg * 4;
     const int nc = n < g.N ? n : g.N - 4;
     f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (!E_SLAB) c2 = *(const f32x4 *)(g.c2 + nc);
+    if constexpr (E_FIN) c2 = *(const f32x4 *)(g.c2 + nc);
     if constexpr (E_LN) c1 = *(const f32x4 *)(g.c1 + nc);
     f16x4 xres[MT];
-    if constexpr (E_RES && !E_SLAB) {
+    if constexpr (E_RES && E_FIN) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int m = r0 + t * 16 + li;
@@ -224,7 +226,52 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             const int m = r0 + t * 16 + li;
             if (m < g.M) *(f32x4 *)(out + (size_t)m * g.N + n) = acc[t];
         }
-        return;
+        if constexpr (!E_TICKET) {
+            return;
+        } else {
+            // Round 5: the reduction of the K slices inside the launch (cdna_hip_programming.md, in-launch split-K reduction: plain
+            // slab stores -> every wave drains -> barrier -> ONE lane: agent-scope release, drained again where the compiler cannot
+            // drop the wait, THEN the relaxed ticket; the last arriver: agent-scope acquire -> barrier -> plain loads).  The K slices
+            // of a (panel, row group) run on different XCDs (unit -> XCD above): nothing here depends on where they run.  The counter
+            // is zero before the first launch (swx_bind_workspace) and is put back by the last arriver; the next launch that uses it
+            // is behind a kernel boundary.  dec_slab_finish's arithmetic, operation for operation: 0 + slab 0 + slab 1 + ... +
+            // bias, then f16(sum + x) -- bit-identical (tests/test_gpu_kernels.py, SWX_FLAG_NO_TICKET).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                   // every wave's slab stores issued and drained; the activation tile is dead
+            int *last_flag = (int *)smem;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                int *cnt = g.ticket + panel * g.n_rg + rg;
+                const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = tk == g.ks2 - 1 ? 1 : 0;
+                if (last) {
+                    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                *last_flag = last;
+            }
+            __syncthreads();
+            if (!*last_flag) return;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int m = r0 + t * 16 + li;
+                const float *sp = g.slabs + (size_t)(m < g.M ? m : g.M - 1) * g.N + n;
+                f32x4 part[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) part[k] = *(const f32x4 *)(sp + (size_t)(k < g.ks2 ? k : g.ks2 - 1) * g.slab_stride);   // all in flight
+                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (k < g.ks2) a += part[k];
+                a += c2;
+                if (m >= g.M) continue;
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] + (float)xres[t][e]);
+                *(f16x4 *)(g.X + (size_t)m * g.ldx + n) = o;
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -536,12 +583,18 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     { const int rc = swx_dec_plan(g.M, g.N, g.K, g.epi, &mt, &ks2); if (rc < 0) return rc; }
     if (ks2 > 1 && !g.slabs) return -4;
     if (ks2 == 1 && (g.epi & DEC_SLAB)) g.epi &= ~DEC_SLAB;      // un-split after all: the kernel finishes the output itself
+    g.epi &= ~DEC_TICKET;
     g.ks2 = ks2; g.kslice = g.K / ks2; g.n_rg = cdiv(g.M, mt * 16);
     g.slab_stride = (int64_t)g.M * g.N;
     const int nks = g.kslice / 32;
     const int units = (g.N / 64) * ks2;
-    const int epi = g.epi & (DEC_LN | DEC_GELU | DEC_RES | DEC_QKV | DEC_SLAB);
-    if (g.tall && g.M > 160 && nks % 4 == 0 && !(swx_flags() & SWX_FLAG_NO_TALL)) {
+    int epi = g.epi & (DEC_LN | DEC_GELU | DEC_RES | DEC_QKV | DEC_SLAB);
+    const bool use_tall = g.tall && g.M > 160 && (g.kslice / 32) % 4 == 0 && !(swx_flags() & SWX_FLAG_NO_TALL);
+    // the K-split projection of the decode-step kernel reduces its slabs inside the launch when the caller provides arrival counters
+    const bool ticket = ks2 > 1 && ks2 <= 4 && !use_tall && g.ticket && epi == (DEC_RES | DEC_SLAB) && g.X &&
+                        (g.N / 64) * cdiv(g.M, mt * 16) <= SWX_DEC_TICKETS && !(swx_flags() & SWX_FLAG_NO_TICKET);
+    if (ticket) epi |= DEC_TICKET;
+    if (use_tall) {
         // tall kernel: ~two rounds of the chip's 256 CUs, every workgroup a run of `tps` 16-row tiles
         const int n_tiles = cdiv(g.M, 16);
         int rs = 512 / (cdiv(units, 8) * 8);
@@ -599,6 +652,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
         case DEC_LN: SWX_DEC_NK(DEC_LN); break;
         case DEC_LN | DEC_GELU: SWX_DEC_NK(DEC_LN | DEC_GELU); break;
         case DEC_RES | DEC_SLAB: SWX_DEC_NK(DEC_RES | DEC_SLAB); break;
+        case DEC_RES | DEC_SLAB | DEC_TICKET: SWX_DEC_NK(DEC_RES | DEC_SLAB | DEC_TICKET); break;
         default: return -4;
     }
 #undef SWX_DEC_NK
@@ -607,7 +661,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     }
     }
     SWX_CHECK_LAUNCH();
-    if (ks2 > 1) {
+    if (ks2 > 1 && !ticket) {
         // the one K-split projection: x += bias + sum of slabs
         if (!(g.epi & DEC_RES) || !g.X) return -4;
         SwxProfScope prof2(PC_NORM, (double)ks2 * g.M * g.N * 4 + 4.0 * g.M * g.N, s);

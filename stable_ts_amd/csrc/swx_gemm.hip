@@ -790,35 +790,48 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[ST][NA], rb[ST][NB];
+    // Round 5: the operand loads in inline asm behind a hand-counted wait (see gemm_f32_rows64 for what hipcc made of ordinary
+    // loads: the steps requested ST - 1 ahead were drained at every step -- vmcnt(3) .. vmcnt(0) in front of each new request).
+    // Clamped addresses, never predicated; rows past M / N are zeroed when the registers go to LDS.  Loads return in issue order:
+    // step kt + 1 has landed once only the (ST - 2) (NA + NB) loads of the steps behind it are pending.
     auto load_regs = [&](int st, int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
-            const int gm = m0 + row;
-            ra[st][i] = (row < BMT && gm < g.M) ? *(const f32x4 *)(A + (size_t)gm * g.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int gm = m0 + (row < BMT ? row : BMT - 1);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[st][i]) : "v"(A + (size_t)(gm < g.M ? gm : g.M - 1) * g.lda + k0 + kc) : "memory");
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
-            const int gn = n0 + row;
-            rb[st][i] = (row < BNT && gn < g.N) ? *(const f32x4 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int gn = n0 + (row < BNT ? row : BNT - 1);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[st][i]) : "v"(W + (size_t)(gn < g.N ? gn : g.N - 1) * g.ldw + k0 + kc) : "memory");
         }
+    };
+    auto wait_stage = [&](int st) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (NA + NB)) : "memory");
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[st][i]));
+#pragma unroll
+        for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(rb[st][i]));
     };
     auto store_lds = [&](int st, int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
             if (row < BMT) {
+                const bool ok = m0 + row < g.M;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][row][kc + e] = ra[st][i][e];
+                for (int e = 0; e < 4; ++e) As[buf][row][kc + e] = ok ? ra[st][i][e] : 0.f;
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
             if (row < BNT) {
+                const bool ok = n0 + row < g.N;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[buf][row][kc + e] = rb[st][i][e];
+                for (int e = 0; e < 4; ++e) Bs[buf][row][kc + e] = ok ? rb[st][i][e] : 0.f;
             }
         }
     };
@@ -842,7 +855,8 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
     const int KT = g.K / BK32;
     // register stage of K step kt is kt % ST; steps 0 .. ST - 2 are requested up front
 #pragma unroll
-    for (int st = 0; st < ST - 1; ++st) if (st < KT) load_regs(st, st * BK32);
+    for (int st = 0; st < ST - 1; ++st) load_regs(st, (st < KT ? st : KT - 1) * BK32);
+    wait_stage(0);
     store_lds(0, 0);
     __syncthreads();
     for (int kt0 = 0; kt0 < KT; kt0 += ST) {
@@ -851,13 +865,15 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
             const int kt = kt0 + u;
             if (kt < KT) {
                 const int cur = kt & 1;
-                if (kt + ST - 1 < KT) load_regs((u + ST - 1) % ST, (kt + ST - 1) * BK32);
+                // unconditional (past the end: the last step again, never stored): the count above holds at every step
+                load_regs((u + ST - 1) % ST, (kt + ST - 1 < KT ? kt + ST - 1 : KT - 1) * BK32);
                 compute(cur);
-                if (kt + 1 < KT) store_lds((u + 1) % ST, cur ^ 1);
+                if (kt + 1 < KT) { wait_stage((u + 1) % ST); store_lds((u + 1) % ST, cur ^ 1); }
                 __syncthreads();
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the idle re-loads of the last step
 
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
 #pragma unroll
@@ -890,32 +906,58 @@ __global__ __launch_bounds__(256) void gemm_f32_rows64(GemmArgs g)
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * BNT;
     const float *A = (const float *)g.A;
     const float *W = (const float *)g.W;
-    // staging: thread -> (row = tid >> 2, 16-k group = tid & 3) of the A tile and, the first 4 BNT threads, of the B tile
+    // staging: A tile: thread -> (row = tid >> 2, 16-k group = tid & 3), four 16-byte loads, written 4 x 4 transposed with 16-byte
+    // LDS stores; B tile (16 NJ rows): thread -> (row = tid >> 4 [+ 16], k = 4 (tid & 15) .. + 3), ONE 16-byte load per 16 rows,
+    // four scalar LDS stores -- every thread does the same work: no divergent branch around a load or its wait
     const int srow = tid >> 2, sgrp = tid & 3;
     const bool a_ok = m0 + srow < g.M;
-    const bool b_thr = tid < 4 * BNT, b_ok = b_thr && n0 + srow < g.N;
-    const float *ap = A + (size_t)(a_ok ? m0 + srow : 0) * g.lda + sgrp * 16;
-    const float *wp = W + (size_t)(b_ok ? n0 + srow : 0) * g.ldw + sgrp * 16;
+    const float *ap = A + (size_t)(a_ok ? m0 + srow : g.M - 1) * g.lda + sgrp * 16;
+    const int brow = tid >> 4, bc4 = tid & 15;
+    bool b_ok[NJ];
+    const float *wp[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        b_ok[j] = n0 + j * 16 + brow < g.N;
+        wp[j] = W + (size_t)(b_ok[j] ? n0 + j * 16 + brow : g.N - 1) * g.ldw + bc4 * 4;
+    }
+    const int bpos = 16 * (bc4 >> 2) + (bc4 & 3);       // k = 16 t + 4 e + i (t = bc4 >> 2, e = bc4 & 3) -> position 16 t + 4 i + e
     const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = zero4;
-    f32x4 ra[2][4], rb[2][4];
+    f32x4 ra[2][4], rb[2][NJ];
+    // Clamped addresses, never a predicated load; the zero-select of rows past M / N only when the registers go to LDS; and the
+    // loads themselves in inline asm behind a hand-counted wait.  What hipcc made of ordinary loads here, seen in the ISA one form
+    // after the other: a conditional load = a branch whose join waits vmcnt(0); a select right behind the load waits for it at
+    // once; a prefetch under `if (c + 2 < KC)` makes the wait for chunk c + 1 valid for the path WITHOUT new loads, i.e. drains
+    // them; and with everything unconditional the loop header still got a vmcnt(0) for the stage carried around the back edge.
+    // Each form drained the two-chunk prefetch once per chunk (first hardware run: 22 us per K = 1280 launch).  Loads return in
+    // issue order: chunk c + 1 has landed once only the NL loads of chunk c + 2 are pending.
+    constexpr int NL = 4 + NJ;                     // loads per thread and chunk
     auto load_regs = [&](int st, int k0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            ra[st][e] = a_ok ? *(const f32x4 *)(ap + k0 + 4 * e) : zero4;
-            rb[st][e] = b_ok ? *(const f32x4 *)(wp + k0 + 4 * e) : zero4;
-        }
+        for (int e = 0; e < 4; ++e) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[st][e]) : "v"(ap + k0 + 4 * e) : "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[st][j]) : "v"(wp[j] + k0) : "memory");
+    };
+    auto wait_stage = [&](int st) {                // stage st is the OLDER of the two in flight
+        if constexpr (NJ == 1)
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ra[st][0]), "+v"(ra[st][1]), "+v"(ra[st][2]), "+v"(ra[st][3]), "+v"(rb[st][0]) : "n"(NL) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(ra[st][0]), "+v"(ra[st][1]), "+v"(ra[st][2]), "+v"(ra[st][3]), "+v"(rb[st][0]), "+v"(rb[st][NJ - 1]) : "n"(NL) : "memory");
     };
     auto store_lds = [&](int st, int buf) {
         // registers hold k = 16 sgrp + 4 e + i as ra[st][e][i]; LDS position 16 sgrp + 4 i + e
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(f32x4 *)&As[buf][srow][16 * sgrp + 4 * i] = (f32x4){ra[st][0][i], ra[st][1][i], ra[st][2][i], ra[st][3][i]};
-            if (b_thr) *(f32x4 *)&Bs[buf][srow][16 * sgrp + 4 * i] = (f32x4){rb[st][0][i], rb[st][1][i], rb[st][2][i], rb[st][3][i]};
+            const f32x4 va = (f32x4){ra[st][0][i], ra[st][1][i], ra[st][2][i], ra[st][3][i]};
+            *(f32x4 *)&As[buf][srow][16 * sgrp + 4 * i] = a_ok ? va : zero4;
         }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bs[buf][j * 16 + brow][bpos + 4 * i] = b_ok[j] ? rb[st][j][i] : 0.f;
     };
     auto compute = [&](int buf) {
 #pragma unroll
@@ -933,7 +975,8 @@ __global__ __launch_bounds__(256) void gemm_f32_rows64(GemmArgs g)
 
     const int KC = g.K / 64;
     load_regs(0, 0);
-    if (KC > 1) load_regs(1, 64);
+    load_regs(1, KC > 1 ? 64 : 0);
+    wait_stage(0);
     store_lds(0, 0);
     __syncthreads();
     for (int c0 = 0; c0 < KC; c0 += 2) {
@@ -941,13 +984,16 @@ __global__ __launch_bounds__(256) void gemm_f32_rows64(GemmArgs g)
         for (int u = 0; u < 2; ++u) {                       // (unrolled: the register stages are compile-time indices)
             const int c = c0 + u;
             if (c < KC) {
-                if (c + 2 < KC) load_regs(u, (c + 2) * 64);          // stage u went to LDS at the end of step c - 1
+                // stage u went to LDS at the end of step c - 1.  Issued unconditionally (past the end: the last chunk again, never
+                // stored): under a condition hipcc's wait for chunk c + 1 must hold on the path WITHOUT new loads and drains them
+                load_regs(u, (c + 2 < KC ? c + 2 : KC - 1) * 64);
                 compute(c & 1);
-                if (c + 1 < KC) store_lds(u ^ 1, (c + 1) & 1);
+                if (c + 1 < KC) { wait_stage(u ^ 1); store_lds(u ^ 1, (c + 1) & 1); }
                 __syncthreads();
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the idle re-loads of the last chunk
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)

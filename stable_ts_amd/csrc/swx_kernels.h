@@ -46,6 +46,8 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_NO_TALL 524288       // multi-token passes: never the tall dec GEMM (register-resident weights, 16-row tiles): A/B, bit-identical
 #define SWX_FLAG_NO_FUSED_XQ 1048576  // decode step: cross-attention query projection as a launch of its own instead of inside the
                                       // cross-attention kernel (A/B; bit-identical)
+#define SWX_FLAG_NO_TICKET 2097152    // decode step: the K-split projection's slabs reduced by a launch of their own (dec_slab_finish) instead of
+                                      // inside the GEMM launch by the last-arriving K slice (A/B and bit-identity reference)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
@@ -57,6 +59,8 @@ int swx_flags();
 #define DEC_RES 4       // X[m][n] = f16(X + c2[n] + acc)   (in place)
 #define DEC_QKV 8       // columns [0,d) -> C, [d,2d) -> kcache[m][pos0[m]], [2d,3d) -> vcache[m][pos0[m]]
 #define DEC_SLAB 16     // K-split allowed: f32 partials to slabs + dec_slab_finish (needs DEC_RES)
+#define DEC_TICKET 32   // (launcher-internal, with DEC_SLAB | DEC_RES) the slab reduction INSIDE the launch: the K slices of a (panel, row
+                        // group) draw a ticket after publishing their slab; the last arriver reduces (dec_slab_finish's arithmetic)
 // The packed weights of the projection that runs NEXT in the decode step, for the cache prefetch the current kernel issues: a few
 // loads per wave whose results nobody reads, one per 128-byte line, dealt over the lanes of the launch in order.  What gets warm
 // is the memory-side Infinity Cache (the consumer's FETCH_SIZE does not drop, its latency does: section 5 of DESIGN.md), so
@@ -77,6 +81,8 @@ struct DecGemmArgs {
     _Float16 *C; int64_t ldc;
     _Float16 *X; int64_t ldx;
     float *slabs;                        // swx_dec_slab_floats(M, N, K) floats when the shape runs K-split
+    int *ticket;                         // K-split shapes of the decode-step kernel: SWX_DEC_TICKETS zeroed ints (self-resetting arrival
+                                         // counters per (panel, row group)) -> the slab reduction runs inside the launch; null: dec_slab_finish
     _Float16 *kcache, *vcache; const int32_t *pos0; int n_ctx, d;
     int rps;                             // DEC_QKV: rows per sequence (0 / 1: one new token per row); row m = sequence m / rps, token m % rps
     int row_mul;                         // DEC_QKV: cache row (and pos0 index) of sequence q = q * row_mul (0 / 1: q itself; the prefill writes row w * G)
@@ -86,6 +92,7 @@ struct DecGemmArgs {
     int tps;                             // launcher (tall kernel): 16-row tiles per workgroup; n_rg = row splits
     DecPrefetch pf;                      // cache prefetch of the NEXT projection's weights (pf.base == null: none)
 };
+#define SWX_DEC_TICKETS 4096
 int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation
 size_t swx_dec_slab_floats(int M, int N, int K);
 int swx_gemm_dec(DecGemmArgs g, hipStream_t s);

@@ -66,7 +66,7 @@ struct swx_model {
     size_t ws_bytes = 0;
     int max_windows = 0, max_rows = 0, ws_n_align = 0;
     struct WsLayout {
-        size_t melT, h1, x, h, qkv, att, u, gmax, small_i32, zeros_i32;
+        size_t melT, h1, x, h, qkv, att, u, gmax, small_i32, zeros_i32, ticket;
         size_t tokens0, tokens1, anc0, anc1, pos0, sum_lp, sum_lp_next, row_done, win_done, win_done_prev, n_done;
         size_t fin_tokens, fin_score, fin_len, fin_count, cand_lp, cand_tok, logits, hid2;
         size_t kcache, vcache, sk, sv, cap, mean, sd, suppress, slabs, heads, win_uid;
@@ -242,6 +242,7 @@ void ws_layout(const swx_model *m, int Bmax, int Mmax, int n_align, swx_model::W
     L.gmax = take((size_t)Bmax * 4);
     L.small_i32 = take((size_t)SMALL_I32 * 4);
     L.zeros_i32 = take((size_t)(Mmax > Bmax ? Mmax : Bmax) * 4 + 256);
+    L.ticket = take((size_t)SWX_DEC_TICKETS * 4);       // arrival counters of the in-launch slab reduction (zero between launches)
     L.tokens0 = take((size_t)Mmax * TS * 4);
     L.tokens1 = take((size_t)Mmax * TS * 4);
     L.anc0 = take((size_t)Mmax * D.n_text_ctx * 4);
@@ -447,7 +448,7 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
         g.M = rows; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
-        g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
+        g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs; g.ticket = m->Wp<int>(m->L.ticket);
         if (l + 1 < D.n_text_layer) g.pf = pf_of(m->dec[l + 1].wqkv_f, 3 * d, d, DEC_LN | DEC_QKV);
         SWX_TRY(swx_gemm_dec(g, s));
     }
@@ -526,7 +527,7 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         SWX_TRY(swx_gemm_dec(g, s));
         g = DecGemmArgs{};
         g.M = rows; g.tall = 1; g.A = u; g.lda = 4 * d; g.W = m->A<f16>(w.w2_p); g.ldw = 4 * d; g.N = d; g.K = 4 * d; g.epi = DEC_RES | DEC_SLAB;
-        g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs;
+        g.c2 = m->A<float>(w.b2); g.X = x; g.ldx = d; g.slabs = slabs; g.ticket = m->Wp<int>(m->L.ticket);
         if (l + 1 < D.n_text_layer) g.pf = pf_of(m->dec[l + 1].wqkv_f, 3 * d, d, DEC_LN | DEC_QKV);
         SWX_TRY(swx_gemm_dec(g, s));
     }
@@ -926,6 +927,7 @@ int swx_bind_workspace(swx_model *m, void *d_ws, size_t bytes, int max_windows, 
     m->ws_n_align = m->n_align;
     m->L = L;
     hipError_t e = hipMemset(m->ws + L.zeros_i32, 0, (size_t)(max_rows > max_windows ? max_rows : max_windows) * 4 + 256);
+    if (e == hipSuccess) e = hipMemset(m->ws + L.ticket, 0, (size_t)SWX_DEC_TICKETS * 4);
     if (e != hipSuccess) return -100 - (int)e;
     if (!m->heads_flat.empty()) {
         e = hipMemcpy(m->ws + L.heads, m->heads_flat.data(), m->heads_flat.size() * 4, hipMemcpyHostToDevice);
@@ -1505,15 +1507,18 @@ int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float
     // d_scratch: N*K halfs (folded weights) + 2N floats (c1, c2) + the slab floats of the shape, 256-byte aligned pieces
     hipStream_t s = S(stream);
     unsigned char *p = (unsigned char *)d_scratch;
-    const size_t need = align_up((size_t)N * K * 2) + 2 * align_up((size_t)N * 4) + align_up(swx_dec_slab_floats(M, N, K) * 4 + 256);
+    const size_t slab_b = align_up(swx_dec_slab_floats(M, N, K) * 4 + 256);
+    const size_t need = align_up((size_t)N * K * 2) + 2 * align_up((size_t)N * 4) + slab_b + (size_t)SWX_DEC_TICKETS * 4;
     if (scratch_bytes < need) return -8;
     f16 *wf = (f16 *)p; p += align_up((size_t)N * K * 2);
     float *c1 = (float *)p; p += align_up((size_t)N * 4);
     float *c2 = (float *)p; p += align_up((size_t)N * 4);
-    float *slabs = (float *)p;
+    float *slabs = (float *)p; p += slab_b;
+    int *ticket = (int *)p;
+    { hipError_t e = hipMemsetAsync(ticket, 0, (size_t)SWX_DEC_TICKETS * 4, s); if (e != hipSuccess) return -100 - (int)e; }
     DecGemmArgs g{};
     g.A = (const f16 *)d_a; g.lda = lda; g.M = M; g.N = N; g.K = K; g.epi = epilogue; g.ldw = K;
-    g.C = (f16 *)d_c; g.ldc = ldc; g.X = (f16 *)d_x; g.ldx = ldc; g.slabs = slabs;
+    g.C = (f16 *)d_c; g.ldc = ldc; g.X = (f16 *)d_x; g.ldx = ldc; g.slabs = slabs; g.ticket = ticket;
     g.kcache = (f16 *)d_kcache; g.vcache = (f16 *)d_vcache; g.pos0 = d_pos0; g.n_ctx = n_ctx; g.d = d;
     g.epi = epilogue & 31;
     g.tall = (epilogue & 64) ? 1 : 0;                 // bit 6: a multi-token pass (the tall kernel from 161 rows on)

@@ -389,7 +389,7 @@ def _dec_gemm(a, w, *, gamma=None, beta=None, bias=None, x=None, epi=0, d=0, n_c
         kc = torch.zeros(M, n_ctx, d, dtype=torch.float16, device=dev)
         vc = torch.zeros(M, n_ctx, d, dtype=torch.float16, device=dev)
         tp = torch.from_numpy(np.asarray(pos0, np.int32)).to(dev)
-    scratch = torch.empty(N * K * 2 + 8 * N + 16 * M * N * 4 + 8192, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(N * K * 2 + 8 * N + 16 * M * N * 4 + 8192 + 4096 * 4, dtype=torch.uint8, device=dev)
     rc = lib.swx_test_dec_gemm(_p(ta), K, _p(tw), None if tg is None else _p(tg), None if tb is None else _p(tb), _p(tbias),
                                _p(tc), ldc, None if tx is None else _p(tx), None if kc is None else _p(kc),
                                None if vc is None else _p(vc), None if tp is None else _p(tp), n_ctx, d, M, N, K, epi,
@@ -427,6 +427,29 @@ def test_dec_gemm_residual(M, N, K):
     ref = _h(x) + b.astype(np.float64) + _h(a) @ _h(w).T
     tol = 2e-3 * np.maximum(1.0, np.abs(ref)) + 1e-3
     assert (np.abs(got - ref) <= tol).all(), float(np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 1280, 5120), (5, 1280, 5120), (20, 384, 1536), (48, 512, 2048), (77, 768, 3072), (160, 1024, 4096)])
+def test_dec_gemm_slab_reduction_inside_the_launch_is_bit_identical(M, N, K):
+    # round 5: the K slices of a (panel, row group) draw a ticket after publishing their f32 slab, the last arriver reduces
+    # (DEC_TICKET) -- against the separate dec_slab_finish launch (SWX_FLAG_NO_TICKET): equal bits, 8 repetitions (the arrival
+    # order of the slices changes from run to run; the counters must be back at zero for the next launch)
+    lib = _lib()
+    rng = np.random.default_rng(M * 5 + N + K)
+    a = rng.standard_normal((M, K)).astype(np.float32) * 0.5
+    w = rng.standard_normal((N, K)).astype(np.float32) * 0.03
+    b = rng.standard_normal(N).astype(np.float32) * 0.1
+    x = rng.standard_normal((M, N)).astype(np.float32)
+    prev = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(prev | 2097152)
+        ref = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16)["x"]
+        lib.swx_debug_flags(prev & ~2097152)
+        for rep in range(8):
+            got = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16)["x"]
+            assert np.array_equal(got, ref), (rep, float(np.abs(got - ref).max()))
+    finally:
+        lib.swx_debug_flags(prev)
 
 
 @pytest.mark.parametrize("M,N,K,gelu", [(100, 1280, 1280, False), (100, 5120, 1280, True), (7, 384, 384, False),
