@@ -129,9 +129,6 @@ def main():
                     "many spans in lockstep, spans.py) instead of the fixed-stride window batches")
     ap.add_argument("--sequential", action="store_true", help="the default model.transcribe(audio): the reference's sequential "
                     "window loop (seek from the last timestamp, prompt carried over), one window per device pass")
-    ap.add_argument("--tokens-follow-audio", action="store_true", help="sequential / span modes: the fixed decode length is a token RATE "
-                    "(--tokens per 30 s of audio): the 0-2 s remainder windows these drivers leave behind a 28-30 s seek advance decode 8 tokens, "
-                    "not a 30-s window's 112 (DecodingOptions.min_tokens_follow_audio) -- on speech such a window emits a word or two and ends")
     ap.add_argument("--raw-seek", action="store_true", help="sequential / span modes: leave every timestamp token selectable.  By default "
                     "these modes suppress the timestamp tokens of 0.02 .. 27.98 s through the reference's own `suppress_tokens` option, "
                     "so that a window's last timestamp -- which the reference's seek advances by (original_whisper.py:629-633) -- lands "
@@ -223,8 +220,6 @@ def main():
         if args.spans > 0 or args.sequential:
             kw.pop("batch_size")
             kw.pop("streams", None)
-            if args.tokens_follow_audio:
-                kw["min_tokens_follow_audio"] = True
             if not args.raw_seek:
                 from stable_ts_amd.tokenizer import get_tokenizer
                 tb = get_tokenizer(model.is_multilingual, num_languages=model.num_languages, language="en", task="transcribe").timestamp_begin
@@ -304,7 +299,6 @@ def main():
                      else "sequential windows (reference control flow)" + ("" if args.raw_seek else ", seek advance 28-30 s per window (timestamp tokens of 0.02-27.98 s suppressed through suppress_tokens)")
                      if args.sequential
                      else f"window-parallel batch {args.batch}" + (f", {args.streams} streams" if args.streams > 1 else ""))
-                  + (f", decode length {args.tokens} tokens per 30 s of audio (remainder windows pro rata, multiples of 8)" if kw.get("min_tokens_follow_audio") else "")
                   + (", default regrouping inside the timed pass" if kw.get("regroup") else ", regroup=False")
                   + (", recording handed over as a HOST tensor (PCIe-inclusive)" if args.host_audio else "")
                   + (f"; ONE recording of {args.minutes * world:g} min scattered by 30-s window over {world} rank(s) "

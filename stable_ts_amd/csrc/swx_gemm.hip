@@ -790,48 +790,35 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     f32x4 ra[ST][NA], rb[ST][NB];
-    // Round 5: the operand loads in inline asm behind a hand-counted wait (see gemm_f32_rows64 for what hipcc made of ordinary
-    // loads: the steps requested ST - 1 ahead were drained at every step -- vmcnt(3) .. vmcnt(0) in front of each new request).
-    // Clamped addresses, never predicated; rows past M / N are zeroed when the registers go to LDS.  Loads return in issue order:
-    // step kt + 1 has landed once only the (ST - 2) (NA + NB) loads of the steps behind it are pending.
     auto load_regs = [&](int st, int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
-            const int gm = m0 + (row < BMT ? row : BMT - 1);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[st][i]) : "v"(A + (size_t)(gm < g.M ? gm : g.M - 1) * g.lda + k0 + kc) : "memory");
+            const int gm = m0 + row;
+            ra[st][i] = (row < BMT && gm < g.M) ? *(const f32x4 *)(A + (size_t)gm * g.lda + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
-            const int gn = n0 + (row < BNT ? row : BNT - 1);
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[st][i]) : "v"(W + (size_t)(gn < g.N ? gn : g.N - 1) * g.ldw + k0 + kc) : "memory");
+            const int gn = n0 + row;
+            rb[st][i] = (row < BNT && gn < g.N) ? *(const f32x4 *)(W + (size_t)gn * g.ldw + k0 + kc) : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    };
-    auto wait_stage = [&](int st) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * (NA + NB)) : "memory");
-#pragma unroll
-        for (int i = 0; i < NA; ++i) asm volatile("" : "+v"(ra[st][i]));
-#pragma unroll
-        for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(rb[st][i]));
     };
     auto store_lds = [&](int st, int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
             if (row < BMT) {
-                const bool ok = m0 + row < g.M;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) As[buf][row][kc + e] = ok ? ra[st][i][e] : 0.f;
+                for (int e = 0; e < 4; ++e) As[buf][row][kc + e] = ra[st][i][e];
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int c = tid + 256 * i, row = c >> 2, kc = (c & 3) * 4;
             if (row < BNT) {
-                const bool ok = n0 + row < g.N;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) Bs[buf][row][kc + e] = ok ? rb[st][i][e] : 0.f;
+                for (int e = 0; e < 4; ++e) Bs[buf][row][kc + e] = rb[st][i][e];
             }
         }
     };
@@ -855,8 +842,7 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
     const int KT = g.K / BK32;
     // register stage of K step kt is kt % ST; steps 0 .. ST - 2 are requested up front
 #pragma unroll
-    for (int st = 0; st < ST - 1; ++st) load_regs(st, (st < KT ? st : KT - 1) * BK32);
-    wait_stage(0);
+    for (int st = 0; st < ST - 1; ++st) if (st < KT) load_regs(st, st * BK32);
     store_lds(0, 0);
     __syncthreads();
     for (int kt0 = 0; kt0 < KT; kt0 += ST) {
@@ -865,15 +851,13 @@ __global__ __launch_bounds__(256) void gemm_f32_tiled(GemmArgs g)
             const int kt = kt0 + u;
             if (kt < KT) {
                 const int cur = kt & 1;
-                // unconditional (past the end: the last step again, never stored): the count above holds at every step
-                load_regs((u + ST - 1) % ST, (kt + ST - 1 < KT ? kt + ST - 1 : KT - 1) * BK32);
+                if (kt + ST - 1 < KT) load_regs((u + ST - 1) % ST, (kt + ST - 1) * BK32);
                 compute(cur);
-                if (kt + 1 < KT) { wait_stage((u + 1) % ST); store_lds((u + 1) % ST, cur ^ 1); }
+                if (kt + 1 < KT) store_lds((u + 1) % ST, cur ^ 1);
                 __syncthreads();
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the idle re-loads of the last step
 
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
 #pragma unroll
@@ -927,6 +911,13 @@ __global__ __launch_bounds__(256) void gemm_f32_rows64(GemmArgs g)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = zero4;
     f32x4 ra[2][4], rb[2][NJ];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ra[st][e] = zero4;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) rb[st][j] = zero4;
+    }
     // Clamped addresses, never a predicated load; the zero-select of rows past M / N only when the registers go to LDS; and the
     // loads themselves in inline asm behind a hand-counted wait.  What hipcc made of ordinary loads here, seen in the ISA one form
     // after the other: a conditional load = a branch whose join waits vmcnt(0); a select right behind the load waits for it at
@@ -993,7 +984,17 @@ __global__ __launch_bounds__(256) void gemm_f32_rows64(GemmArgs g)
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the idle re-loads of the last chunk
+    // The idle re-loads of the last chunk are still in flight, and hipcc believes their destination registers dead (no store
+    // follows): without the statements below it hands them out to the epilogue's address arithmetic while the loads land in them
+    // (first hardware run of this form: wrong results and a memory fault).  Every staging register stays allocated up to the wait.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(ra[st][e]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(rb[st][j]));
+    }
     const int col_l = lane & 15, row_l = (lane >> 4) * 4;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)

@@ -41,10 +41,6 @@ class DecodingOptions:
     # extension (not in upstream): EOT is suppressed until this many tokens were sampled -- used only to give
     # random-weight benchmarks a fixed decode length; 0 keeps the reference behaviour
     min_tokens: int = 0
-    # extension, with min_tokens: the fixed decode length is meant per 30 s of audio -- a window of d seconds gets
-    # ceil(min_tokens * d / 30 / 8) * 8 tokens (speech has a token RATE; a 1-s remainder window of the sequential / span drivers
-    # that is forced to emit a 30-s window's tokens costs a full decode pass that no real recording causes)
-    min_tokens_follow_audio: bool = False
     seed: int = 0
 
 

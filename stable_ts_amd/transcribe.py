@@ -83,26 +83,9 @@ def _xkv_select(model, xkv, idx: Sequence[int]):
     return sel
 
 
-def _scaled_budgets(options: DecodingOptions, seconds: Optional[Sequence[float]]) -> List[DecodingOptions]:
-    """`min_tokens_follow_audio` (synthetic-weight benchmarking, decoding.py): the fixed decode length of every window of one call.
-    Windows of at least half a chunk keep the full length (one lockstep job, as without the switch -- spans cut at quiet places
-    are 25-35 s long); the shorter ones -- the remainders the sequential / span drivers leave behind a seek advance -- share ONE
-    job whose length is the longest remainder's pro-rata share, rounded up to a multiple of 8."""
-    n_win = 0 if seconds is None else len(seconds)
-    if not (options.min_tokens and options.min_tokens_follow_audio) or not n_win:
-        return [options] * max(n_win, 1)
-    short = [s_ for s_ in seconds if s_ < CHUNK_LENGTH / 2]
-    if not short:
-        return [options] * n_win
-    n = min(options.min_tokens, max(8, -(-int(np.ceil(options.min_tokens * max(max(short), 0.0) / CHUNK_LENGTH)) // 8) * 8))
-    small = replace(options, min_tokens=n, sample_len=min(options.sample_len or n, n))
-    return [small if s_ < CHUNK_LENGTH / 2 else options for s_ in seconds]
-
-
 def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float], prompts, ts_masks,
                           compression_ratio_threshold, logprob_threshold, no_speech_threshold,
-                          uids: Optional[Sequence[int]] = None, torch_rng: bool = False,
-                          durations: Optional[Sequence[float]] = None) -> List[DecodingResult]:
+                          uids: Optional[Sequence[int]] = None, torch_rng: bool = False) -> List[DecodingResult]:
     """original_whisper.py:349-393, for W windows: every window walks the temperature ladder independently; the ones that
     still need a fallback are re-decoded together at the next temperature.  ``torch_rng`` (the sequential driver, one window
     per call): sampled retries draw from torch's generator call for call like the reference's loop (Engine.decode), so with
@@ -119,9 +102,7 @@ def _decode_with_fallback(model, xkv, base: dict, temperatures: Sequence[float],
             kw.pop("best_of", None)
         options = DecodingOptions(**kw, temperature=t)
         sub = _xkv_select(model, xkv, pending)
-        budgets = _scaled_budgets(options, None if durations is None else [durations[w] for w in pending])
-        plans = [DecodingPlan(model, replace(budgets[k] if durations is not None else options,
-                                             prompt=(list(prompts[w]) if prompts[w] else None))) for k, w in enumerate(pending)]
+        plans = [DecodingPlan(model, replace(options, prompt=(list(prompts[w]) if prompts[w] else None))) for w in pending]
         groups = {}
         for k, p in enumerate(plans):
             groups.setdefault((p.sample_begin, p.sample_len, p.options.min_tokens), []).append(k)
@@ -244,7 +225,7 @@ def _process_batch(model, tokenizer, batch: List[dict], o: dict, pre: Optional[d
     results = _decode_with_fallback(model, xkv, o["decode_options"], o["temperatures"], [b["prompt"] for b in batch],
                                     ts_masks, o["compression_ratio_threshold"], o["logprob_threshold"],
                                     o["no_speech_threshold"], uids=[int(b["seek_sample"]) // 160 for b in batch],
-                                    torch_rng=bool(o.get("torch_sampling")), durations=[n / SAMPLE_RATE for n in seg_samples])
+                                    torch_rng=bool(o.get("torch_sampling")))
     t_ph = _phase("decode (device loop + result copy)", t_ph)
     time_precision = (N_FRAMES // model.dims.n_audio_ctx) * HOP_LENGTH / SAMPLE_RATE
     punct = o["prepend_punctuations"] + o["append_punctuations"]

@@ -259,3 +259,23 @@ def test_big8_gemm_phases():
     assert len(meta) == 1
     for n, v in meta.items():
         assert v["private_segment_fixed_size"] == 0 and v["vgpr_count"] <= 256, (n, v)
+
+
+def test_f32_rows64_asm_loads_are_not_touched_before_their_wait():
+    """gemm_f32_rows64 (round 5) keeps its operand loads in inline asm behind hand-counted waits.  Its first hardware run computed
+    garbage and faulted: the idle re-loads of the last K chunk landed in registers hipcc had already handed to the epilogue's
+    address arithmetic (no store follows them, so the compiler believed them dead).  scripts/isa_asm_load_audit.py walks the
+    compiled kernel in program order (loop bodies twice, the pending set carried around the back edge): between an asm load and
+    the counted wait that covers it, no compiler-generated instruction may read or write its destination."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_asm_load_audit", os.path.join(ROOT, "scripts", "isa_asm_load_audit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lines = _device_asm("swx_gemm.hip").split("\n")
+    for key in ("gemm_f32_rows64ILi1E", "gemm_f32_rows64ILi2E"):
+        body = mod.kernel_body(lines, key)
+        assert body is not None, key
+        viol, n_loads, n_waits = mod.audit(body)
+        assert n_loads >= 15 and n_waits >= 4, (key, n_loads, n_waits)       # prologue 2 x NL + two unrolled chunks; three counted waits + the drain
+        assert not viol, (key, viol[:6])
+        assert not any("scratch_" in ln for ln in body), key

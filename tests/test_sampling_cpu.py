@@ -72,55 +72,3 @@ def test_reference_loop_iterations_bounds():
 def test_cuda_generator_offsets_are_available():
     g = torch.Generator()
     assert hasattr(g, "get_offset") and hasattr(g, "set_offset")
-
-
-def test_min_tokens_follow_audio_scales_the_fixed_decode_length():
-    """DecodingOptions.min_tokens_follow_audio (synthetic-weight benchmarking, like min_tokens): the fixed decode length is per 30 s
-    of audio for the REMAINDER windows of a call (shorter than half a chunk), which share one lockstep job; the others keep the
-    full length."""
-    from stable_ts_amd.decoding import DecodingOptions
-    from stable_ts_amd.transcribe import _scaled_budgets
-    o = DecodingOptions(sample_len=112, min_tokens=112, min_tokens_follow_audio=True)
-    assert _scaled_budgets(o, [30.0, 26.0, 15.0]) == [o, o, o] and _scaled_budgets(o, None) == [o]
-    got = _scaled_budgets(o, [30.0, 0.4, 27.5, 6.1, 2.0])
-    assert [g.min_tokens for g in got] == [112, 24, 112, 24, 24] and [g.sample_len for g in got] == [112, 24, 112, 24, 24]
-    for sec, want in ((0.0, 8), (2.0, 8), (2.2, 16), (14.9, 56)):
-        g = _scaled_budgets(o, [sec])[0]
-        assert (g.min_tokens, g.sample_len) == (want, want), (sec, g.min_tokens)
-    plain = DecodingOptions(sample_len=112, min_tokens=112)
-    assert _scaled_budgets(plain, [1.0, 30.0]) == [plain, plain]          # without the switch nothing changes
-    assert _scaled_budgets(DecodingOptions(sample_len=40, min_tokens=112, min_tokens_follow_audio=True), [14.0])[0].sample_len == 40
-
-
-def test_remainder_windows_decode_pro_rata(monkeypatch):
-    """the sequential driver on the CPU stand-in: a 34-s recording = one 30-s window + a remainder; with the switch the remainder's
-    decode job is short, without it both get the full length; the first window is untouched either way"""
-    import os
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    sys.path.insert(0, here)
-    sys.path.insert(0, os.path.join(here, "golden"))
-    from oracle.whisper.model import build_model
-    from oracle_engine import CpuWhisper, install
-    import make_golden as G
-    install(monkeypatch)
-    mine = CpuWhisper(build_model("tiny.en", seed=1234, std=0.02, embed_gain=9.0, ts_gain=0.1))
-    audio = G.synth_audio(34.0, seed=3)
-    calls = []
-    real = mine.engine.decode
-
-    def spy(xkv, init, **k):
-        calls.append((k["sample_len"], k["min_tokens"]))
-        return real(xkv, init, **k)
-    mine.engine.decode = spy
-    kw = dict(language="en", temperature=0.0, logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None,
-              sample_len=24, min_tokens=24, word_timestamps=False, suppress_silence=False, condition_on_previous_text=False)
-    base = mine.transcribe(audio, **kw)
-    plain = list(calls)
-    del calls[:]
-    scaled = mine.transcribe(audio, min_tokens_follow_audio=True, **kw)
-    assert plain and all(c == (24, 24) for c in plain)
-    # (where the first window's last timestamp puts the seek decides how long the remainder windows are)
-    assert calls[0] == (24, 24) and all(a == b and a % 8 == 0 and a <= 24 for a, b in calls)
-    assert any(a < 24 for a, _ in calls[1:]), calls
-    assert [t for t in scaled.segments[0].tokens] == [t for t in base.segments[0].tokens]
