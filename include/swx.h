@@ -256,7 +256,8 @@ int swx_prof_enable(int on);
  * per-op path instead of the fused "dec" step (its reference), 2048 = decode cross-attention on the row-layout K / V^T
  * (reference of the fragment-ordered copy), 8192 = memory-walking logit filters (reference of the register kernel),
  * 16384 = decode loop without the captured step graph, 32768 = decode step without the cache prefetch of the next projection's
- * weights, 65536 / 131072 = tiled GEMM never on the ring / the 256 x 256 kernel (bit-identical either way).  Default 0; nothing reads an environment variable.
+ * weights, 65536 / 131072 = tiled GEMM never on the ring / the 256 x 256 kernel (bit-identical either way), 2097152 = the decode step's
+ * K-split projection reduces its slabs inside the GEMM launch (arrival tickets; bit-identical, measured slower in round 5).  Default 0; nothing reads an environment variable.
  * flags < 0 only queries.  Returns the previous value. */
 int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);

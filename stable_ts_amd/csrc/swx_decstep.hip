@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             // of a (panel, row group) run on different XCDs (unit -> XCD above): nothing here depends on where they run.  The counter
             // is zero before the first launch (swx_bind_workspace) and is put back by the last arriver; the next launch that uses it
             // is behind a kernel boundary.  dec_slab_finish's arithmetic, operation for operation: 0 + slab 0 + slab 1 + ... +
-            // bias, then f16(sum + x) -- bit-identical (tests/test_gpu_kernels.py, SWX_FLAG_NO_TICKET).
+            // bias, then f16(sum + x) -- bit-identical (tests/test_gpu_kernels.py, SWX_FLAG_TICKET).
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                   // every wave's slab stores issued and drained; the activation tile is dead
             int *last_flag = (int *)smem;
@@ -590,9 +590,9 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     const int units = (g.N / 64) * ks2;
     int epi = g.epi & (DEC_LN | DEC_GELU | DEC_RES | DEC_QKV | DEC_SLAB);
     const bool use_tall = g.tall && g.M > 160 && (g.kslice / 32) % 4 == 0 && !(swx_flags() & SWX_FLAG_NO_TALL);
-    // the K-split projection of the decode-step kernel reduces its slabs inside the launch when the caller provides arrival counters
+    // SWX_FLAG_TICKET: the K-split projection of the decode-step kernel reduces its slabs inside the launch (measured slower: swx_kernels.h)
     const bool ticket = ks2 > 1 && ks2 <= 4 && !use_tall && g.ticket && epi == (DEC_RES | DEC_SLAB) && g.X &&
-                        (g.N / 64) * cdiv(g.M, mt * 16) <= SWX_DEC_TICKETS && !(swx_flags() & SWX_FLAG_NO_TICKET);
+                        (g.N / 64) * cdiv(g.M, mt * 16) <= SWX_DEC_TICKETS && (swx_flags() & SWX_FLAG_TICKET);
     if (ticket) epi |= DEC_TICKET;
     if (use_tall) {
         // tall kernel: ~two rounds of the chip's 256 CUs, every workgroup a run of `tps` 16-row tiles

@@ -432,8 +432,9 @@ def test_dec_gemm_residual(M, N, K):
 @pytest.mark.parametrize("M,N,K", [(100, 1280, 5120), (5, 1280, 5120), (20, 384, 1536), (48, 512, 2048), (77, 768, 3072), (160, 1024, 4096)])
 def test_dec_gemm_slab_reduction_inside_the_launch_is_bit_identical(M, N, K):
     # round 5: the K slices of a (panel, row group) draw a ticket after publishing their f32 slab, the last arriver reduces
-    # (DEC_TICKET) -- against the separate dec_slab_finish launch (SWX_FLAG_NO_TICKET): equal bits, 8 repetitions (the arrival
-    # order of the slices changes from run to run; the counters must be back at zero for the next launch)
+    # (DEC_TICKET, SWX_FLAG_TICKET: measured slower than the separate dec_slab_finish launch, so off by default) -- against the
+    # separate launch: equal bits, 8 repetitions (the arrival order of the slices changes from run to run; the counters must be
+    # back at zero for the next launch)
     lib = _lib()
     rng = np.random.default_rng(M * 5 + N + K)
     a = rng.standard_normal((M, K)).astype(np.float32) * 0.5
@@ -442,9 +443,9 @@ def test_dec_gemm_slab_reduction_inside_the_launch_is_bit_identical(M, N, K):
     x = rng.standard_normal((M, N)).astype(np.float32)
     prev = lib.swx_debug_flags(-1)
     try:
-        lib.swx_debug_flags(prev | 2097152)
-        ref = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16)["x"]
         lib.swx_debug_flags(prev & ~2097152)
+        ref = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16)["x"]
+        lib.swx_debug_flags(prev | 2097152)
         for rep in range(8):
             got = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16)["x"]
             assert np.array_equal(got, ref), (rep, float(np.abs(got - ref).max()))
