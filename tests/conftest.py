@@ -43,6 +43,14 @@ def _limit_threads():
         pass
 
 
+def subprocess_env():
+    """environment for the hardware checks that run in a child process (tests/hw_checks/*.py): torch sizes its intra-op pool by the
+    VISIBLE hardware threads (256 on the MI355X boxes) and the CPU oracle inside those scripts then runs 256 OpenMP workers under a
+    16-CPU quota -- score_qk_check.py took 145 s of the serial GPU suite that way (17 s of CPU work).  The children get the quota."""
+    n = str(_cpu_quota())
+    return dict(os.environ, OMP_NUM_THREADS=n, MKL_NUM_THREADS=n)
+
+
 def pytest_configure(config):
     _limit_threads()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / the driver)")

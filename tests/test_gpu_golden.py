@@ -172,7 +172,9 @@ def test_refinement_func_matches_reference_seam_b3():
     # of the tests that follow.
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(HERE, "hw_checks", "b3_check.py")], capture_output=True, text=True, timeout=300)
+    from conftest import subprocess_env
+    r = subprocess.run([sys.executable, os.path.join(HERE, "hw_checks", "b3_check.py")], capture_output=True, text=True, timeout=300,
+                       env=subprocess_env())
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
 
 

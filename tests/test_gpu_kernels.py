@@ -366,7 +366,9 @@ def test_new_kernel_paths_in_subprocess(check):
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "hw_checks", check)], capture_output=True, text=True, timeout=600)
+    from conftest import subprocess_env
+    r = subprocess.run([sys.executable, os.path.join(here, "hw_checks", check)], capture_output=True, text=True, timeout=600,
+                       env=subprocess_env())
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
 
 
