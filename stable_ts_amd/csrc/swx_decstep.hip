@@ -219,59 +219,66 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
 #pragma unroll
     for (int i = 0; i < DEC_NPF; ++i) asm volatile("" ::"v"(pfv[i]));
     if (n >= g.N) return;                          // N % 4 == 0 is checked by the launcher
-    if constexpr (E_SLAB) {
+    if constexpr (E_SLAB && !E_TICKET) {
         float *out = g.slabs + (size_t)ks_id * g.slab_stride;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int m = r0 + t * 16 + li;
             if (m < g.M) *(f32x4 *)(out + (size_t)m * g.N + n) = acc[t];
         }
-        if constexpr (!E_TICKET) {
-            return;
-        } else {
-            // Round 5: the reduction of the K slices inside the launch (cdna_hip_programming.md, in-launch split-K reduction: plain
-            // slab stores -> every wave drains -> barrier -> ONE lane: agent-scope release, drained again where the compiler cannot
-            // drop the wait, THEN the relaxed ticket; the last arriver: agent-scope acquire -> barrier -> plain loads).  The K slices
-            // of a (panel, row group) run on different XCDs (unit -> XCD above): nothing here depends on where they run.  The counter
-            // is zero before the first launch (swx_bind_workspace) and is put back by the last arriver; the next launch that uses it
-            // is behind a kernel boundary.  dec_slab_finish's arithmetic, operation for operation: 0 + slab 0 + slab 1 + ... +
-            // bias, then f16(sum + x) -- bit-identical (tests/test_gpu_kernels.py, SWX_FLAG_TICKET).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                   // every wave's slab stores issued and drained; the activation tile is dead
-            int *last_flag = (int *)smem;
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                int *cnt = g.ticket + panel * g.n_rg + rg;
-                const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = tk == g.ks2 - 1 ? 1 : 0;
-                if (last) {
-                    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                }
-                *last_flag = last;
-            }
-            __syncthreads();
-            if (!*last_flag) return;
+        return;
+    }
+    if constexpr (E_TICKET) {
+        // Round 5: the reduction of the K slices inside the launch (cdna_hip_programming.md, in-launch split-K reduction).  The K
+        // slices of a (panel, row group) run on different XCDs (unit -> XCD above); nothing here depends on where they run.
+        // Second form (the first -- plain slab stores, agent-scope release fence = buffer_wbl2 of the XCD's whole L2 in every one of
+        // the 240 workgroups, acquire fence = buffer_inv in the last arriver -- made the launch 17.0 us against 8.2 + 5.0 us for the
+        // slab GEMM and its finish launch: profiles/r05_ticket_on_kernels.csv): the slabs are PUBLISHED WRITE-THROUGH (16-byte
+        // `sc1` stores: at vmcnt(0) they are in memory, no L2 write-back) -> every wave drains -> barrier -> ONE lane draws the relaxed
+        // agent-scope ticket; the last arriver reads every slab with `sc1` loads (coherent reads: no invalidate) and reduces with
+        // dec_slab_finish's arithmetic, operation for operation: 0 + slab 0 + slab 1 + ... + bias, then f16(sum + x) -- bit-identical
+        // (tests/test_gpu_kernels.py, SWX_FLAG_TICKET).  The counter is zero before the first launch (swx_bind_workspace) and is put
+        // back by the last arriver; the next launch that uses it is behind a kernel boundary.
+        float *out = g.slabs + (size_t)ks_id * g.slab_stride;
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int m = r0 + t * 16 + li;
-                const float *sp = g.slabs + (size_t)(m < g.M ? m : g.M - 1) * g.N + n;
-                f32x4 part[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) part[k] = *(const f32x4 *)(sp + (size_t)(k < g.ks2 ? k : g.ks2 - 1) * g.slab_stride);   // all in flight
-                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (k < g.ks2) a += part[k];
-                a += c2;
-                if (m >= g.M) continue;
-                f16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] + (float)xres[t][e]);
-                *(f16x4 *)(g.X + (size_t)m * g.ldx + n) = o;
-            }
-            return;
+        for (int t = 0; t < MT; ++t) {
+            const int m = r0 + t * 16 + li;
+            const float *dstp = out + (size_t)(m < g.M ? m : g.M - 1) * g.N + n;      // rows past M: the last row's own value again
+            const f32x4 val = acc[t];
+            if (m < g.M) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dstp), "v"(val) : "memory");
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // every wave's slab stores are in memory; the activation tile is dead
+        int *last_flag = (int *)smem;
+        if (tid == 0) {
+            int *cnt = g.ticket + panel * g.n_rg + rg;
+            const int tk = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = tk == g.ks2 - 1 ? 1 : 0;
+            if (last) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *last_flag = last;
+        }
+        __syncthreads();
+        if (!*last_flag) return;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int m = r0 + t * 16 + li;
+            const float *sp = g.slabs + (size_t)(m < g.M ? m : g.M - 1) * g.N + n;
+            f32x4 part[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)                      // all in flight; coherent (sc1) reads of what the other XCDs wrote through
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(part[k]) : "v"(sp + (size_t)(k < g.ks2 ? k : g.ks2 - 1) * g.slab_stride) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(part[0]), "+v"(part[1]), "+v"(part[2]), "+v"(part[3]) : : "memory");
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < g.ks2) a += part[k];
+            a += c2;
+            if (m >= g.M) continue;
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (f16)(a[e] + (float)xres[t][e]);
+            *(f16x4 *)(g.X + (size_t)m * g.ldx + n) = o;
+        }
+        return;
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t) {

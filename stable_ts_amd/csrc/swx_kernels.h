@@ -47,10 +47,11 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_NO_FUSED_XQ 1048576  // decode step: cross-attention query projection as a launch of its own instead of inside the
                                       // cross-attention kernel (A/B; bit-identical)
 #define SWX_FLAG_TICKET 2097152       // decode step: the K-split projection's slabs reduced INSIDE the GEMM launch by the last-arriving K slice
-                                      // (release / ticket / acquire, DEC_TICKET) instead of by dec_slab_finish.  Built and measured in round 5,
-                                      // bit-identical, and SLOWER: 451.8 vs 432.6 ms per headline pass (+5.3 us per layer-step: the agent-scope
-                                      // release writes the XCD's L2 back and every slice drains, barriers and draws a ticket; the finish launch it
-                                      // replaces costs 4.8 us) -- profiles/r05_c5_bench_ticket_ab.json.  Off by default; kept for A/B.
+                                      // (DEC_TICKET) instead of by dec_slab_finish.  Built and measured in round 5 in two forms, both
+                                      // bit-identical: plain slab stores + agent-scope release / acquire fences 451.8 vs 432.6 ms per headline
+                                      // pass (the launch 17.0 us against 8.2 + 5.0); write-through `sc1` slab stores + drained ticket + `sc1`
+                                      // reads (the form kept) 432.4 vs 430.1 ms -- break-even at best, so off by default; kept for A/B
+                                      // (profiles/r05_c5_bench_ticket_ab.json, r05_c12_bench_ticket_sc1_ab.json).
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
