@@ -55,6 +55,7 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
     for name, lines in kernels.items():
         pending, in_asm, nload, first_barrier, last_mfma, drains = {}, False, 0, None, None, []
         pf_pending, n_pf = set(), 0            # L2-prefetch loads (global_load_dword): results unused, registers held to the final wait
+        red_pending, n_red = set(), 0          # DEC_TICKET: coherent slab reads of the in-launch reduction
         for i, ln in enumerate(lines):
             t = ln.strip()
             if t.startswith(";;#ASMSTART"):
@@ -69,6 +70,12 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
                 last_mfma = i
             if "scratch_" in t:
                 pytest.fail(f"{name}: scratch traffic: {t}")
+            if in_asm and t.startswith("global_load_dwordx4") and " sc1" in t:
+                # DEC_TICKET (round 5): the last arriver's coherent reads of the K slices' slabs, issued after the weight stream is
+                # long consumed; ONE asm `s_waitcnt vmcnt(0)` behind each batch of four releases them
+                red_pending |= _regs(t.split()[1].rstrip(","))
+                n_red += 1
+                continue
             if in_asm and t.startswith("global_load_dwordx4"):
                 for r in _regs(t.split()[1].rstrip(",")):
                     pending[r] = nload
@@ -80,7 +87,14 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
                 continue
             if in_asm and t.startswith("s_waitcnt vmcnt(0)") and not pending:
                 pf_pending.clear()               # the wave's last wait: every load has landed
+                red_pending.clear()
                 continue
+            if not in_asm and red_pending and t and not t.startswith((";", ".")):
+                used = set()
+                for tk in re.findall(r"v\[\d+:\d+\]|v\d+", t):
+                    used |= _regs(tk)
+                hit = used & red_pending
+                assert not hit, f"{name}: line {i}: `{t}` touches a slab read's register {sorted(hit)[:4]} before its wait"
             if not in_asm and pf_pending and t and not t.startswith((";", ".")):
                 used = set()
                 for tk in re.findall(r"v\[\d+:\d+\]|v\d+", t):
@@ -102,7 +116,8 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
                 assert not hit, f"{name}: line {i}: `{t}` touches asm-loaded registers {sorted(hit)[:4]} before their wait"
         assert nload in (12, 16, 20, 24, 32, 40), (name, nload)
         assert n_pf == 4, (name, n_pf)
-        assert not pending and not pf_pending, (name, len(pending), len(pf_pending))
+        assert not pending and not pf_pending and not red_pending, (name, len(pending), len(pf_pending), len(red_pending))
+        assert n_red in (0, 4, 8, 12), (name, n_red)                 # four slab reads per row tile of a DEC_TICKET instantiation
         assert first_barrier is not None and last_mfma is not None and first_barrier < last_mfma, name
         early = [d for d in drains if d < last_mfma]
         assert not early, f"{name}: s_waitcnt vmcnt(0) before the last MFMA (lines {early[:3]}): the weight stream is drained"
