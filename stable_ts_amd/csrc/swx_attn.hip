@@ -1120,6 +1120,26 @@ int swx_xkv_pack(const void *k, const void *vt, void *packed, int B, int H, int 
     return 0;
 }
 
+// The dynamic-LDS attribute of the four attn_flash_f32 instantiations, once per DEVICE (the attribute belongs to the device's code
+// object: a process that drives several GPUs sets it on each).  False when the device cannot grant 68 KB: the caller then takes
+// the VALU kernel instead of failing.
+static bool f32_flash_ready(bool vt, bool split)
+{
+    constexpr int MAX_DEV = 64;
+    static signed char state[MAX_DEV][4] = {};            // 0 unknown, 1 ready, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return false;
+    const int v = (vt ? 2 : 0) + (split ? 1 : 0);
+    if (state[dev][v] == 0) {
+        const void *fn = vt ? (split ? (const void *)attn_flash_f32<true, true> : (const void *)attn_flash_f32<true, false>)
+                            : (split ? (const void *)attn_flash_f32<false, true> : (const void *)attn_flash_f32<false, false>);
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F32_LDS_BYTES);
+        if (e != hipSuccess) (void)hipGetLastError();
+        state[dev][v] = e == hipSuccess ? 1 : -1;
+    }
+    return state[dev][v] > 0;
+}
+
 int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
 {
     if (a.B <= 0 || a.nq <= 0 || a.nk <= 0) return 0;
@@ -1185,24 +1205,23 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         else if (qb == 4) hipLaunchKernelGGL((attn_flash2_f16<true, 4>), g, dim3(256), 0, s, a);
         else if (qb == 3) hipLaunchKernelGGL((attn_flash2_f16<true, 3>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_flash2_f16<true, 2>), g, dim3(256), 0, s, a);
-    } else if (dtype == SWX_F32 && (force_kernel == 0 || force_kernel == 7) && a.vt_kp % F32_KT == 0) {
+    } else if (dtype == SWX_F32 && (force_kernel == 0 || force_kernel == 7) && a.vt_kp % F32_KT == 0 &&
+               // a transposed V is read as V[d][kt0 .. kt0 + 63] for every key tile: its row pitch must cover the padded key axis
+               (a.vt_kp == 0 || a.vt_kp >= cdiv(a.nk, F32_KT) * F32_KT) && f32_flash_ready(a.vt_kp != 0, a.nq <= 16)) {
         // strict f32 on the exact-f32 matrix instruction: queries <= 16 per batch item (decode step: HBM-bound, the four waves split
-        // the keys) or blocks of 128 queries (encoder self-attention, scoring pass: MFMA-bound)
+        // the keys) or blocks of 128 queries (encoder self-attention, scoring pass: MFMA-bound).  Where the 68 KB of dynamic LDS
+        // cannot be granted (f32_flash_ready: not gfx950) the launch falls through to the VALU kernel below.
         const bool split = a.nq <= 16;
         SwxProfScope prof(split ? PC_ATTN_ROWWISE : PC_ATTN_FLASH,
                           split ? (double)a.B * a.H * 64 * esz * (2.0 * a.nk + 2.0 * a.nq) : 4.0 * a.B * a.H * (double)a.nq * a.nk * 64, s);
         dim3 gd(split ? 1 : cdiv(a.nq, 128), a.H, a.B);
-#define SWX_F32_FLASH(VT_, SP_) do { \
-        static bool attr_done = false; \
-        if (!attr_done) { \
-            hipError_t e_ = hipFuncSetAttribute((const void *)attn_flash_f32<VT_, SP_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)F32_LDS_BYTES); \
-            if (e_ != hipSuccess) return -100 - (int)e_; \
-            attr_done = true; \
-        } \
-        hipLaunchKernelGGL((attn_flash_f32<VT_, SP_>), gd, dim3(256), F32_LDS_BYTES, s, a); } while (0)
-        if (a.vt_kp) { if (split) SWX_F32_FLASH(true, true); else SWX_F32_FLASH(true, false); }
-        else { if (split) SWX_F32_FLASH(false, true); else SWX_F32_FLASH(false, false); }
-#undef SWX_F32_FLASH
+        if (a.vt_kp) {
+            if (split) hipLaunchKernelGGL((attn_flash_f32<true, true>), gd, dim3(256), F32_LDS_BYTES, s, a);
+            else hipLaunchKernelGGL((attn_flash_f32<true, false>), gd, dim3(256), F32_LDS_BYTES, s, a);
+        } else {
+            if (split) hipLaunchKernelGGL((attn_flash_f32<false, true>), gd, dim3(256), F32_LDS_BYTES, s, a);
+            else hipLaunchKernelGGL((attn_flash_f32<false, false>), gd, dim3(256), F32_LDS_BYTES, s, a);
+        }
     } else {
         if (force_kernel == 7) return -5;
         // algorithmic bytes: K and V of every (window, head) once + q in + o out

@@ -478,9 +478,14 @@ __global__ __launch_bounds__(256) void decode_beam_update_kernel(DecodeBufs b, i
     __syncthreads();
     if (!frozen) {
         for (int ci = tid; ci < nc; ci += 256) {
-            const float mine = sc[ci];
+            // a TOTAL order even if a score is NaN (a numeric blow-up upstream of here): NaN ranks as -inf, so that `order` stays
+            // a permutation and lane 0 below never reads an unwritten slot; finite scores rank exactly as before
+            const float raw = sc[ci], mine = (raw != raw) ? -INFINITY : raw;
             int rank = 0;
-            for (int q = 0; q < nc; ++q) rank += (sc[q] > mine || (sc[q] == mine && q < ci)) ? 1 : 0;
+            for (int q = 0; q < nc; ++q) {
+                const float rq = sc[q], oq = (rq != rq) ? -INFINITY : rq;
+                rank += (oq > mine || (oq == mine && q < ci)) ? 1 : 0;
+            }
             order[rank] = (short)ci;
         }
     }

@@ -599,7 +599,8 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     const bool use_tall = g.tall && g.M > 160 && (g.kslice / 32) % 4 == 0 && !(swx_flags() & SWX_FLAG_NO_TALL);
     // SWX_FLAG_TICKET: the K-split projection of the decode-step kernel reduces its slabs inside the launch (measured slower: swx_kernels.h)
     const bool ticket = ks2 > 1 && ks2 <= 4 && !use_tall && g.ticket && epi == (DEC_RES | DEC_SLAB) && g.X &&
-                        (g.N / 64) * cdiv(g.M, mt * 16) <= SWX_DEC_TICKETS && (swx_flags() & SWX_FLAG_TICKET);
+                        (g.N / 64) * cdiv(g.M, mt * 16) <= SWX_DEC_TICKETS && (swx_flags() & SWX_FLAG_TICKET) &&
+                        g.N % 64 == 0;      // the kernel's early `n >= N` exit sits in front of a block barrier: whole panels only
     if (ticket) epi |= DEC_TICKET;
     if (use_tall) {
         // tall kernel: ~two rounds of the chip's 256 CUs, every workgroup a run of `tps` 16-row tiles

@@ -1139,6 +1139,12 @@ int swx_decode(swx_model *m, const swx_decode_cfg *cfg, const int32_t *d_init_to
     SWX_TRY(swx_decode_init(b, d_init_tokens, s));
 
     const size_t layer_stride = (size_t)m->max_rows * D.n_text_ctx * d * e;
+    if (g_debug_flags & SWX_FLAG_TICKET) {
+        // the in-launch slab reduction relies on arrival counters that every launch leaves at zero; a launch that was aborted (fault,
+        // reset) would leave them non-zero and every later job would silently pick the wrong last arriver: 16 KB, once per job
+        hipError_t e_ = hipMemsetAsync(m->ws + m->L.ticket, 0, (size_t)SWX_DEC_TICKETS * 4, s);
+        if (e_ != hipSuccess) return -100 - (int)e_;
+    }
     // ---- prefill: one row per window (row w*G), n_init tokens
     FwdCfg f{};
     f.W = W; f.rpw = 1; f.row_mul = G; f.n_new = n_init;
@@ -1515,7 +1521,9 @@ int swx_test_dec_gemm(const void *d_a, int64_t lda, const void *d_w, const float
     float *c2 = (float *)p; p += align_up((size_t)N * 4);
     float *slabs = (float *)p; p += slab_b;
     int *ticket = (int *)p;
-    { hipError_t e = hipMemsetAsync(ticket, 0, (size_t)SWX_DEC_TICKETS * 4, s); if (e != hipSuccess) return -100 - (int)e; }
+    // bit 7 of `epilogue`: the caller zeroed the counters ONCE and keeps one scratch buffer over its calls -- what the decode path does
+    // (swx_bind_workspace zeroes, the last arriver of every launch resets); without it every call starts from fresh counters
+    if (!(epilogue & 128)) { hipError_t e = hipMemsetAsync(ticket, 0, (size_t)SWX_DEC_TICKETS * 4, s); if (e != hipSuccess) return -100 - (int)e; }
     DecGemmArgs g{};
     g.A = (const f16 *)d_a; g.lda = lda; g.M = M; g.N = N; g.K = K; g.epi = epilogue; g.ldw = K;
     g.C = (f16 *)d_c; g.ldc = ldc; g.X = (f16 *)d_x; g.ldx = ldc; g.slabs = slabs; g.ticket = ticket;

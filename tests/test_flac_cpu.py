@@ -190,3 +190,57 @@ def test_loader_paths_take_flac(tmp_path):
     # ID3v2 tag in front of the marker
     tagged = b"ID3\x04\x00\x00" + bytes([0, 0, 0, 20]) + bytes(20) + data
     assert audio_io.is_flac(tagged) and np.array_equal(audio_io.load_audio(tagged), want)
+
+
+def test_forged_streaminfo_frame_count_is_refused_before_any_allocation():
+    """STREAMINFO's 36-bit sample count is untrusted input -- 2**36 - 1 frames declared by a ~1 KB stream must not
+    reach np.empty (a 512 GiB request) but raise the loader's RuntimeError (audio/__init__.py:215-221: RuntimeError for
+    audio that cannot be decoded)."""
+    _, data = _small_stream()
+    bad = bytearray(data)
+    si = 8                                   # "fLaC" + the 4-byte metadata block header; STREAMINFO: total samples = low nibble of
+    bad[si + 13] |= 0x0F                     # byte 13 + bytes 14..17
+    bad[si + 14: si + 18] = b"\xff\xff\xff\xff"
+    with pytest.raises(RuntimeError, match="declares 68719476735 sample frames"):
+        audio_io.read_flac(bytes(bad), verify_md5=False)
+    # a count that passes the size bound but is wrong is caught after decoding
+    bad = bytearray(data)
+    bad[si + 17] ^= 0x01
+    with pytest.raises(RuntimeError, match="sample frames it declares|Failed to load audio"):
+        audio_io.read_flac(bytes(bad), verify_md5=False)
+
+
+def test_is_flac_behind_an_id3_tag_never_reads_the_file(tmp_path, monkeypatch):
+    """most MP3s start with an ID3v2 tag; is_flac() must decide from 10 + 4 bytes, not slurp the file"""
+    p = tmp_path / "song.mp3"
+    p.write_bytes(b"ID3\x04\x00\x00" + bytes([0, 0, 0x10, 0]) + bytes(2048) + b"\xff\xfb\x90\x00" + bytes(1 << 20))
+    reads = []
+    real_open = audio_io._open_binary
+
+    class Spy:
+        def __init__(self, f):
+            self.f = f
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            self.f.close()
+
+        def read(self, n=-1):
+            out = self.f.read(n)
+            reads.append((n, len(out)))
+            return out
+
+        def seek(self, *a):
+            return self.f.seek(*a)
+
+    monkeypatch.setattr(audio_io, "_open_binary", lambda src: Spy(real_open(src)))
+    assert audio_io.is_flac(str(p)) is False
+    assert reads and all(n >= 0 for n, _ in reads) and sum(got for _, got in reads) <= 14, reads
+    reads.clear()
+    _, data = _small_stream()
+    q = tmp_path / "tagged.flac"
+    q.write_bytes(b"ID3\x04\x00\x00" + bytes([0, 0, 0, 20]) + bytes(20) + data)
+    assert audio_io.is_flac(str(q)) is True
+    assert sum(got for _, got in reads) <= 14, reads

@@ -25,7 +25,14 @@ Asserted per window (reference: whisper_word_level/original_whisper.py:251-260 f
  * word timestamps of the greedy transcript (~111 text tokens): where the device's DTW path leaves the oracle's, EVERY such detour
    (maximal stretch between two cells common to both paths) costs no more than 1e-3 of the path cost ON THE ORACLE'S matrix -- the
    oracle's own backtrace could have gone either way --, >= 97 % of the words within +-20 ms, token probabilities at the fp16 bar.
-Every case writes its numbers to gpurun_out/f16_bench_windows_report.json BEFORE asserting (copied to profiles/ per round)."""
+Every case writes its numbers to gpurun_out/f16_bench_windows_report.json BEFORE asserting (copied to profiles/ per round).
+
+Round 6: every case also runs in the STRICT mode (``dtype='f32'``, exact-f32 MFMA -- the mode bench.py's
+``strict_f32`` leg times on this very configuration), and there the north-star tolerances are asserted LITERALLY: greedy and beam-5
+token ids identical, |delta avg logprob| <= 1e-3, per-token |delta log p| <= 1e-3, DTW index path ``array_equal``, every word within
++-20 ms.  Should an f32 search ever part from the oracle's, the located near-tie machinery applies with the f32 budget F32_BUDGET
+(per-token maximum / mean of the strict mode against the oracle, as measured by the words case of this file: reported as
+``max_abs_dlogp`` in the f32 entries of the report)."""
 import gc
 import json
 import os
@@ -45,7 +52,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADS = ((7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6))   # large-v3's
 WINDOWS = (0, 7, 19)            # tests/test_gpu_batch_invariance.py::ALONE
+DTYPES = ("f16", "f32")
 STEPS, BEAM = 112, 5
+# strict mode: per-token |delta log p| against the oracle, (max, mean).  Measured on the three windows (profiles/r06_bench_windows_report.json,
+# "max_abs_dlogp" of the f32 words cases); the numbers here are the BUDGET of a located near-tie, i.e. a bound with margin on them.
+F32_BUDGET = (2e-4, 2e-5)
 _STATE = {}
 
 
@@ -70,8 +81,10 @@ def _report(name, payload):
         json.dump(data, f, indent=1)
 
 
-def _budget():
-    """per-token |delta log p| of the complete fp16 mode over 112 tokens, from the committed emulation (max, mean)"""
+def _budget(dtype="f16"):
+    """per-token |delta log p| of the complete fp16 mode over 112 tokens, from the committed emulation (max, mean); strict mode: F32_BUDGET"""
+    if dtype == "f32":
+        return F32_BUDGET
     with open(os.path.join(ROOT, "profiles", "r04_f16_error_budget_112.json")) as f:
         v = json.load(f)["variants"]["all of the above = the fp16 mode"]
     return float(v["max_dlogp"]), float(v["mean_dlogp"])
@@ -97,30 +110,37 @@ def _setup():
     for l, h in HEADS:
         mask[l, h] = True
     m.set_alignment_heads_mask(mask)
-    eng = Engine(ModelDimensions(**dims.__dict__), dtype="f16", max_windows=1, max_rows=BEAM, alignment_heads=HEADS)
-    eng.load_state_dict(sd)
+    engines, models = {}, {}
+    for dt in DTYPES:
+        engines[dt] = Engine(ModelDimensions(**dims.__dict__), dtype=dt, max_windows=1, max_rows=BEAM, alignment_heads=HEADS)
+        engines[dt].load_state_dict(sd)
+        models[dt] = sw.Whisper.from_engine(engines[dt])
     del sd
     gc.collect()
-    _STATE.update(oracle=m, engine=eng, model=sw.Whisper.from_engine(eng), dims=dims, windows={},
+    _STATE.update(oracle=m, engines=engines, models=models, dims=dims, windows={},
                   audio=bench.synth_audio(30.0 * 20, seed=0),          # what bench.py transcribes (--minutes 10)
                   tok=get_tokenizer(True, num_languages=m.num_languages, language="en", task="transcribe"))
     return _STATE
 
 
-def _window(st, k):
-    """window k of the benchmark's recording: oracle side on the oracle's log-mel, device side as a window alone"""
+def _window(st, k, dtype="f16"):
+    """window k of the benchmark's recording: oracle side on the oracle's log-mel, device side (one cross-K/V buffer per mode) as a
+    window alone.  The oracle's decodes are cached per window and shared by the two modes."""
     if k not in st["windows"]:
         from oracle.whisper.audio import log_mel_spectrogram
         seg = st["audio"][k * 480000:(k + 1) * 480000].contiguous()
         mel_ref = log_mel_spectrogram(seg, st["dims"].n_mels).float().contiguous()
         with torch.no_grad():
             xa_ref = st["oracle"].encoder(mel_ref[None])
-        model = st["model"]
-        mel = model.log_mel_batch([seg.cuda()], [0])
+        st["windows"][k] = dict(seg=seg, mel_ref=mel_ref, xa_ref=xa_ref, cache={}, dev={})
+    win = st["windows"][k]
+    if dtype not in win["dev"]:
+        model = st["models"][dtype]
+        mel = model.log_mel_batch([win["seg"].cuda()], [0])
         xa = model.encoder(mel)
-        st["windows"][k] = dict(mel_ref=mel_ref, xa_ref=xa_ref, xkv=model.cross_kv(xa), cache={},
-                                mel_max_abs_diff=float((mel[0].float().cpu() - mel_ref).abs().max()))
-    return st["windows"][k]
+        win["dev"][dtype] = dict(xkv=model.cross_kv(xa), mel_max_abs_diff=float((mel[0].float().cpu() - win["mel_ref"]).abs().max()),
+                                 xa_max_abs_diff=float((xa[0].float().cpu() - win["xa_ref"][0]).abs().max()))
+    return dict(win, engine=st["engines"][dtype], model=st["models"][dtype], dtype=dtype, **win["dev"][dtype])
 
 
 def _task(st, win, beam, n):
@@ -175,7 +195,7 @@ def _oracle_decode(st, win, beam, n):
 def _device_beams(st, win, beam, s, n):
     """the device's decode job cut after s steps: {sampled tokens: cumulative score} of every row, winner first"""
     task = _task(st, win, beam, n)
-    out = st["engine"].decode(win["xkv"], [list(task.initial_tokens)], n_group=task.n_group, beam=bool(beam), patience=None,
+    out = win["engine"].decode(win["xkv"], [list(task.initial_tokens)], n_group=task.n_group, beam=bool(beam), patience=None,
                               sample_len=s, sot_index=task.sot_index, min_tokens=n, **_tok_cfg(task))
     sb = out["sample_begin"]
     rows = []
@@ -217,11 +237,12 @@ def _oracle_score_of(st, win, beam, n, toks):
     return float(sum(_oracle_steps_of(st, win, beam, n, toks)[0]))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", WINDOWS)
-def test_bench_window_greedy_identical_or_located_near_tie(k):
+def test_bench_window_greedy_identical_or_located_near_tie(k, dtype):
     st = _setup()
-    win = _window(st, k)
-    mx, mean = _budget()
+    win = _window(st, k, dtype)
+    mx, mean = _budget(dtype)
     ref, _ = _oracle_decode(st, win, None, STEPS)
     rows, nsp = _device_beams(st, win, None, STEPS, STEPS)
     toks, s = rows[0]
@@ -229,11 +250,11 @@ def test_bench_window_greedy_identical_or_located_near_tie(k):
     n_same = next((i for i, (a, b) in enumerate(zip(toks, ref.tokens)) if a != b), min(len(toks), len(ref.tokens)))
     rep = dict(tokens=len(ref.tokens), identical_prefix=n_same, identical=list(toks) == list(ref.tokens), avg_logprob=(avg, ref.avg_logprob),
                text_tokens=sum(1 for t in ref.tokens if t < st["tok"].eot), no_speech=(nsp, ref.no_speech_prob),
-               mel_max_abs_diff_device_vs_oracle=win["mel_max_abs_diff"])
+               mel_max_abs_diff_device_vs_oracle=win["mel_max_abs_diff"], encoder_max_abs_diff_device_vs_oracle=win["xa_max_abs_diff"])
     assert len(ref.tokens) == STEPS and len(toks) == STEPS and rep["text_tokens"] >= 100, rep
     if rep["identical"]:
         rep["d_avg_logprob"] = abs(avg - ref.avg_logprob)
-        _report(f"window{k}/greedy112", rep)
+        _report(f"window{k}/greedy112/{dtype}", rep)
         assert rep["d_avg_logprob"] <= 1e-3, rep                 # north star: identical token ids, logprobs within 1e-3
     else:
         # a greedy search that leaves the oracle's at step i took, there, a token the ORACLE ranks within the fp16 budget of its own
@@ -249,19 +270,20 @@ def test_bench_window_greedy_identical_or_located_near_tie(k):
                    steps_where_device_token_is_not_the_oracle_argmax=[dict(step=i + 1, gap=gp, device=toks[i], oracle_argmax=best[i])
                                                                       for i, gp in enumerate(gaps) if gp > 0],
                    avg_logprob_of_device_sequence_by_oracle=rescored, d_avg_logprob_same_sequence=abs(avg - rescored))
-        _report(f"window{k}/greedy112", rep)
+        _report(f"window{k}/greedy112/{dtype}", rep)
         assert best[n_same] == ref.tokens[n_same], rep           # identical prefix: the teacher-forced arg-max there is the oracle's token
         assert 0 < gaps[n_same] <= 2 * mx, rep                   # the located near-tie
         assert max(gaps) <= 2 * mx, rep                          # ... and no step anywhere that is more than a near-tie
         assert rep["d_avg_logprob_same_sequence"] <= 1e-3, rep   # logprobs within 1e-3 on the same tokens
-    assert abs(nsp - ref.no_speech_prob) <= 1e-4 + 5e-2 * ref.no_speech_prob, rep
+    assert abs(nsp - ref.no_speech_prob) <= 1e-4 + (5e-2 if dtype == "f16" else 1e-3) * ref.no_speech_prob, rep
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", WINDOWS)
-def test_bench_window_beam5_identical_or_located_near_tie(k):
+def test_bench_window_beam5_identical_or_located_near_tie(k, dtype):
     st = _setup()
-    win = _window(st, k)
-    mx, mean = _budget()
+    win = _window(st, k, dtype)
+    mx, mean = _budget(dtype)
     ref, trace = _oracle_decode(st, win, BEAM, STEPS)
     assert len(trace) == STEPS and len(ref.tokens) == STEPS
     rows, _ = _device_beams(st, win, BEAM, STEPS, STEPS)
@@ -269,10 +291,16 @@ def test_bench_window_beam5_identical_or_located_near_tie(k):
     avg = s_dev / (len(toks) + 1)
     rep = dict(tokens=len(ref.tokens), winner_identical=list(toks) == list(ref.tokens), avg_logprob_device=avg,
                avg_logprob_oracle_winner=ref.avg_logprob, text_tokens=sum(1 for t in ref.tokens if t < st["tok"].eot),
-               budget_per_token=dict(max_dlogp=mx, mean_dlogp=mean, source="profiles/r04_f16_error_budget_112.json"))
+               budget_per_token=dict(max_dlogp=mx, mean_dlogp=mean,
+                                     source="profiles/r04_f16_error_budget_112.json" if dtype == "f16" else "F32_BUDGET (this file)"))
     if rep["winner_identical"]:
         rep["d_avg_logprob"] = abs(avg - ref.avg_logprob)
-        _report(f"window{k}/beam112", rep)
+        # every one of the five final beams, not only the winner: the same sequences with the same cumulative scores
+        o_kept = trace[-1]["kept"]
+        rep["final_beam_sets_identical"] = {t for t, _ in rows} == set(o_kept)
+        if rep["final_beam_sets_identical"]:
+            rep["final_beam_max_abs_dsum_logprob"] = max(abs(sc - o_kept[t]) for t, sc in rows)
+        _report(f"window{k}/beam112/{dtype}", rep)
         assert rep["d_avg_logprob"] <= 1e-3, rep
         return
     # ---- locate the first step at which the two searches hold different beams
@@ -288,7 +316,7 @@ def test_bench_window_beam5_identical_or_located_near_tie(k):
         o_of = {t: v for t, v in trace[-1]["kept"].items()}
         gap = (o_of[tuple(ref.tokens)] - o_of[tuple(toks)]) / (STEPS + 1)
         rep.update(final_ranking_gap_avg_logprob=gap)
-        _report(f"window{k}/beam112", rep)
+        _report(f"window{k}/beam112/{dtype}", rep)
         assert 0 <= gap <= 2 * (mx + STEPS * mean) / (STEPS + 1), rep
         return
     tr = trace[first - 1]
@@ -312,7 +340,7 @@ def test_bench_window_beam5_identical_or_located_near_tie(k):
     # (d) / (e): the device's winner under the oracle
     rescored = _oracle_score_of(st, win, BEAM, STEPS, toks) / (len(toks) + 1)
     rep.update(avg_logprob_of_device_sequence_by_oracle=rescored, d_avg_logprob_same_sequence=abs(avg - rescored))
-    _report(f"window{k}/beam112", rep)
+    _report(f"window{k}/beam112/{dtype}", rep)
     assert not missing, rep
     assert len(only_d) == len(only_o) >= 1, rep
     assert rep["kept_score_max_abs_diff"] <= mx + first * mean, rep                     # (b)
@@ -350,18 +378,19 @@ def detours(ti, tj, ri, rj, neg):
     return out
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", WINDOWS)
-def test_bench_window_words_of_the_greedy_transcript(k):
+def test_bench_window_words_of_the_greedy_transcript(k, dtype):
     from stable_ts_amd.timing import AlignmentJob, find_alignment_batch
     st = _setup()
-    win = _window(st, k)
+    win = _window(st, k, dtype)
     tok = st["tok"]
     ref, _ = _oracle_decode(st, win, None, STEPS)
     text = [x for x in ref.tokens if x < tok.eot]
     ref_words, cache = ost.find_alignment(st["oracle"], tok, list(text), win["mel_ref"], 480000, audio_features=win["xa_ref"],
                                           return_cache=True)
     job = AlignmentJob(tok, list(text), 480000)
-    words = find_alignment_batch(st["model"], [job], win["xkv"], return_debug=True)[0]
+    words = find_alignment_batch(win["model"], [job], win["xkv"], return_debug=True)[0]
     ri, rj = cache["dtw_path"]
     ti, tj = job.debug["path"]
     neg = cache["neg_matrix"].double().numpy()
@@ -371,16 +400,25 @@ def test_bench_window_words_of_the_greedy_transcript(k):
     p_got = np.asarray(job.debug["token_probs"], dtype=np.float64)[:len(p_ref)]
     mid = (p_ref > 1e-30) & (p_ref < 0.99)
     dt = np.asarray([(abs(a.start - b.start), abs(a.end - b.end)) for a, b in zip(words, ref_words)])
-    over = np.abs(np.log(p_got[mid]) - np.log(p_ref[mid])) / (2e-2 + 1e-3 * np.abs(np.log(p_ref[mid])))
+    dlp = np.abs(np.log(p_got[mid]) - np.log(p_ref[mid]))
+    over = dlp / (2e-2 + 1e-3 * np.abs(np.log(p_ref[mid])))
     rep = dict(words=len(ref_words), text_tokens=len(text), same_word_split=[w.word for w in words] == [w.word for w in ref_words],
                dtw_path_identical=bool(np.array_equal(ti, ri) and np.array_equal(tj, rj)), path_cost_oracle=cost_ref,
                detours=[dict(d, extra_cost_rel=d["extra_cost"] / abs(cost_ref)) for d in det],
                within_20ms=float(((dt[:, 0] <= 0.0201) & (dt[:, 1] <= 0.0201)).mean()), max_dt=float(dt.max()),
                words_off=[dict(word=a.word, start=(a.start, b.start), end=(a.end, b.end)) for a, b in zip(words, ref_words)
                           if abs(a.start - b.start) > 0.0201 or abs(a.end - b.end) > 0.0201],
-               max_dlogprob_over_tol=float(over.max()) if mid.any() else None, unsaturated_tokens=int(mid.sum()))
-    _report(f"window{k}/words112", rep)
+               max_dlogprob_over_tol=float(over.max()) if mid.any() else None, unsaturated_tokens=int(mid.sum()),
+               max_abs_dlogp=float(dlp.max()) if mid.any() else None, mean_abs_dlogp=float(dlp.mean()) if mid.any() else None,
+               neg_matrix_max_abs_diff=float(np.abs(job.debug["neg_matrix"] - neg).max()) if "neg_matrix" in job.debug else None)
+    _report(f"window{k}/words112/{dtype}", rep)
     assert rep["same_word_split"] and rep["words"] >= 20, rep
+    if dtype == "f32":
+        # the strict mode carries the north star literally: bit-exact DTW index path, every word within +-20 ms, per-token 1e-3
+        assert rep["dtw_path_identical"], rep
+        assert rep["within_20ms"] == 1.0, rep
+        assert rep["max_abs_dlogp"] is None or rep["max_abs_dlogp"] <= 1e-3, rep
+        return
     for d in rep["detours"]:
         assert -1e-6 <= d["extra_cost_rel"] <= 1e-3, (d, rep)         # every moved stretch is a near-tie of the oracle's own DTW
     assert rep["within_20ms"] >= 0.97, rep

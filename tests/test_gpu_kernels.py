@@ -373,8 +373,13 @@ def test_new_kernel_paths_in_subprocess(check):
 
 
 # ------------------------------------------------------------------------------------- decode-step "dec" GEMM
-def _dec_gemm(a, w, *, gamma=None, beta=None, bias=None, x=None, epi=0, d=0, n_ctx=0, pos0=None):
-    """calls swx_test_dec_gemm; returns dict(c=..., x=..., kcache=..., vcache=...) as CPU float32 arrays"""
+def _dec_scratch_bytes(M, N, K):
+    return N * K * 2 + 8 * N + 16 * M * N * 4 + 8192 + 4096 * 4
+
+
+def _dec_gemm(a, w, *, gamma=None, beta=None, bias=None, x=None, epi=0, d=0, n_ctx=0, pos0=None, scratch=None):
+    """calls swx_test_dec_gemm; returns dict(c=..., x=..., kcache=..., vcache=...) as CPU float32 arrays.  ``scratch``: a zeroed
+    buffer the caller keeps over several calls (epi bit 128: the library then leaves the arrival counters as the last launch left them)"""
     lib = _lib()
     M, K = a.shape
     N = w.shape[0]
@@ -391,7 +396,8 @@ def _dec_gemm(a, w, *, gamma=None, beta=None, bias=None, x=None, epi=0, d=0, n_c
         kc = torch.zeros(M, n_ctx, d, dtype=torch.float16, device=dev)
         vc = torch.zeros(M, n_ctx, d, dtype=torch.float16, device=dev)
         tp = torch.from_numpy(np.asarray(pos0, np.int32)).to(dev)
-    scratch = torch.empty(N * K * 2 + 8 * N + 16 * M * N * 4 + 8192 + 4096 * 4, dtype=torch.uint8, device=dev)
+    if scratch is None:
+        scratch = torch.empty(_dec_scratch_bytes(M, N, K), dtype=torch.uint8, device=dev)
     rc = lib.swx_test_dec_gemm(_p(ta), K, _p(tw), None if tg is None else _p(tg), None if tb is None else _p(tb), _p(tbias),
                                _p(tc), ldc, None if tx is None else _p(tx), None if kc is None else _p(kc),
                                None if vc is None else _p(vc), None if tp is None else _p(tp), n_ctx, d, M, N, K, epi,
@@ -435,8 +441,9 @@ def test_dec_gemm_residual(M, N, K):
 def test_dec_gemm_slab_reduction_inside_the_launch_is_bit_identical(M, N, K):
     # round 5: the K slices of a (panel, row group) draw a ticket after publishing their f32 slab, the last arriver reduces
     # (DEC_TICKET, SWX_FLAG_TICKET: measured slower than the separate dec_slab_finish launch, so off by default) -- against the
-    # separate launch: equal bits, 8 repetitions (the arrival order of the slices changes from run to run; the counters must be
-    # back at zero for the next launch)
+    # separate launch: equal bits, 8 repetitions on ONE scratch buffer whose counters are zeroed once, before the first launch (epi bit
+    # 128: no memset inside the call) -- as in the decode path, every launch must leave the counters at zero for the next one
+    # (with a fresh buffer and a memset per call the self-reset was never exercised)
     lib = _lib()
     rng = np.random.default_rng(M * 5 + N + K)
     a = rng.standard_normal((M, K)).astype(np.float32) * 0.5
@@ -448,8 +455,9 @@ def test_dec_gemm_slab_reduction_inside_the_launch_is_bit_identical(M, N, K):
         lib.swx_debug_flags(prev & ~2097152)
         ref = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16)["x"]
         lib.swx_debug_flags(prev | 2097152)
+        scratch = torch.zeros(_dec_scratch_bytes(M, N, K), dtype=torch.uint8, device="cuda")
         for rep in range(8):
-            got = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16)["x"]
+            got = _dec_gemm(a, w, bias=b, x=x, epi=4 | 16 | 128, scratch=scratch)["x"]
             assert np.array_equal(got, ref), (rep, float(np.abs(got - ref).max()))
     finally:
         lib.swx_debug_flags(prev)
