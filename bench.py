@@ -204,7 +204,9 @@ def main():
         # the start-up); weak scaling: the recording grows with the number of ranks.
         base = synth_audio(min(seconds, 600.0), seed=0)
         reps = int(np.ceil(seconds * world / (base.shape[0] / 16000.0)))
-        audio = base.repeat(reps)[: int(seconds * world * 16000)].to(dev)
+        audio = base.repeat(reps)[: int(seconds * world * 16000)]
+        if not args.host_audio:
+            audio = audio.to(dev)
     else:
         audio = synth_audio(seconds, seed=rank)
         if not args.host_audio:
@@ -253,7 +255,9 @@ def main():
     torch.cuda.synchronize()
     par.barrier()
     import torch.distributed as _dist
-    dt = par.max_over_ranks(time.perf_counter() - t0, device=dev if _dist.is_initialized() else None)
+    # RCCL reduces device tensors; the CPU dry run of this plumbing (tests/test_bench_dist_cpu.py, gloo) reduces on the host
+    dt = par.max_over_ranks(time.perf_counter() - t0,
+                            device=dev if _dist.is_initialized() and _dist.get_backend() == "nccl" else None)
 
     log(f"timed region done: {dt:.3f}s for {args.steps} steps")
     ab = None

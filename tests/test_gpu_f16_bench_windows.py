@@ -55,7 +55,8 @@ WINDOWS = (0, 7, 19)            # tests/test_gpu_batch_invariance.py::ALONE
 DTYPES = ("f16", "f32")
 STEPS, BEAM = 112, 5
 # strict mode: per-token |delta log p| against the oracle, (max, mean).  Measured on the three windows (profiles/r06_bench_windows_report.json,
-# "max_abs_dlogp" of the f32 words cases); the numbers here are the BUDGET of a located near-tie, i.e. a bound with margin on them.
+# "max_abs_dlogp" / "mean_abs_dlogp" of the f32 words cases): 4.0e-5 / 4.0e-5 / 5.0e-5 and 3.9e-6 / 5.4e-6 / 7.3e-6; the numbers here are
+# the BUDGET of a located near-tie: 4x / 3x those.  (Round 6 on hardware: no f32 search parted from the oracle's, so it was never used.)
 F32_BUDGET = (2e-4, 2e-5)
 _STATE = {}
 
