@@ -88,7 +88,8 @@ def main():
         # the encoder at 20 / 8 / 4 windows: 7 = 128 x 128 tiles overlapped through occupancy, 12 = the 256 x 256 kernel (gemm_f16_big8)
         print("-- tiled MFMA GEMM at large M: us per launch (TFLOP/s) by force_kernel")
         codes = [7, 12, 0]
-        print("  " + " " * 28 + "".join(f"{c:>18d}" for c in codes))
+        print("  " + " " * 28 + "".join(f"{c:>18d}" for c in codes) + "   12, grouped tile order")
+        flags0 = lib.swx_debug_flags(-1)
         for M, N, K in [(30000, 1280, 1280), (30000, 3840, 1280), (30000, 5120, 1280), (30000, 1280, 5120), (30000, 2560, 1280),
                         (12000, 1280, 1280), (12000, 3840, 1280), (12000, 5120, 1280), (12000, 1280, 5120),
                         (6000, 3840, 1280), (6000, 5120, 1280), (6000, 1280, 5120), (60000, 1280, 384), (30000, 1280, 3840)]:
@@ -96,10 +97,13 @@ def main():
             bias = torch.zeros(N, device=dev)
             row = []
             epi = EPI_BIAS | (2 if N == 5120 else 0)          # the MLP's first projection carries the GELU
-            for code in codes:
-                rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, epi, code, st)
-                row.append(timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, epi, code, st),
+            for code in codes + [-12]:
+                fk = abs(code)
+                lib.swx_debug_flags((flags0 | 4194304) if code < 0 else flags0)       # -12: SWX_FLAG_BIG8_GROUPED
+                rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, epi, fk, st)
+                row.append(timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, epi, fk, st),
                                  max(args.iters // 10, 5)) if rc == 0 else float("nan"))
+                lib.swx_debug_flags(flags0)
             print(f"  M={M:6d} N={N:6d} K={K:5d}:" + "".join(f"{u:9.1f} ({2.0 * M * N * K / u / 1e6:6.0f})" for u in row))
 
     if args.only in ("flash_small",):

@@ -627,10 +627,28 @@ __global__ __launch_bounds__(512) void gemm_f16_big8(GemmArgs g)
     const int wm_u = wave_u >> 2;
     int bx = blockIdx.x, by = blockIdx.y;
     {
-        const int gx = gridDim.x, nwg = gx * gridDim.y, orig = by * gx + bx;
+        // Workgroup `orig` runs on XCD orig % 8 (round-robin dispatch); XCD x takes the contiguous range [start(x), start(x + 1)) of
+        // a tile LIST, its k-th workgroup the k-th entry of that range -- so the ~32 tiles an XCD runs at one time are 32 neighbours
+        // of the list.  The list is row-major.  At N = 5120 (20 column tiles) those 32 neighbours span every column, i.e. the whole
+        // 13.1 MB weight matrix streams through the XCD's 4 MB L2 once per 256-row band (counters, round 5: 1.49 GB per launch for
+        // 397 MB algorithmic).  Round 6 built the alternative (tile_order 1, SWX_FLAG_BIG8_GROUPED): GROUPS of 4 column tiles walked
+        // along M, the last group taking the remainder -- 32 neighbours = 8 row bands x 4 column bands, the group's weight bands
+        // (2.6 MB at K = 1280) resident in L2 for the whole walk.  A pure renumbering, bit-identical
+        // (tests/hw_checks/gemm_big8_check.py runs both orders) -- and NOT faster: 458 vs 453 us at N = 5120 + GELU, 384 vs 372 us at
+        // K = 5120, 291 vs 284 us at N = 3840 (profiles/r06_c2_kb_gemm_big_tile_order.txt), 427.0 vs 425.5 ms per headline pass.  The
+        // re-streamed operands come out of the 256 MB Infinity Cache, whose bandwidth the launch does not exhaust: the extra
+        // fabric traffic costs nothing, so the default stays row-major.
+        const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy, orig = by * gx + bx;
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        bx = wg % gx; by = wg / gx;
+        if (g.tile_order != 1 || gx <= 4) { bx = wg % gx; by = wg / gx; }
+        else {
+            constexpr int GN = 4;
+            const int nfull = gx / GN, per = GN * gy;            // tiles per full group
+            const int grp = wg / per;
+            if (grp < nfull) { const int rem = wg - grp * per; by = rem / GN; bx = grp * GN + (rem - by * GN); }
+            else { const int gl = gx - nfull * GN, rem = wg - nfull * per; by = rem / gl; bx = nfull * GN + (rem - by * gl); }
+        }
     }
     const int m0 = by * BG, n0 = bx * BG;
     const f16 *A = (const f16 *)g.A;
@@ -1154,8 +1172,11 @@ int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s)
             SwxProfScope prof(PC_GEMM_TILED, 2.0 * (double)g.M * g.N * g.K, s);
             const dim3 grid(cdiv(g.N, BN), cdiv(g.M, BM));
             switch (plan) {
-                case SWX_GEMM_BIG:
-                    hipLaunchKernelGGL(gemm_f16_big8, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * B8_BUF, s, g); break;
+                case SWX_GEMM_BIG: {
+                    GemmArgs gb = g;
+                    gb.tile_order = (swx_flags() & SWX_FLAG_BIG8_GROUPED) ? 1 : 0;
+                    hipLaunchKernelGGL(gemm_f16_big8, dim3(cdiv(g.N, BG), cdiv(g.M, BG)), dim3(512), 2 * B8_BUF, s, gb); break;
+                }
                 case SWX_GEMM_RING64: launch_ring<64, 3>(g, s); break;
                 case SWX_GEMM_RING128: launch_ring<128, 3>(g, s); break;
                 case SWX_GEMM_GLDS64: hipLaunchKernelGGL(gemm_f16_glds_64, dim3(cdiv(g.N, 64), grid.y), dim3(256), 0, s, g); break;

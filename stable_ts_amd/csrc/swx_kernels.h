@@ -22,6 +22,8 @@ struct GemmArgs {
     int M, N, K;
     int epi;
     int vt_s, vt_kp; int64_t vt_bs;   // EPI_STORE_VT: rows per batch item, padded key stride, element stride between batch items
+    int tile_order;                   // gemm_f16_big8 only, set by swx_gemm: 0 = row-major, 1 = an XCD's concurrent tiles share a band of
+                                      // weights that fits its L2 (groups of 4 column tiles, walked along M; SWX_FLAG_BIG8_GROUPED)
 };
 int swx_gemm(int dtype, const GemmArgs &g, int force_kernel, hipStream_t s);
 // the f16 kernel a launch gets (swx_gemm.hip; a pure function of the shape, the epilogue and the switches)
@@ -52,6 +54,9 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
                                       // pass (the launch 17.0 us against 8.2 + 5.0); write-through `sc1` slab stores + drained ticket + `sc1`
                                       // reads (the form kept) 432.4 vs 430.1 ms -- break-even at best, so off by default; kept for A/B
                                       // (profiles/r05_c5_bench_ticket_ab.json, r05_c12_bench_ticket_sc1_ab.json).
+#define SWX_FLAG_BIG8_GROUPED 4194304 // 256 x 256 GEMM: tiles listed in groups of 4 column tiles walked along M instead of row-major (A/B;
+                                      // bit-identical).  Built in round 6 to cut the N = 5120 launch's 3.8x fabric traffic: measured neutral to
+                                      // 3 % SLOWER at every encoder shape (profiles/r06_c2_kb_gemm_big_tile_order.txt), so off by default
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

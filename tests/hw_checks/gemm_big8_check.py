@@ -38,7 +38,9 @@ def main() -> int:
               (30000, 1280, 1280, EPI_BIAS | EPI_RES), (30000, 2560, 1280, EPI_BIAS), (12000, 1280, 1280, EPI_BIAS | EPI_RES),
               (6000, 5120, 1280, EPI_BIAS | EPI_GELU), (256, 256, 128, 0), (256, 256, 192, EPI_BIAS), (257, 263, 256, EPI_BIAS | EPI_RES),
               (1000, 1152, 3840, EPI_BIAS | EPI_RES), (515, 520, 640, EPI_BIAS | EPI_GELU | EPI_RES), (77, 136, 128, EPI_BIAS | EPI_RES),
-              (4500, 3840, 1280, EPI_BIAS), (3000, 1000, 1280, EPI_BIAS)]
+              (4500, 3840, 1280, EPI_BIAS), (3000, 1000, 1280, EPI_BIAS),
+              # round 6 (the grouped tile order behind SWX_FLAG_BIG8_GROUPED: groups of 4 column tiles + a remainder group): 6 / 9 / 13 column tiles, ragged M
+              (5000, 1536, 256, EPI_BIAS), (2100, 2304, 384, EPI_BIAS | EPI_RES), (1300, 3300, 128, EPI_BIAS)]
     for (M, N, K, epi) in shapes:
         a = (torch.randn(M, K, generator=g) * 0.5).half().to(dev)
         w = (torch.randn(N, K, generator=g) * 0.03).half().to(dev)
@@ -60,8 +62,12 @@ def main() -> int:
         with torch.cuda.stream(side):                                    # background traffic for the whole repetition loop
             for _ in range(15 * args.reps):
                 junk_b.copy_(junk_a, non_blocking=True)
+        flags0 = lib.swx_debug_flags(-1)
         for rep in range(args.reps):
+            # even repetitions: the row-major tile order (the default), odd ones: the grouped order (SWX_FLAG_BIG8_GROUPED)
+            lib.swx_debug_flags((flags0 | 4194304) if rep & 1 else (flags0 & ~4194304))
             rc13, c13 = run(12)
+            lib.swx_debug_flags(flags0)
             same = rc13 == 0 and torch.equal(c13[:, :N], c1[:, :N])
             wrong += not same
         torch.cuda.synchronize()
