@@ -27,7 +27,8 @@ def main() -> int:
     for (R, H, d, n_ctx, pos_lo, pos_hi, use_anc) in [(100, 20, 1280, 448, 3, 120, True), (100, 20, 1280, 448, 120, 447, True),
                                                       (5, 20, 1280, 448, 200, 447, True), (5, 20, 1280, 448, 128, 129, False),
                                                       (40, 8, 512, 448, 0, 447, True), (7, 6, 384, 448, 250, 400, False),
-                                                      (100, 20, 1280, 448, 127, 128, True), (33, 20, 1280, 448, 380, 447, True)]:
+                                                      (100, 20, 1280, 448, 127, 128, True), (33, 20, 1280, 448, 380, 447, True),
+                                                      (15, 6, 384, 448, 0, 127, True), (600, 20, 1280, 448, 3, 120, True)]:
         q = (torch.randn(R, d, generator=g) * 0.8).half().to(dev)
         kc = (torch.randn(R, n_ctx, d, generator=g) * 0.8).half().to(dev)
         vc = torch.randn(R, n_ctx, d, generator=g).half().to(dev)
@@ -39,8 +40,10 @@ def main() -> int:
             anc[torch.arange(R), pos.cpu().long()] = torch.arange(R).int()      # the newest position is the row's own (the beam
             anc = anc.to(dev)                                                    # update writes it so; the step kernel assumes it)
         outs = {}
-        for variant in (0, 1, 2):
-            if variant == 0 and pos_hi >= 128:
+        # + 8 * 5 (round 6): the decode loop's launch for windows of five beams -- workgroups numbered so that the beams of a window
+        # share an XCD, position and ancestor ids requested together
+        for variant in (0, 1, 2) + ((0 + 40, 1 + 40) if R % 5 == 0 else ()):
+            if (variant & 7) == 0 and pos_hi >= 128:
                 continue
             o = torch.full((R, d), float("nan"), dtype=torch.half, device=dev)
             rc = lib.swx_test_self_attn_step(p(q), p(kc), p(vc), p(anc), p(pos), R, H, n_ctx, d, variant, p(o), st)

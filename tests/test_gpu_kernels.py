@@ -356,7 +356,8 @@ def test_attention_f32_mfma_edges(B, H, nq, nk):
         assert (o.cpu() - o1.cpu()).abs().max().item() < 3e-5, kp
 
 
-@pytest.mark.parametrize("check", ["gemm_glds_check.py", "gemm_big8_check.py", "mel_ragged_check.py", "score_qk_check.py"])
+@pytest.mark.parametrize("check", ["gemm_glds_check.py", "gemm_big8_check.py", "mel_ragged_check.py", "score_qk_check.py",
+                                   "self_attn_step_check.py"])
 def test_new_kernel_paths_in_subprocess(check):
     # gemm_f16_glds / gemm_f16_ring / gemm_f16_big8 (the direct-to-LDS tiled GEMMs vs the register-staged kernel: bit-identical) and
     # swx_log_mel_ragged (the un-padded spectrogram of refine / locate; index logic CPU-checked in test_mel_ragged_cpu),
