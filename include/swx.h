@@ -287,8 +287,7 @@ int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k,
                        void *d_o, int64_t ldo, int B, int H, int nq, int nk, int force_kernel, int vt_kp, void *stream);
 
 /* decode-step self-attention (f16): variant 0 = the single-token kernel without long-context code (positions < 128), 1 = the
- * single-token kernel, 2 = the general cached-attention kernel (their bit-identity reference); + 8 * G: the decode loop's launch for
- * windows of G rows (the G rows of a window that share a head are numbered onto one XCD; R % G == 0).  d_q [R][d]; caches
+ * single-token kernel, 2 = the general cached-attention kernel (their bit-identity reference).  d_q [R][d]; caches
  * [R_phys][n_ctx][d] with the new token's K / V already at position pos0[r] of row r; d_anc [R][n_ctx] or NULL; d_o [R][d]. */
 int swx_test_self_attn_step(const void *d_q, void *d_kcache, void *d_vcache, const int32_t *d_anc, const int32_t *d_pos0,
                             int R, int H, int n_ctx, int d, int variant, void *d_o, void *stream);

@@ -888,48 +888,24 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
 // shuffles).  Arithmetic order is self_attn_cached's, so both paths agree bit for bit.
 // HBM traffic: K and V of every cached position of every row once = R * (pos + 1) * d * 2 * 2 bytes per launch (57 MB at
 // position 111 for 100 rows of large-v3: at the end of a window's decode this kernel is bandwidth-, not latency-bound).
-template <bool LONG, bool REMAP>
+template <bool LONG>
 __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
 {
     constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
     __shared__ float qs[DH];
     __shared__ float ps[512];
-    const int lane = threadIdx.x;
-    int h = blockIdx.x, r = blockIdx.y;
-    if (REMAP) {
-        // Round 6.  The hardware deals workgroup L = y * gridDim.x + x to XCD L % 8.  Numbered (row, head) as above, the five beams
-        // of a window land on two XCDs for a given head, and every K / V row they have in common (profiles/r06_beam_prefix_stats.json:
-        // the five beams of the benchmark hold 2.8-3.8 distinct rows per position, i.e. 25-45 % of their reads are duplicates) is
-        // fetched into two L2s.  Here L is read as (beam g, window w, head h) with g slowest and the (w, h) block padded to a
-        // multiple of 8 by the launcher: the beams of (w, h) differ by a multiple of 8 in L, so they share an XCD and its L2.
-        const int L = blockIdx.y * gridDim.x + blockIdx.x;
-        const int per = gridDim.x;                         // windows x heads, padded to a multiple of 8 (idle tail workgroups exit)
-        const int g = L / per, rem = L - g * per;
-        const int w = rem / a.H;
-        h = rem - w * a.H;
-        r = w * a.group + g;
-        if (r >= a.R || w * a.group >= a.R) return;
-    }
+    const int lane = threadIdx.x, h = blockIdx.x, r = blockIdx.y;
     const int d = a.d;
+    const int pos = a.pos0[r];
     const int32_t *anc = a.anc ? a.anc + (size_t)r * a.n_ctx : nullptr;
     const f16 *kc = (const f16 *)a.kcache, *vc = (const f16 *)a.vcache;
     const int j0 = lane, j1 = lane + 64;
-    const int32_t *ap = anc ? anc : a.pos0;
-    int pos, pr0, pr1;
-    if (REMAP) {
-        // the row's position and its ancestor ids of positions lane / lane + 64 in ONE round trip: the table has n_ctx >= 128 entries
-        // per row whatever the position, so the loads need not wait for it (round 5: position -> ids -> K rows, three round trips)
-        const int t0 = anc ? anc[j0] : 0, t1 = anc ? anc[j1] : 0;
-        pos = a.pos0[r];
-        pr0 = (anc && j0 < pos) ? t0 : r; pr1 = (anc && j1 < pos) ? t1 : r;
-    } else {
-        pos = a.pos0[r];
-        // ancestor ids: clamped unconditional loads + select (a predicated load would cost its own round trip)
-        const bool old0 = j0 < pos, old1 = j1 < pos;       // the ancestor table covers the older positions; the new one is row r's own
-        const int t0 = ap[(anc && old0) ? j0 : 0], t1 = ap[(anc && old1) ? j1 : 0];
-        pr0 = (anc && old0) ? t0 : r; pr1 = (anc && old1) ? t1 : r;
-    }
     const bool has0 = j0 <= pos, has1 = j1 <= pos;         // positions that live in the cache (the new one included)
+    // ancestor ids: clamped unconditional loads + select (a predicated load would cost its own round trip)
+    const int32_t *ap = anc ? anc : a.pos0;
+    const bool old0 = j0 < pos, old1 = j1 < pos;           // the ancestor table covers the older positions; the new one is row r's own
+    const int t0 = ap[(anc && old0) ? j0 : 0], t1 = ap[(anc && old1) ? j1 : 0];
+    const int pr0 = (anc && old0) ? t0 : r, pr1 = (anc && old1) ? t1 : r;
     qs[lane] = (float)((const f16 *)a.qkv)[(size_t)r * a.ldqkv + h * DH + lane];
     // ---- K rows of positions lane, lane + 64 and the V fragments of positions < 128: one batch of loads
     f16x8 k0[8], k1[8];
@@ -1307,16 +1283,8 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
         if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.skip_append) return -5;
         // (a decode whose positions stay below 128 -- no prompt carried over -- takes the variant without the long-context code:
         // 157 instead of 211 registers, three waves per SIMD)
-        const bool shortk = a.pos_bound > 0 && a.pos_bound <= 128;
-        const bool remap = a.group >= 1 && a.R % a.group == 0 && a.n_ctx >= 128 && !(swx_flags() & SWX_FLAG_SELFATTN_R5);
-        if (remap) {
-            const dim3 gr(cdiv((a.R / a.group) * a.H, 8) * 8, a.group);
-            if (shortk) hipLaunchKernelGGL((self_attn_step_f16<false, true>), gr, dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((self_attn_step_f16<true, true>), gr, dim3(64), 0, s, a);
-        } else {
-            if (shortk) hipLaunchKernelGGL((self_attn_step_f16<false, false>), dim3(a.H, a.R), dim3(64), 0, s, a);
-            else hipLaunchKernelGGL((self_attn_step_f16<true, false>), dim3(a.H, a.R), dim3(64), 0, s, a);
-        }
+        if (a.pos_bound > 0 && a.pos_bound <= 128) hipLaunchKernelGGL(self_attn_step_f16<false>, dim3(a.H, a.R), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(self_attn_step_f16<true>, dim3(a.H, a.R), dim3(64), 0, s, a);
         SWX_CHECK_LAUNCH();
         return 0;
     }

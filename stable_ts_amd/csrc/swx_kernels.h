@@ -57,8 +57,6 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_BIG8_GROUPED 4194304 // 256 x 256 GEMM: tiles listed in groups of 4 column tiles walked along M instead of row-major (A/B;
                                       // bit-identical).  Built in round 6 to cut the N = 5120 launch's 3.8x fabric traffic: measured neutral to
                                       // 3 % SLOWER at every encoder shape (profiles/r06_c2_kb_gemm_big_tile_order.txt), so off by default
-#define SWX_FLAG_SELFATTN_R5 8388608   // decode-step self-attention as in round 5: workgroups numbered (row, head) and the ancestor ids requested
-                                      // after the row's position has arrived (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
@@ -182,8 +180,6 @@ struct SelfAttnArgs {
     int step_pos;                    // profiler only: position of the new token when the host knows it (decode loop), else 0
     int pos_bound;                   // decode step: an upper bound of every row's position known to the host (initial tokens + sample
                                      // budget), or 0 = unknown.  <= 128: the kernel variant without the code for positions >= 128
-    int group;                       // decode step: rows per window (beams); > 1: the launch numbers its workgroups so that the rows of a
-                                     // window that share a head run on ONE XCD (their common ancestors' K / V rows meet in its L2)
 };
 // logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);

@@ -405,7 +405,7 @@ int decoder_step_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         SelfAttnArgs sa{};
         sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = rows; sa.n_new = 1; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1; sa.step_cached = 1;
-        sa.step_pos = f.step_pos; sa.pos_bound = f.pos_bound; sa.group = f.rpw;
+        sa.step_pos = f.step_pos; sa.pos_bound = f.pos_bound;
         SWX_TRY(swx_self_attention(m->dtype, sa, 1, s));
         // x += att Wo^T + bo
         g = DecGemmArgs{};
@@ -1551,8 +1551,6 @@ int swx_test_self_attn_step(const void *d_q, void *d_kcache, void *d_vcache, con
     SelfAttnArgs sa{};
     sa.qkv = d_q; sa.ldqkv = d; sa.kcache = d_kcache; sa.vcache = d_vcache; sa.anc = (int32_t *)d_anc; sa.pos0 = d_pos0;
     sa.o = d_o; sa.ldo = d; sa.R = R; sa.n_new = 1; sa.H = H; sa.n_ctx = n_ctx; sa.d = d; sa.skip_append = 1;
-    sa.group = variant >> 3;                          // rows per window: > 0 = the decode loop's launch (beams of a window on one XCD)
-    variant &= 7;
     sa.step_cached = variant < 2 ? 1 : 0;
     sa.pos_bound = variant == 0 ? 128 : 0;
     return swx_self_attention(SWX_F16, sa, 1, S(stream));

@@ -40,10 +40,8 @@ def main() -> int:
             anc[torch.arange(R), pos.cpu().long()] = torch.arange(R).int()      # the newest position is the row's own (the beam
             anc = anc.to(dev)                                                    # update writes it so; the step kernel assumes it)
         outs = {}
-        # + 8 * 5 (round 6): the decode loop's launch for windows of five beams -- workgroups numbered so that the beams of a window
-        # share an XCD, position and ancestor ids requested together
-        for variant in (0, 1, 2) + ((0 + 40, 1 + 40) if R % 5 == 0 else ()):
-            if (variant & 7) == 0 and pos_hi >= 128:
+        for variant in (0, 1, 2):
+            if variant == 0 and pos_hi >= 128:
                 continue
             o = torch.full((R, d), float("nan"), dtype=torch.half, device=dev)
             rc = lib.swx_test_self_attn_step(p(q), p(kc), p(vc), p(anc), p(pos), R, H, n_ctx, d, variant, p(o), st)
