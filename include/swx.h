@@ -220,7 +220,10 @@ int swx_median_filter(const float *d_x, int64_t rows, int n, int width, float *d
  * k == 0), out[w][1 + j] = |x[idx[w][j]]| (0 for an index outside [0, n)).  The floating-point part of the analysis stays in
  * host code on these values (stable_ts_amd/stabilization.py::loudness_from_probe). */
 int swx_loudness_probe(const float *d_pcm, int64_t pcm_stride, const int32_t *d_nk, const int32_t *d_idx, int n_idx, int W,
-                       float *d_out, void *stream);
+                       float *d_out, void *d_scratch, size_t scratch_bytes, void *stream);
+/* d_scratch (>= swx_loudness_probe_scratch_bytes(W) bytes, or NULL): with it and fewer than 16 windows the selection runs spread over
+ * the chip (a forced-alignment pass analyses one window per call); without it one workgroup per window.  The same element either way. */
+size_t swx_loudness_probe_scratch_bytes(int W);
 
 /* ---- f2 audio front-end: FLAC decoding on the HOST (no device work; csrc/swx_flac.hip).  The reference pipes every container
  * through an `ffmpeg -f s16le` child process (stable_whisper/audio/utils.py:63-125); offline boxes have no ffmpeg and the

@@ -82,7 +82,23 @@ def main():
                 rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, code, st)
                 row.append(timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS, code, st),
                                  max(args.iters // 4, 5)) if rc == 0 else float("nan"))
-            print(f"  M={M:6d} N={N:6d} K={K:5d}:" + "".join(f"{u:9.1f}" for u in row))
+            # the dispatch's kernel with COLD weights (rotating through 600 MB of copies: more than the 256 MB Infinity Cache holds), which
+            # is how a batch-1 encoder meets them (1.27 GB of weights per window), and with a side stream touching the next copy while
+            # the current launch runs (what a weight prefetch one GEMM ahead would do)
+            ws = weight_copies(rnd, N, K)
+            cold = timed(lambda i: lib.swx_test_gemm(1, p(a), K, p(ws[i % len(ws)]), p(bias), None, p(c), N, M, N, K, EPI_BIAS, 0, st),
+                         max(args.iters // 4, 5))
+            side = torch.cuda.Stream()
+            sink = torch.empty(1, dtype=torch.float32, device=dev)
+
+            def with_prefetch(i):
+                nxt = ws[(i + 1) % len(ws)]
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    sink.copy_(nxt.view(-1)[::32].float().sum().reshape(1), non_blocking=True)      # touches every 64-byte line
+                lib.swx_test_gemm(1, p(a), K, p(ws[i % len(ws)]), p(bias), None, p(c), N, M, N, K, EPI_BIAS, 0, st)
+            pf = timed(with_prefetch, max(args.iters // 4, 5))
+            print(f"  M={M:6d} N={N:6d} K={K:5d}:" + "".join(f"{u:9.1f}" for u in row) + f"   cold {cold:7.1f}   cold + side-stream touch of the next {pf:7.1f}")
 
     if args.only in ("gemm_big",):
         # the encoder at 20 / 8 / 4 windows: 7 = 128 x 128 tiles overlapped through occupancy, 12 = the 256 x 256 kernel (gemm_f16_big8)

@@ -79,7 +79,8 @@ SYMBOLS = {
     "swx_align_weights": (c_int, [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int32), c_float, c_int, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
     "swx_median_filter": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
-    "swx_loudness_probe": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "swx_loudness_probe": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "swx_loudness_probe_scratch_bytes": (c_size_t, [c_int]),
     "swx_flac_probe": (c_int, [c_void_p, c_size_t, POINTER(swx_flac_info)]),
     "swx_flac_decode": (c_int64, [c_void_p, c_size_t, c_void_p, c_int64, POINTER(swx_flac_info)]),
     "swx_dtw_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

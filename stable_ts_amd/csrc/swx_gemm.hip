@@ -54,8 +54,8 @@ constexpr int CLD = BN + 4;                 // f32 staging row of the epilogue
 // staged: loaded per row group after the previous group's store (a store through a f16 pointer may alias the f32 bias, so
 // hipcc keeps the order) they were eight dependent L2 round trips per tile -- 43 % of a K = 1280 launch (see below).
 template <int NJ>      // NJ 16-column fragments per wave: tile width BNT = 32 NJ (128 or 64 columns)
-__device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][NJ], int m0, int n0,
-                                                     int tid, int lane, int wm, int wn)
+__device__ __forceinline__ void tile_epilogue_f16_one(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][NJ], int m0, int n0,
+                                                         int tid, int lane, int wm, int wn)
 {
     constexpr int BNT = 32 * NJ, WN = 16 * NJ;        // tile width, columns per wave
     constexpr int CLD_ = BNT + 4;
@@ -182,6 +182,25 @@ __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned ch
         }
         if (half == 0) __syncthreads();
     }
+}
+
+// EPI_KV (round 6): the K and the V projection of a decoder layer's cross-attention as ONE launch over the fused weight rows -- a
+// tile left of N / 2 takes the K epilogue (rows grouped per window), a tile right of it the V epilogue (transposed per head into
+// C2, columns counted from N / 2).  Workgroup-uniform; per element the arithmetic of the two separate launches.
+template <int NJ>
+__device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][NJ], int m0, int n0,
+                                                     int tid, int lane, int wm, int wn)
+{
+    if (!(g.epi & EPI_KV)) { tile_epilogue_f16_one<NJ>(g, smem, acc, m0, n0, tid, lane, wm, wn); return; }
+    GemmArgs h = g;
+    const int half = g.N >> 1;
+    if (n0 >= half) {
+        h.epi = (g.epi & ~(EPI_KV | EPI_CBATCH)) | EPI_STORE_VT;
+        h.C = (f16 *)g.C2 - (size_t)half * g.vt_kp;          // the V epilogue addresses by the absolute column
+    } else {
+        h.epi = (g.epi & ~(EPI_KV | EPI_STORE_VT)) | EPI_CBATCH;
+    }
+    tile_epilogue_f16_one<NJ>(h, smem, acc, m0, n0, tid, lane, wm, wn);
 }
 
 

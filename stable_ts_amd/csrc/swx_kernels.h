@@ -11,6 +11,9 @@
 #define EPI_RESF32MOD 16
 #define EPI_CBATCH 64        // C rows are grouped in batch items of vt_s rows, vt_bs elements apart (row-major inside an item)
 #define EPI_STORE_VT 32     // store C transposed per head: C[((row / vt_s) * (N/64) + col/64) * 64 + col%64][row % vt_s] with row stride vt_kp
+#define EPI_KV 128          // f16 tiled kernels only: ONE launch for the cross-attention K and V projections of a layer (fused weight rows
+                            // [2d][d]): columns [0, N/2) are stored like EPI_CBATCH into C, columns [N/2, N) like EPI_STORE_VT into C2
+                            // (column index relative to N/2); N/2 is a multiple of the tile width, so a tile is one or the other
 
 struct GemmArgs {
     const void *A; int64_t lda;     // [M][K] compute dtype
@@ -19,6 +22,7 @@ struct GemmArgs {
     const void *R; int64_t ldr;     // residual, compute dtype (may alias C)
     const float *Rf; int res_mod;   // f32 residual [res_mod][N], row index = m % res_mod
     void *C; int64_t ldc;           // compute dtype, or f32 with EPI_OUT_F32
+    void *C2;                       // EPI_KV: base of the transposed half
     int M, N, K;
     int epi;
     int vt_s, vt_kp; int64_t vt_bs;   // EPI_STORE_VT: rows per batch item, padded key stride, element stride between batch items
@@ -57,6 +61,8 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_BIG8_GROUPED 4194304 // 256 x 256 GEMM: tiles listed in groups of 4 column tiles walked along M instead of row-major (A/B;
                                       // bit-identical).  Built in round 6 to cut the N = 5120 launch's 3.8x fabric traffic: measured neutral to
                                       // 3 % SLOWER at every encoder shape (profiles/r06_c2_kb_gemm_big_tile_order.txt), so off by default
+#define SWX_FLAG_XKV_TWO_LAUNCHES 8388608 // cross-K/V projection as two launches (K, then V) instead of one over the fused weight rows (A/B; bit-identical)
+#define SWX_FLAG_LOUDNESS_ONE_WG 16777216  // silence analysis probe: always the one-workgroup-per-window selection kernel (A/B; the same element)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

@@ -74,15 +74,106 @@ __global__ __launch_bounds__(LP_T) void loudness_probe_kernel(const float *__res
     }
 }
 
+// ---- the same selection spread over the chip (round 6).  One workgroup per window is fine for a batch of windows (20 workgroups
+// side by side) but a forced-alignment pass analyses ONE window per call: a single workgroup walks 480 000 samples four times,
+// 108-410 us per window = 3 % of align()'s pass (profiles/r06_c7_align_kernels.csv).  Here every radix pass is a launch of NB
+// workgroups per window (LDS histogram with the run-length trick above, non-empty bins flushed to the window's global histogram
+// of that pass) followed by a one-workgroup pick of the digit; the last pick also gathers the index list.  A selection: the result
+// is the same element of the input whatever the order of the counting.
+constexpr int LPM_T = 256;
+
+struct LpState { unsigned prefix, remaining; };
+
+__global__ __launch_bounds__(LPM_T) void lp_hist_kernel(const float *__restrict__ pcm, int64_t pcm_stride, const int32_t *__restrict__ nk,
+                                                        const LpState *__restrict__ st, unsigned *__restrict__ hist, int pass)
+{
+    __shared__ unsigned h[256];
+    const int w = blockIdx.y, tid = threadIdx.x;
+    const int n = nk[2 * w], k = nk[2 * w + 1];
+    if (k <= 0 || k > n) return;
+    const unsigned *x = (const unsigned *)(pcm + (size_t)w * pcm_stride);
+    h[tid] = 0u;
+    __syncthreads();
+    const unsigned prefix = pass == 3 ? 0u : st[w].prefix;
+    const unsigned hi_mask = pass == 3 ? 0u : (0xFFFFFFFFu << (8 * (pass + 1)));
+    unsigned run_d = 0xFFFFFFFFu, run_n = 0u;
+    for (int i = blockIdx.x * LPM_T + tid; i < n; i += gridDim.x * LPM_T) {
+        const unsigned b = x[i] & 0x7FFFFFFFu;
+        if ((b & hi_mask) == (prefix & hi_mask)) {
+            const unsigned d = (b >> (8 * pass)) & 255u;
+            if (d == run_d) ++run_n;
+            else {
+                if (run_n) atomicAdd(&h[run_d], run_n);
+                run_d = d; run_n = 1u;
+            }
+        }
+    }
+    if (run_n) atomicAdd(&h[run_d], run_n);
+    __syncthreads();
+    if (h[tid]) atomicAdd(&hist[((size_t)w * 4 + pass) * 256 + tid], h[tid]);
+}
+
+// grid (W), 256 threads: the digit of this pass from the window's complete histogram; after the last pass the threshold and the gather
+__global__ __launch_bounds__(LPM_T) void lp_pick_kernel(const float *__restrict__ pcm, int64_t pcm_stride, const int32_t *__restrict__ nk,
+                                                        LpState *__restrict__ st, const unsigned *__restrict__ hist, int pass,
+                                                        const int32_t *__restrict__ idx, int n_idx, float *__restrict__ out)
+{
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const int n = nk[2 * w], k = nk[2 * w + 1];
+    const bool valid = k > 0 && k <= n;
+    float *o = out + (size_t)w * (n_idx + 1);
+    if (valid && tid == 0) {
+        const unsigned *h = hist + ((size_t)w * 4 + pass) * 256;
+        const unsigned prefix = pass == 3 ? 0u : st[w].prefix;
+        unsigned cum = 0, rem = pass == 3 ? (unsigned)k : st[w].remaining;
+        int d = 255;
+        for (; d > 0; --d) {
+            if (cum + h[d] >= rem) break;
+            cum += h[d];
+        }
+        st[w].remaining = rem - cum;
+        st[w].prefix = prefix | ((unsigned)d << (8 * pass));
+        if (pass == 0) o[0] = __uint_as_float(st[w].prefix);
+    }
+    if (pass != 0) return;
+    if (!valid && tid == 0) o[0] = __builtin_nanf("");
+    const unsigned *x = (const unsigned *)(pcm + (size_t)w * pcm_stride);
+    const int32_t *ix = idx + (size_t)w * n_idx;
+    for (int j = tid; j < n_idx; j += LPM_T) {
+        const int i = ix[j];
+        o[1 + j] = (i >= 0 && i < n) ? __uint_as_float(x[i] & 0x7FFFFFFFu) : 0.f;
+    }
+}
+
 }  // namespace
 
+extern "C" size_t swx_loudness_probe_scratch_bytes(int W)
+{
+    return W > 0 ? (size_t)W * (4 * 256 * sizeof(unsigned) + sizeof(LpState)) : 0;
+}
+
 extern "C" int swx_loudness_probe(const float *d_pcm, int64_t pcm_stride, const int32_t *d_nk, const int32_t *d_idx, int n_idx,
-                                  int W, float *d_out, void *stream)
+                                  int W, float *d_out, void *d_scratch, size_t scratch_bytes, void *stream)
 {
     if (W <= 0) return 0;
     if (!d_pcm || !d_nk || !d_out || n_idx < 0 || (n_idx > 0 && !d_idx)) return -1;
-    hipLaunchKernelGGL(loudness_probe_kernel, dim3(W), dim3(LP_T), 0, (hipStream_t)stream, d_pcm, pcm_stride, d_nk, d_idx, n_idx,
-                       d_out);
+    hipStream_t s = (hipStream_t)stream;
+    // few windows (forced alignment, the sequential window loop): the selection spread over the chip, nine short launches;
+    // a batch of windows: one workgroup per window, one launch
+    if (W < 16 && d_scratch && !(swx_flags() & SWX_FLAG_LOUDNESS_ONE_WG)) {
+        if (scratch_bytes < swx_loudness_probe_scratch_bytes(W)) return -8;
+        unsigned *hist = (unsigned *)d_scratch;
+        LpState *st = (LpState *)(hist + (size_t)W * 4 * 256);
+        { hipError_t e = hipMemsetAsync(hist, 0, (size_t)W * 4 * 256 * sizeof(unsigned), s); if (e != hipSuccess) return -100 - (int)e; }
+        const int nb = W >= 8 ? 32 : 64;
+        for (int pass = 3; pass >= 0; --pass) {
+            hipLaunchKernelGGL(lp_hist_kernel, dim3(nb, W), dim3(LPM_T), 0, s, d_pcm, pcm_stride, d_nk, st, hist, pass);
+            hipLaunchKernelGGL(lp_pick_kernel, dim3(W), dim3(LPM_T), 0, s, d_pcm, pcm_stride, d_nk, st, hist, pass, d_idx, n_idx, d_out);
+        }
+        SWX_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(loudness_probe_kernel, dim3(W), dim3(LP_T), 0, s, d_pcm, pcm_stride, d_nk, d_idx, n_idx, d_out);
     SWX_CHECK_LAUNCH();
     return 0;
 }

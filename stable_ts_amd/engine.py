@@ -492,7 +492,9 @@ def loudness_probe(chunks: Sequence[torch.Tensor]) -> list:
     d_nk = torch.from_numpy(h_nk).to(dev)
     out = torch.empty(W, n_idx + 1, dtype=torch.float32, device=dev)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    check(lib.swx_loudness_probe(_ptr(buf), stride, _ptr(d_nk), _ptr(d_idx), n_idx, W, _ptr(out), stream), "swx_loudness_probe")
+    scratch = torch.empty(max(int(lib.swx_loudness_probe_scratch_bytes(W)), 16), dtype=torch.uint8, device=dev)
+    check(lib.swx_loudness_probe(_ptr(buf), stride, _ptr(d_nk), _ptr(d_idx), n_idx, W, _ptr(out), _ptr(scratch), scratch.numel(),
+                                 stream), "swx_loudness_probe")
     h = out.cpu()
     res = []
     for w, (n, ix) in enumerate(zip(ns, idxs)):

@@ -526,7 +526,23 @@ def test_loudness_probe_kernel():
     g = torch.Generator().manual_seed(5)
     cases += [torch.randn(480000, generator=g) * s for s in (1.0, 1e-3, 30.0)]
     cases += [torch.full((480000,), 0.25), torch.cat([torch.zeros(479000), torch.ones(1000) * 0.5])]     # ties at the threshold
-    probes = loudness_probe([c.cuda() for c in cases])
+    lib = _lib()
+    prev = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(prev | 16777216)                                            # one workgroup per window, whatever the batch
+        probes = loudness_probe([c.cuda() for c in cases])
+    finally:
+        lib.swx_debug_flags(prev)
+    # round 6: fewer than 16 windows per call (forced alignment: one) take the selection that is spread over the chip (radix passes as
+    # launches of 64 / 32 workgroups per window); the same element, the same gathered samples
+    singles = [loudness_probe([c.cuda()])[0] for c in cases]
+    fives = [pr for i in range(0, len(cases), 5) for pr in loudness_probe([c.cuda() for c in cases[i:i + 5]])]
+    nines = [pr for i in range(0, len(cases), 9) for pr in loudness_probe([c.cuda() for c in cases[i:i + 9]])]
+    for ref, *others in zip(probes, singles, fives, nines):
+        for o in others:
+            assert (ref is None) == (o is None)
+            if ref is not None:
+                assert ref[0] == o[0] and np.float32(ref[1]).tobytes() == np.float32(o[1]).tobytes() and torch.equal(ref[3], o[3])
     n_checked = 0
     for x, pr in zip(cases, probes):
         n = x.numel()
@@ -552,3 +568,28 @@ def test_loudness_probe_kernel():
         assert r1["is_silent"] == r2["is_silent"]
         n_checked += 1
     assert n_checked >= 12
+
+
+@pytest.mark.parametrize("name,B", [("tiny.en", 1), ("base.en", 1), ("base.en", 3)])
+def test_cross_kv_from_one_launch_equals_two_launches(name, B):
+    # round 6: the K and V projections of a decoder layer's cross-attention as ONE GEMM launch over the fused weight rows (EPI_KV: a
+    # tile is a K tile or a V^T tile) against the two launches of rounds 1-5 (swx_debug_flags 8388608): the whole cross-K/V buffer --
+    # K rows, V^T blocks and the fragment-ordered copy the decode steps stream -- bit for bit
+    import stable_ts_amd as sw
+    lib = _lib()
+    dims = sw.dims_for(name)
+    model = sw.Whisper(dims, device="cuda:0", dtype="f16", max_windows=B, max_rows=B)
+    model.load_state_dict(sw.random_state_dict(dims, seed=7, std=0.05))
+    g = torch.Generator().manual_seed(B)
+    xa = (torch.randn(B, dims.n_audio_ctx, dims.n_audio_state, generator=g) * 0.7).half().cuda()
+    prev = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(prev | 8388608)
+        two = model.cross_kv(xa).clone()
+        lib.swx_debug_flags(prev & ~8388608)
+        one = model.cross_kv(xa).clone()
+    finally:
+        lib.swx_debug_flags(prev)
+    torch.cuda.synchronize()
+    assert one.numel() == two.numel() and torch.equal(one, two), int((one != two).sum())
+    assert float(one.view(torch.float16).float().abs().max()) > 0.1        # not a buffer of zeros
