@@ -246,9 +246,11 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const f16 *__restrict_
 // f16(rstd (acc - mean c1) + c2) in a 2 KB LDS tile the attention part reads its query fragments from -- the statistics, the
 // k-step order and the epilogue expression of swx_decstep.hip::gemm_dec_f16<1, FQ, DEC_LN>, so q is bit-identical to the separate
 // launch (tests: test_decode_f16_fused_cross_query_is_bit_identical).  The first K / V^T block is requested before any of it.
-template <bool PACKED, int QG, int FQ>
+template <bool PACKED, int QG, int FQ, int XV = 0>     // XV: 0 one key block per wave in flight (rounds 2-5); 1: two, with nt loads (round 6)
 __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
 {
+    constexpr bool NT = XV == 1 && PACKED;
+    constexpr int DEPTH = XV == 0 ? 1 : 2;
     __shared__ float sm_m[4][16], sm_l[4][16];
     __shared__ float sm_o[4][DH][17];
     extern __shared__ __attribute__((aligned(1024))) unsigned char fq_smem[];   // FQ: [16][FQ * 32] f16 | float2 stat[16] | f16 q[16][64]
@@ -282,9 +284,15 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
         if constexpr (PACKED) {
             const int blk = cb < nblk ? cb : nblk - 1;
 #pragma unroll
-            for (int f = 0; f < 4; ++f) kf[f] = *(const f16x8 *)(Kpk + ((size_t)blk * 4 + f) * 512);
+            for (int f = 0; f < 4; ++f) {
+                const f16x8 *kp_ = (const f16x8 *)(Kpk + ((size_t)blk * 4 + f) * 512);
+                kf[f] = NT ? __builtin_nontemporal_load(kp_) : *kp_;
+            }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) vf[t] = *(const f16x8 *)(Vpk + ((size_t)blk * 4 + t) * 512);
+            for (int t = 0; t < 4; ++t) {
+                const f16x8 *vp_ = (const f16x8 *)(Vpk + ((size_t)blk * 4 + t) * 512);
+                vf[t] = NT ? __builtin_nontemporal_load(vp_) : *vp_;
+            }
             return;
         }
         const int k0 = (cb < nblk ? cb : nblk - 1) << 5;    // tail prefetch re-reads the last block: loads are never predicated
@@ -446,7 +454,33 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
             }
         }
     };
-    {
+    if constexpr (DEPTH > 1) {
+        // Round 6: DEPTH key blocks in flight per wave.  The loop below issues a block's eight loads and waits for them in the same
+        // iteration (the compiled loop: 8 loads, vmcnt(7) .. vmcnt(0), 8 MFMAs), so a wave pays one memory round trip per block --
+        // twelve per launch -- and the launch has W x H x 4 waves x 8 KB = 12.8 MB in flight: by Little's law ~5.5 TB/s at the ~2.3 us
+        // a loaded round trip takes, which is what the kernel measures.  Here block n + DEPTH of the wave is requested before block
+        // n + 1 is multiplied.  Same blocks in the same order per wave: bit-identical.  Loads past the wave's last block re-read it
+        // (clamped, never predicated: a predicated load costs a drained join).  The stages are unconditional inside the loop and the
+        // remainder follows it: with a stage under an `if` the wait in front of the first stage has to assume the shorter path and
+        // drains the younger blocks' loads too (seen in the ISA of the first form).  Measured on the headline pass, A/B in one process
+        // (profiles/r06_c12_*): two blocks + nt 427.3 ms, two blocks 429.8, three blocks + nt 428.9, one block (round 5) 432.9.
+        f16x8 kS[DEPTH][4], vS[DEPTH][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { kS[0][f] = kA[f]; vS[0][f] = vA[f]; }
+#pragma unroll
+        for (int dd = 1; dd < DEPTH; ++dd) load_blk(wave + 4 * dd, kS[dd], vS[dd]);
+        int cb = wave;
+        for (; cb + 4 * (DEPTH - 1) < nblk; cb += 4 * DEPTH) {
+#pragma unroll
+            for (int dd = 0; dd < DEPTH; ++dd) {
+                compute_blk(cb + 4 * dd, kS[dd], vS[dd]);
+                load_blk(cb + 4 * (DEPTH + dd), kS[dd], vS[dd]);
+            }
+        }
+#pragma unroll
+        for (int dd = 0; dd < DEPTH - 1; ++dd)
+            if (cb + 4 * dd < nblk) compute_blk(cb + 4 * dd, kS[dd], vS[dd]);
+    } else {
         compute_blk(wave, kA, vA);                           // nblk >= 4: every wave owns at least one block
 #pragma unroll 2
         for (int cb = wave + 4; cb < nblk; cb += 4) {
@@ -490,6 +524,13 @@ __global__ __launch_bounds__(256) void attn_decode_cross_f16(AttnArgs a) { attn_
 // (W x H = 400 workgroups stream K / V^T concurrently; at one per CU they would run in two rounds) -- two blocks per CU = 256 registers
 template <int FQ>
 __global__ __launch_bounds__(256, 2) void attn_decode_cross_xq_f16(AttnArgs a) { attn_decode_cross_body<true, 1, FQ>(a); }
+// round 6: the K / V^T stream -- 384 KB per (window, head) that ONE workgroup reads once per step and nobody reads again for 5 GB of
+// other traffic -- with two key blocks of a wave in flight and the non-temporal load policy (MI355X_MICROARCH.md, row `nt-weights`);
+// SWX_FLAG_XATTN_R5 keeps the one-block loop above as its bit-identity reference
+template <int FQ>
+__global__ __launch_bounds__(256, 2) void attn_decode_cross_xq2_f16(AttnArgs a) { attn_decode_cross_body<true, 1, FQ, 1>(a); }
+template <bool PACKED, int QG>
+__global__ __launch_bounds__(256) void attn_decode_cross2_f16(AttnArgs a) { attn_decode_cross_body<PACKED, QG, 0, 1>(a); }
 
 // ================================================================================================ flash f32 (round 5)
 // Strict-f32 mode on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32: f32 operands, f32 accumulate).  Until round 5 every
@@ -1163,10 +1204,12 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         const int qg = (a.nq <= 16 || wgs1 <= 512) ? 1 : (ngrp >= 4 && wgs1 > 2048) ? 4 : 2;
         dim3 gd(a.H, a.B, cdiv(ngrp, qg));
         const bool packed = a.kv_packed && !(swx_flags() & SWX_FLAG_NO_PACKED_XKV);     // else row-layout K / V^T: the reference
+        const bool r5_loop = (swx_flags() & SWX_FLAG_XATTN_R5) != 0;                    // one key block per wave in flight (A/B)
         if (packed && a.fq_w && qg == 1 && a.nq <= 16) {
             // fused query projection: + [16][K] residual tile, statistics, q tile in dynamic LDS
             const int fq = a.fq_k / 32;
             const size_t lds = (size_t)16 * a.fq_k * 2 + 16 * sizeof(float2) + 16 * DH * 2;
+
 #define SWX_XQ(FQ_) do { \
             static bool attr_done = false; \
             if (!attr_done) { \
@@ -1174,7 +1217,14 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
                 if (e_ != hipSuccess) return -100 - (int)e_; \
                 attr_done = true; \
             } \
-            hipLaunchKernelGGL((attn_decode_cross_xq_f16<FQ_>), gd, dim3(256), lds, s, a); } while (0)
+            static bool attr_done2 = false; \
+            if (!r5_loop && !attr_done2) { \
+                hipError_t e_ = hipFuncSetAttribute((const void *)attn_decode_cross_xq2_f16<FQ_>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+                if (e_ != hipSuccess) return -100 - (int)e_; \
+                attr_done2 = true; \
+            } \
+            if (!r5_loop) hipLaunchKernelGGL((attn_decode_cross_xq2_f16<FQ_>), gd, dim3(256), lds, s, a); \
+            else hipLaunchKernelGGL((attn_decode_cross_xq_f16<FQ_>), gd, dim3(256), lds, s, a); } while (0)
             switch (fq) {
                 case 12: SWX_XQ(12); break; case 16: SWX_XQ(16); break; case 20: SWX_XQ(20); break;
                 case 24: SWX_XQ(24); break; case 32: SWX_XQ(32); break; case 40: SWX_XQ(40); break;
@@ -1183,9 +1233,15 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
 #undef SWX_XQ
         } else if (packed) {
             if (a.fq_w) return -5;
-            if (qg == 1) hipLaunchKernelGGL((attn_decode_cross_f16<true, 1>), gd, dim3(256), 0, s, a);
-            else if (qg == 2) hipLaunchKernelGGL((attn_decode_cross_f16<true, 2>), gd, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((attn_decode_cross_f16<true, 4>), gd, dim3(256), 0, s, a);
+            if (r5_loop) {
+                if (qg == 1) hipLaunchKernelGGL((attn_decode_cross_f16<true, 1>), gd, dim3(256), 0, s, a);
+                else if (qg == 2) hipLaunchKernelGGL((attn_decode_cross_f16<true, 2>), gd, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((attn_decode_cross_f16<true, 4>), gd, dim3(256), 0, s, a);
+            } else {
+                if (qg == 1) hipLaunchKernelGGL((attn_decode_cross2_f16<true, 1>), gd, dim3(256), 0, s, a);
+                else if (qg == 2) hipLaunchKernelGGL((attn_decode_cross2_f16<true, 2>), gd, dim3(256), 0, s, a);
+                else hipLaunchKernelGGL((attn_decode_cross2_f16<true, 4>), gd, dim3(256), 0, s, a);
+            }
         } else {
             if (a.fq_w) return -5;
             if (qg == 1) hipLaunchKernelGGL((attn_decode_cross_f16<false, 1>), gd, dim3(256), 0, s, a);

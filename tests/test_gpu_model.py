@@ -375,6 +375,49 @@ def test_decode_f16_fused_cross_query_is_bit_identical(name, beam, windows):
     assert np.array_equal(np.asarray(on["no_speech_prob"]), np.asarray(off["no_speech_prob"]))
 
 
+@pytest.mark.parametrize("name,beam,windows", [("tiny.en", False, 3), ("base.en", True, 3), ("base.en", True, 11), ("tiny.en", True, 1)])
+def test_decode_f16_cross_attention_two_blocks_in_flight_is_bit_identical(name, beam, windows):
+    # round 6: the fused decode-step cross-attention with TWO key blocks of a wave in flight and non-temporal K / V^T loads
+    # (attn_decode_cross_xq2_f16, the default) against the loop that requests and consumes one block per iteration (flag 33554432 =
+    # SWX_FLAG_XATTN_R5): the same blocks in the same order per wave, so tokens, lengths, sums of log-probabilities and the no-speech
+    # probability must be IDENTICAL.
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 78, B=windows)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=30,
+                                                     beam_size=5 if beam else None))
+    kw = dict(n_group=task.n_group, beam=beam, sample_len=30, sot_index=task.sot_index, min_tokens=30,
+              **_tok_cfg(task.tokenizer, task))
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    old = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(old & ~33554432)
+        a = eng.decode(xkv, [list(task.initial_tokens)] * windows, **kw)
+        lib.swx_debug_flags(old | 33554432)
+        b = eng.decode(xkv, [list(task.initial_tokens)] * windows, **kw)
+    finally:
+        lib.swx_debug_flags(old)
+    for key in ("lens", "tokens", "sum_logprobs", "no_speech_prob"):
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+    # the multi-token passes stream the same way (attn_decode_cross2_f16, 1 / 2 / 4 groups of 16 rows): a scoring pass over the windows
+    heads_list = [tuple(p) for p in m.alignment_heads.indices().T.tolist()]
+    eng.set_alignment_heads(heads_list)
+    tok = task.tokenizer
+    g = torch.Generator().manual_seed(windows)
+    toks = [[*tok.sot_sequence, tok.no_timestamps, *torch.randint(18, 50000, (40 + 7 * (w % 3),), generator=g).tolist(), tok.eot]
+            for w in range(windows)]
+    try:
+        lib.swx_debug_flags(old & ~33554432)
+        p1, n1, _ = eng.score(xkv, toks, [1500] * windows, n_sot=len(tok.sot_sequence), eot=tok.eot)
+        n1 = n1.clone()
+        lib.swx_debug_flags(old | 33554432)
+        p2, n2, _ = eng.score(xkv, toks, [1500] * windows, n_sot=len(tok.sot_sequence), eot=tok.eot)
+    finally:
+        lib.swx_debug_flags(old)
+    assert p1 == p2 and torch.equal(n1, n2)
+
+
 @pytest.mark.parametrize("name,mode", [("tiny.en", "greedy"), ("tiny.en", "beam"), ("base.en", "sample"), ("base.en", "beam_masks"),
                                        ("tiny.en", "greedy_free")])
 def test_decode_select_register_kernel_is_bit_identical(name, mode):
