@@ -260,7 +260,8 @@ int swx_prof_enable(int on);
  * (reference of the fragment-ordered copy), 8192 = memory-walking logit filters (reference of the register kernel),
  * 16384 = decode loop without the captured step graph, 32768 = decode step without the cache prefetch of the next projection's
  * weights, 65536 / 131072 = tiled GEMM never on the ring / the 256 x 256 kernel (bit-identical either way), 2097152 = the decode step's
- * K-split projection reduces its slabs inside the GEMM launch (arrival tickets; bit-identical, measured slower in round 5).  Default 0; nothing reads an environment variable.
+ * K-split projection reduces its slabs inside the GEMM launch (arrival tickets; bit-identical, measured slower in round 5),
+ * 67108864 = f16 flash attention on generation 2's tile instead of the software-pipelined one (bit-identical).  Default 0; nothing reads an environment variable.
  * flags < 0 only queries.  Returns the previous value. */
 int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);
@@ -294,6 +295,12 @@ int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k,
  * [R_phys][n_ctx][d] with the new token's K / V already at position pos0[r] of row r; d_anc [R][n_ctx] or NULL; d_o [R][d]. */
 int swx_test_self_attn_step(const void *d_q, void *d_kcache, void *d_vcache, const int32_t *d_anc, const int32_t *d_pos0,
                             int R, int H, int n_ctx, int d, int variant, void *d_o, void *stream);
+
+/* the VALU lane-exchange helpers of csrc/swx_common.h (v_permlane16/32_swap, DPP) against __shfl_xor, on n_waves waves of 64
+ * u32 values: d_out[((w * 13 + k) * 64) + lane], k = 0..5 lane_xor<32, 16, 8, 4, 2, 1>, k = 6..11 the __shfl_xor of the same
+ * offsets, k = 12 a bit mask of the derived forms that agreed with their shuffle form (1 wave_sum_d, 2 / 4 lane_xor16_max / 32_max,
+ * 8 / 16 lane_xor16_add / 32_add, 32 wave_max, 64 wave_sum: 127 = all).  Nothing in the reference corresponds to it. */
+int swx_test_lane_xor(const uint32_t *d_in, uint32_t *d_out, int n_waves, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 //   self_attn_cached    decoder self-attention over the KV cache; beams address the cache through an ancestor table
 //                       (position -> physical row) so that a beam reorder never copies K/V.
 //   qk_capture          raw scaled q.k of the alignment heads only (what timing.py:50-56 hooks out of every layer).
+#include <type_traits>
 #include "swx_common.h"
 #include "swx_kernels.h"
 
@@ -141,8 +142,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash2_f16(AttnArgs a)
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sc[tt][r]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = lane_xor16_max(tmax);                // (VALU row swaps, not ds_bpermute: swx_common.h)
+            tmax = lane_xor32_max(tmax);
             const float m_new = fmaxf(m_run[qb], tmax);                               // raw units
             const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * SC2);    // m_run = -inf on the first tile -> 0
             const float mc = m_new * SC2;
@@ -155,8 +156,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash2_f16(AttnArgs a)
                     sc[tt][r] = p;
                     psum += p;
                 }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
+            psum = lane_xor16_add(psum);
+            psum = lane_xor32_add(psum);
             l_run[qb] = l_run[qb] * alpha + psum;
             m_run[qb] = m_new;
 #pragma unroll
@@ -183,6 +184,189 @@ __global__ __launch_bounds__(256, 2) void attn_flash2_f16(AttnArgs a)
         if (t + 1 < ntile) store_tile(cur ^ 1);
         __syncthreads();
     }
+
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + qb * 16 + qn;
+        if (qi < a.nq) {
+            const float inv = 1.0f / l_run[qb];
+            f16 *op = (f16 *)a.o + ((size_t)b * a.q_rows_per_batch + qi) * a.ldo + h * DH;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f16x4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ov[r] = (f16)(o[qb][t][r] * inv);
+                *(f16x4 *)(op + t * 16 + g * 4) = ov;
+            }
+        }
+    }
+}
+
+// ================================================================================================ flash f16 (generation 3, round 6)
+// The arithmetic of attn_flash2_f16<true, QB> operation for operation (bit-identical: tests/test_gpu_kernels.py::
+// test_flash3_is_bit_identical_to_flash2), re-staged so that the matrix pipe and the VALU of ONE wave overlap.  Generation 2's key
+// tile is  for qb: { 8 QK^T MFMAs -> softmax of that block (~100 VALU + 17 v_exp on the MFMA results) }  then 32 PV MFMAs: hipcc
+// keeps that order, so every wave alternates between MFMA-only and VALU-only stretches (0.25 MFMA utilisation by counters at two
+// waves per SIMD).  Here the tile is ONE basic block (the key-range mask lives in a peeled instantiation for the last tile, the
+// next tile's loads / stores are unconditional) laid out as a software pipeline over the query blocks:
+//     QK(0) | softmax(0) + QK(1) | softmax(1) + QK(2) + PV(0) | softmax(2) + QK(3) + PV(1) | softmax(3) + PV(2) | PV(3)
+// with sched_group_barrier pipelines that put one MFMA in front of every few VALU instructions of a softmax.  Per accumulator the
+// MFMAs keep their order (QK^T: d-half 0 then 1; PV: key block 0 then 1, after that block's rescale).
+template <int QB>
+__global__ __launch_bounds__(256, 2) void attn_flash3_f16(AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f16 Ks[2][FL_KT][FL_LD];   // [buf][key][d]
+    __shared__ __attribute__((aligned(16))) f16 Vt[2][DH][FL_LD];      // [buf][d][key]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * (QB * 64) + wave * (QB * 16);
+    const int qn = lane & 15, g = lane >> 4;
+    const f16 *Q = (const f16 *)a.q;
+    const f16 *K = (const f16 *)a.k + (size_t)b * a.k_bs + h * DH;
+    const f16 *V = (const f16 *)a.v + (size_t)b * a.v_bs + (size_t)h * DH * a.vt_kp;
+
+    f16x8 qf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qi = q0 + qb * 16 + qn;
+        const f16 *qp = Q + ((size_t)b * a.q_rows_per_batch + (qi < a.nq ? qi : a.nq - 1)) * a.ldq + h * DH + g * 8;   // clamped
+        qf[qb][0] = *(const f16x8 *)(qp);
+        qf[qb][1] = *(const f16x8 *)(qp + 32);
+    }
+    f32x4 o[QB][4];
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        m_run[qb] = -__builtin_inff(); l_run[qb] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[qb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int ntile = (a.nk + FL_KT - 1) / FL_KT;
+    f16x8 rk[2], rv[2];
+    auto load_tile = [&](int kt0) {           // (past the last tile: the last tile again -- never predicated, never stored to a live buffer)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, c8 = (c & 7) * 8;
+            const int kg = kt0 + r;
+            const int kgc = kg < a.nk ? kg : a.nk - 1;
+            rk[i] = *(const f16x8 *)(K + (size_t)kgc * a.ldkv + c8);
+            if (kg >= a.nk) rk[i] = (f16x8)(f16)0;
+            rv[i] = *(const f16x8 *)(V + (size_t)r * a.vt_kp + kt0 + c8);               // zero padded past nk in the source
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 256 * i, r = c >> 3, c8 = (c & 7) * 8;
+            *(f16x8 *)&Ks[buf][r][c8] = rk[i];
+            *(f16x8 *)&Vt[buf][r][c8] = rv[i];
+        }
+    };
+    constexpr float SC2 = 0.125f * 1.4426950408889634f;
+
+    auto tile = [&](auto mask_tag, int cur, int kt0) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        f16x8 kf[4][2], va[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) kf[tt][kk] = *(const f16x8 *)&Ks[cur][tt * 16 + qn][kk * 32 + g * 8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f16x4 lo = *(const f16x4 *)&Vt[cur][tt * 16 + qn][32 * c + g * 4];
+                const f16x4 hi = *(const f16x4 *)&Vt[cur][tt * 16 + qn][32 * c + 16 + g * 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { va[c][tt][e] = lo[e]; va[c][tt][4 + e] = hi[e]; }
+            }
+        f32x4 sc[2][4];
+        f16x8 pb[2][2];
+        auto qk = [&](int qb, f32x4 (&s4)[4]) {
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                s4[tt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                s4[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tt][0], qf[qb][0], s4[tt], 0, 0, 0);
+                s4[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[tt][1], qf[qb][1], s4[tt], 0, 0, 0);
+            }
+        };
+        auto pv = [&](int qb, const f16x8 (&p2)[2]) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) o[qb][tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(va[c][tt], p2[c], o[qb][tt], 0, 0, 0);
+        };
+        auto softmax = [&](int qb, f32x4 (&s4)[4], f16x8 (&p2)[2]) {
+            if constexpr (MASK) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kt0 + tt * 16 + g * 4 + r >= a.nk) s4[tt][r] = -__builtin_inff();
+            }
+            float tmax = -__builtin_inff();
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, s4[tt][r]);
+            tmax = lane_xor16_max(tmax);
+            tmax = lane_xor32_max(tmax);
+            const float m_new = fmaxf(m_run[qb], tmax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * SC2);
+            const float mc = m_new * SC2;
+            float psum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s4[tt][r], SC2, -mc));
+                    s4[tt][r] = p;
+                    psum += p;
+                }
+            psum = lane_xor16_add(psum);
+            psum = lane_xor32_add(psum);
+            l_run[qb] = l_run[qb] * alpha + psum;
+            m_run[qb] = m_new;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) { o[qb][tt][0] *= alpha; o[qb][tt][1] *= alpha; o[qb][tt][2] *= alpha; o[qb][tt][3] *= alpha; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p2[c][r] = (f16)s4[2 * c][r]; p2[c][4 + r] = (f16)s4[2 * c + 1][r]; }
+        };
+        qk(0, sc[0]);
+        auto stage = [&](auto qb_tag) {
+            constexpr int qb = decltype(qb_tag)::value;
+            if constexpr (qb + 1 < QB) qk(qb + 1, sc[(qb + 1) & 1]);
+            if constexpr (qb >= 1) pv(qb - 1, pb[(qb - 1) & 1]);
+            softmax(qb, sc[qb & 1], pb[qb & 1]);
+            // one MFMA in front of every few VALU instructions of this stage's softmax (8 or 16 MFMAs per stage, ~115 VALU)
+            constexpr int NM = (qb + 1 < QB ? 8 : 0) + (qb >= 1 ? 8 : 0);
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, NM == 16 ? 7 : 14, 0);
+            }
+        };
+        stage(std::integral_constant<int, 0>{});
+        if constexpr (QB > 1) stage(std::integral_constant<int, 1>{});
+        if constexpr (QB > 2) stage(std::integral_constant<int, 2>{});
+        if constexpr (QB > 3) stage(std::integral_constant<int, 3>{});
+        static_assert(QB <= 4, "stages are listed by hand");
+        pv(QB - 1, pb[(QB - 1) & 1]);
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t + 1 < ntile; ++t) {
+        load_tile((t + 1) * FL_KT);
+        tile(std::false_type{}, t & 1, t * FL_KT);
+        store_tile((t & 1) ^ 1);
+        __syncthreads();
+    }
+    if (ntile * FL_KT > a.nk) tile(std::true_type{}, (ntile - 1) & 1, (ntile - 1) * FL_KT);
+    else tile(std::false_type{}, (ntile - 1) & 1, (ntile - 1) * FL_KT);
 
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -376,7 +560,10 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
                     s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
                 }
 #pragma unroll
-            for (int o2 = 1; o2 < 16; o2 <<= 1) { s1 += __shfl_xor(s1, o2, 64); s2 += __shfl_xor(s2, o2, 64); }
+            for (int o2 = 0; o2 < 1; ++o2) {     // 1, 2, 4, 8 in this order (DPP exchanges: swx_common.h)
+                s1 += lane_xor<1>(s1, lane); s2 += lane_xor<1>(s2, lane); s1 += lane_xor<2>(s1, lane); s2 += lane_xor<2>(s2, lane);
+                s1 += lane_xor<4>(s1, lane); s2 += lane_xor<4>(s2, lane); s1 += lane_xor<8>(s1, lane); s2 += lane_xor<8>(s2, lane);
+            }
             if (li == 0) {
                 const float inv = 1.0f / (float)kslice;
                 const float mean = s1 * inv;
@@ -429,8 +616,8 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
                     s[t][r] = v;
                     tmax = fmaxf(tmax, v);
                 }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = lane_xor16_max(tmax);                // (VALU row swaps, not ds_bpermute: swx_common.h)
+            tmax = lane_xor32_max(tmax);
             const float m_new = fmaxf(m_run[u], tmax);
             const float alpha = __expf(m_run[u] - m_new);
             float psum = 0.f;
@@ -443,8 +630,8 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
                     psum += p;
                     pb[4 * t + r] = (f16)p;
                 }
-            psum += __shfl_xor(psum, 16, 64);
-            psum += __shfl_xor(psum, 32, 64);
+            psum = lane_xor16_add(psum);
+            psum = lane_xor32_add(psum);
             l_run[u] = l_run[u] * alpha + psum;
             m_run[u] = m_new;
 #pragma unroll
@@ -650,8 +837,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f32(AttnArgs a)
                         tmax = fmaxf(tmax, v);
                     }
                 }
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                tmax = lane_xor16_max(tmax);                // (VALU row swaps, not ds_bpermute: swx_common.h)
+                tmax = lane_xor32_max(tmax);
                 const float m_new = fmaxf(m_run[qb], tmax);
                 const float m_use = m_new == -__builtin_inff() ? 0.f : m_new;      // a wave whose keys are all masked so far (SPLIT)
                 const float alpha = expf(m_run[qb] - m_use);                        // m_run = -inf -> 0
@@ -698,8 +885,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f32(AttnArgs a)
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
             float l = l_run[qb];
-            l += __shfl_xor(l, 16, 64);
-            l += __shfl_xor(l, 32, 64);
+            l = lane_xor16_add(l);
+            l = lane_xor32_add(l);
             const int qi = q0 + qb * 16 + qn;
             if (active && qi < a.nq) {
                 const float inv = 1.0f / l;
@@ -735,8 +922,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f32(AttnArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ov[r] += sm[(w * 18 + 2 + wave * 4 + r) * 64 + lane] * sc_w;
         }
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        l = lane_xor16_add(l);
+        l = lane_xor32_add(l);
         const int qi = q0 + qn;
         if (qi < a.nq) {
             const float inv = 1.0f / l;
@@ -910,9 +1097,9 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        acc[e] += __shfl_xor(acc[e], 8, 64);
-        acc[e] += __shfl_xor(acc[e], 16, 64);
-        acc[e] += __shfl_xor(acc[e], 32, 64);
+        acc[e] += lane_xor<8>(acc[e], lane);
+        acc[e] = lane_xor16_add(acc[e]);
+        acc[e] = lane_xor32_add(acc[e]);
     }
     if (kg == 0) {
         T *op = (T *)a.o + ((size_t)ri * a.n_new + i) * a.ldo + h * DH + dc;
@@ -1082,9 +1269,9 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        acc[e] += __shfl_xor(acc[e], 8, 64);
-        acc[e] += __shfl_xor(acc[e], 16, 64);
-        acc[e] += __shfl_xor(acc[e], 32, 64);
+        acc[e] += lane_xor<8>(acc[e], lane);
+        acc[e] = lane_xor16_add(acc[e]);
+        acc[e] = lane_xor32_add(acc[e]);
     }
     if (kg == 0) {
         f16 *op = (f16 *)a.o + (size_t)r * a.ldo + h * DH + dc;
@@ -1257,7 +1444,11 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         const bool wide_fills = (int64_t)a.B * a.H * cdiv(a.nq, 256) >= 256;
         const int qb = !a.vt_kp ? 2 : force_kernel == 4 ? 2 : force_kernel == 6 ? 3 : (force_kernel == 5 || (a.nq >= 1024 && wide_fills)) ? 4 : 2;
         dim3 g(cdiv(a.nq, 64 * qb), a.H, a.B);
+        const bool gen3 = a.vt_kp && !(swx_flags() & SWX_FLAG_FLASH_R5);     // round 6: the software-pipelined tile (bit-identical)
         if (!a.vt_kp) hipLaunchKernelGGL((attn_flash2_f16<false, 2>), g, dim3(256), 0, s, a);
+        else if (gen3 && qb == 4) hipLaunchKernelGGL((attn_flash3_f16<4>), g, dim3(256), 0, s, a);
+        else if (gen3 && qb == 3) hipLaunchKernelGGL((attn_flash3_f16<3>), g, dim3(256), 0, s, a);
+        else if (gen3) hipLaunchKernelGGL((attn_flash3_f16<2>), g, dim3(256), 0, s, a);
         else if (qb == 4) hipLaunchKernelGGL((attn_flash2_f16<true, 4>), g, dim3(256), 0, s, a);
         else if (qb == 3) hipLaunchKernelGGL((attn_flash2_f16<true, 3>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_flash2_f16<true, 2>), g, dim3(256), 0, s, a);

@@ -37,19 +37,101 @@ template <> __device__ __forceinline__ void load8<float>(const float *p, float (
     for (int e = 0; e < 4; ++e) { o[e] = a[e]; o[4 + e] = b[e]; }
 }
 
+// ---- cross-lane exchange on the VALU (no ds_bpermute) -------------------------------------------------------------------------
+// `__shfl_xor(x, o)` compiles to ds_bpermute_b32: an LDS-pipe round trip (~120 cycles) on whatever dependency chain it sits in --
+// four per 16-query block and key tile of the flash kernels' online softmax, six per wave reduction (22 block reductions in the
+// token-selection kernel), eight in a row of LayerNorm statistics.  lane_xor<O>(x) returns the SAME value (x of lane ^ O) from
+// VALU instructions: O = 32 / 16 by gfx950's v_permlane32_swap / v_permlane16_swap (with both operands = x the swap leaves x of
+// the lower half / even rows in one result and x of the upper half / odd rows in the other; a select by the lane's own half /
+// row parity picks the partner's), O = 8 by DPP row_ror:8, O = 4 by two bank-masked DPP row shifts, O = 2 / 1 by DPP quad_perm.
+// Callers keep their operand order (own op partner), so every reduction is bit-identical to its shuffle form by construction;
+// the helpers themselves are checked lane by lane against __shfl_xor on hardware (tests/test_gpu_kernels.py::
+// test_lane_xor_helpers_match_shuffles).
+__device__ __forceinline__ int swx_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <int O> __device__ __forceinline__ unsigned lane_xor_u32(unsigned x, int lane)
+{
+    static_assert(O == 1 || O == 2 || O == 4 || O == 8 || O == 16 || O == 32, "lane_xor: one butterfly step");
+#ifdef SWX_LANE_XOR_BPERMUTE      // A/B build only (stable_ts_amd/build.py::build_variant): the ds_bpermute form of rounds 1-5
+    return (unsigned)__shfl_xor((int)x, O, 64);
+#endif
+    if constexpr (O == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);      // r[0] = x of lanes 0..31, r[1] = x of lanes 32..63
+        return (lane & 32) ? r[0] : r[1];
+    } else if constexpr (O == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);      // r[0] = x of the even row, r[1] = of the odd row
+        return (lane & 16) ? r[0] : r[1];
+    } else if constexpr (O == 8) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xF, 0xF, false);           // row_ror:8
+    } else if constexpr (O == 4) {
+        int t = __builtin_amdgcn_update_dpp(0, (int)x, 0x104, 0xF, 0x5, false);                     // banks 0, 2 <- lane + 4 (row_shl:4)
+        t = __builtin_amdgcn_update_dpp(t, (int)x, 0x114, 0xF, 0xA, false);                         // banks 1, 3 <- lane - 4 (row_shr:4)
+        return (unsigned)t;
+    } else if constexpr (O == 2) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);            // quad_perm [2, 3, 0, 1]
+    } else {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);            // quad_perm [1, 0, 3, 2]
+    }
+}
+template <int O> __device__ __forceinline__ float lane_xor(float x, int lane) { return __uint_as_float(lane_xor_u32<O>(__float_as_uint(x), lane)); }
+template <int O> __device__ __forceinline__ int lane_xor(int x, int lane) { return (int)lane_xor_u32<O>((unsigned)x, lane); }
+template <int O> __device__ __forceinline__ double lane_xor(double x, int lane)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const unsigned lo = lane_xor_u32<O>((unsigned)u, lane), hi = lane_xor_u32<O>((unsigned)(u >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// the two cross-row steps of a COMMUTATIVE reduction without the select: v_max_f32 and the IEEE add commute bit for bit
+__device__ __forceinline__ float lane_xor16_max(float x) {
+#ifdef SWX_LANE_XOR_BPERMUTE
+    return fmaxf(x, __shfl_xor(x, 16, 64));
+#endif
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float lane_xor32_max(float x) {
+#ifdef SWX_LANE_XOR_BPERMUTE
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+#endif
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float lane_xor16_add(float x) {
+#ifdef SWX_LANE_XOR_BPERMUTE
+    return x + __shfl_xor(x, 16, 64);
+#endif
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float lane_xor32_add(float x) {
+#ifdef SWX_LANE_XOR_BPERMUTE
+    return x + __shfl_xor(x, 32, 64);
+#endif
+    const unsigned u = __float_as_uint(x);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// wave reductions, butterfly from 32 down to 1 (the order every caller's bit-identity claims were made with)
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const int lane = swx_lane_id();
+    v = fmaxf(v, lane_xor<32>(v, lane)); v = fmaxf(v, lane_xor<16>(v, lane)); v = fmaxf(v, lane_xor<8>(v, lane));
+    v = fmaxf(v, lane_xor<4>(v, lane)); v = fmaxf(v, lane_xor<2>(v, lane)); v = fmaxf(v, lane_xor<1>(v, lane));
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = swx_lane_id();
+    v += lane_xor<32>(v, lane); v += lane_xor<16>(v, lane); v += lane_xor<8>(v, lane);
+    v += lane_xor<4>(v, lane); v += lane_xor<2>(v, lane); v += lane_xor<1>(v, lane);
     return v;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int lane = swx_lane_id();
+    v += lane_xor<32>(v, lane); v += lane_xor<16>(v, lane); v += lane_xor<8>(v, lane);
+    v += lane_xor<4>(v, lane); v += lane_xor<2>(v, lane); v += lane_xor<1>(v, lane);
     return v;
 }
 

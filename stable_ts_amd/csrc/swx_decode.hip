@@ -29,14 +29,11 @@ __device__ __forceinline__ ArgMax argmax_combine(ArgMax a, ArgMax b)
 
 __device__ ArgMax block_argmax(ArgMax x, ArgMax *sh)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        ArgMax y;
-        y.v = __shfl_xor(x.v, o, 64);
-        y.i = __shfl_xor(x.i, o, 64);
-        x = argmax_combine(x, y);
-    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // butterfly 32 .. 1 with own-vs-partner operand order as before; the exchange runs on the VALU (swx_common.h: lane_xor)
+#define SWX_ARGMAX_STEP(O) { ArgMax y; y.v = lane_xor<O>(x.v, lane); y.i = lane_xor<O>(x.i, lane); x = argmax_combine(x, y); }
+    SWX_ARGMAX_STEP(32) SWX_ARGMAX_STEP(16) SWX_ARGMAX_STEP(8) SWX_ARGMAX_STEP(4) SWX_ARGMAX_STEP(2) SWX_ARGMAX_STEP(1)
+#undef SWX_ARGMAX_STEP
     __syncthreads();
     if (lane == 0) sh[wave] = x;
     __syncthreads();

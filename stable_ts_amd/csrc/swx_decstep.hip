@@ -168,7 +168,10 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
                     s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
                 }
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            for (int o = 0; o < 1; ++o) {        // 1, 2, 4, 8 in this order (DPP exchanges: swx_common.h)
+                s1 += lane_xor<1>(s1, lane); s2 += lane_xor<1>(s2, lane); s1 += lane_xor<2>(s1, lane); s2 += lane_xor<2>(s2, lane);
+                s1 += lane_xor<4>(s1, lane); s2 += lane_xor<4>(s2, lane); s1 += lane_xor<8>(s1, lane); s2 += lane_xor<8>(s2, lane);
+            }
             if (li == 0) {
                 const float inv = 1.0f / (float)kslice;
                 const float mean = s1 * inv;
@@ -429,7 +432,10 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
                     s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
                 }
 #pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            for (int o = 0; o < 1; ++o) {        // 1, 2, 4, 8 in this order (DPP exchanges: swx_common.h)
+                s1 += lane_xor<1>(s1, lane); s2 += lane_xor<1>(s2, lane); s1 += lane_xor<2>(s1, lane); s2 += lane_xor<2>(s2, lane);
+                s1 += lane_xor<4>(s1, lane); s2 += lane_xor<4>(s2, lane); s1 += lane_xor<8>(s1, lane); s2 += lane_xor<8>(s2, lane);
+            }
             if (li == 0) {
                 const float inv = 1.0f / (float)kslice;
                 const float mean = s1 * inv;

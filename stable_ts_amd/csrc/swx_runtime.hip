@@ -702,6 +702,37 @@ void swx_prof_end(hipStream_t s)
 }
 
 // ================================================================================================== C ABI
+// lane-exchange helpers vs __shfl_xor (swx_test_lane_xor)
+__global__ __launch_bounds__(64) void lane_xor_check_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x;
+    const uint32_t x = in[blockIdx.x * 64 + lane];
+    uint32_t *o = out + (size_t)blockIdx.x * 13 * 64 + lane;
+    o[0 * 64] = lane_xor_u32<32>(x, lane); o[1 * 64] = lane_xor_u32<16>(x, lane); o[2 * 64] = lane_xor_u32<8>(x, lane);
+    o[3 * 64] = lane_xor_u32<4>(x, lane);  o[4 * 64] = lane_xor_u32<2>(x, lane);  o[5 * 64] = lane_xor_u32<1>(x, lane);
+    o[6 * 64] = (uint32_t)__shfl_xor((int)x, 32, 64); o[7 * 64] = (uint32_t)__shfl_xor((int)x, 16, 64);
+    o[8 * 64] = (uint32_t)__shfl_xor((int)x, 8, 64);  o[9 * 64] = (uint32_t)__shfl_xor((int)x, 4, 64);
+    o[10 * 64] = (uint32_t)__shfl_xor((int)x, 2, 64); o[11 * 64] = (uint32_t)__shfl_xor((int)x, 1, 64);
+    double v = (double)__uint_as_float(x);
+    double ref = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ref += __shfl_xor(ref, off, 64);
+    const double got = wave_sum_d(v);
+    unsigned ok = (__double_as_longlong(got) == __double_as_longlong(ref)) ? 1u : 0u;
+    // the select-free forms for commutative operations, on finite values
+    const float f = (float)(int)(x >> 9) * 1.1920929e-7f - 0.37f;
+    ok |= (__float_as_uint(lane_xor16_max(f)) == __float_as_uint(fmaxf(f, __shfl_xor(f, 16, 64)))) ? 2u : 0u;
+    ok |= (__float_as_uint(lane_xor32_max(f)) == __float_as_uint(fmaxf(f, __shfl_xor(f, 32, 64)))) ? 4u : 0u;
+    ok |= (__float_as_uint(lane_xor16_add(f)) == __float_as_uint(f + __shfl_xor(f, 16, 64))) ? 8u : 0u;
+    ok |= (__float_as_uint(lane_xor32_add(f)) == __float_as_uint(f + __shfl_xor(f, 32, 64))) ? 16u : 0u;
+    float wm = f, ws = f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { wm = fmaxf(wm, __shfl_xor(wm, off, 64)); ws += __shfl_xor(ws, off, 64); }
+    ok |= (__float_as_uint(wave_max(f)) == __float_as_uint(wm)) ? 32u : 0u;
+    ok |= (__float_as_uint(wave_sum(f)) == __float_as_uint(ws)) ? 64u : 0u;
+    o[12 * 64] = ok;
+}
+
 extern "C" {
 
 int swx_debug_flags(int flags)
@@ -1580,6 +1611,14 @@ int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k,
     a.v_bs = vt_kp ? (int64_t)H * 64 * vt_kp : (int64_t)nk * ldkv;
     a.B = B; a.H = H; a.nq = nq; a.nk = nk; a.q_rows_per_batch = nq;
     return swx_attention(dtype, a, force_kernel, S(stream));
+}
+
+int swx_test_lane_xor(const uint32_t *d_in, uint32_t *d_out, int n_waves, void *stream)
+{
+    if (!d_in || !d_out || n_waves <= 0) return -1;
+    hipLaunchKernelGGL(lane_xor_check_kernel, dim3(n_waves), dim3(64), 0, S(stream), d_in, d_out);
+    SWX_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // extern "C"

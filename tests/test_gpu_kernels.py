@@ -319,6 +319,31 @@ def test_attention_kernels(B, H, nq, nk):
             assert err < 2e-5, (force, kp, err)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,nq,nk", [(2, 3, 1500, 1500), (1, 2, 64, 64), (1, 2, 300, 128), (1, 1, 17, 70), (2, 2, 1500, 1), (1, 4, 257, 1472),
+                                       (1, 2, 100, 1500)])
+def test_flash3_is_bit_identical_to_flash2(B, H, nq, nk):
+    """Round 6: the software-pipelined f16 flash tile (attn_flash3_f16: last tile peeled, MFMAs of the neighbouring query blocks
+    inside every softmax) against generation 2 (SWX_FLAG_FLASH_R5 = 67108864), 32 / 48 / 64 queries per wave, full and ragged
+    last key tiles: the same MFMA and softmax operations per accumulator, hence the same bits."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(B * 77 + nq + nk)
+    q = (torch.randn(B, nq, H * 64, generator=g) * 1.5).half().cuda()
+    k = torch.randn(B, nk, H * 64, generator=g).half().cuda()
+    v = torch.randn(B, nk, H * 64, generator=g).half().cuda()
+    kp = ((nk + 63) // 64) * 64 if nk > 1000 else 1536
+    old = lib.swx_debug_flags(-1)
+    try:
+        for force in (4, 6, 5, 2):
+            lib.swx_debug_flags(old | 67108864)
+            ref = _attn(1, q, k, v, force, kp).clone()
+            lib.swx_debug_flags(old & ~67108864)
+            got = _attn(1, q, k, v, force, kp)
+            assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (force, (ref.float() - got.float()).abs().max().item())
+    finally:
+        lib.swx_debug_flags(old)
+
+
 @pytest.mark.parametrize("B,H,nq,nk", [(1, 1, 1, 1500), (3, 4, 5, 1500), (2, 2, 16, 1500), (1, 3, 7, 333)])
 def test_attention_decode_cross_kernel(B, H, nq, nk):
     # the HBM-streaming decode-step kernel (<=16 queries, transposed V) vs f64 reference; fp16 P rounding: 6e-3
@@ -592,4 +617,24 @@ def test_cross_kv_from_one_launch_equals_two_launches(name, B):
         lib.swx_debug_flags(prev)
     torch.cuda.synchronize()
     assert one.numel() == two.numel() and torch.equal(one, two), int((one != two).sum())
-    assert float(one.view(torch.float16).float().abs().max()) > 0.1        # not a buffer of zeros
+    assert float(one.view(torch.float16).float().abs().max()) > 0.1        # not a buffer of zeros@pytest.mark.gpu
+def test_lane_xor_helpers_match_shuffles():
+    """csrc/swx_common.h: the wave reductions and the online-softmax row statistics exchange lanes on the VALU (gfx950's
+    v_permlane16/32_swap, DPP) instead of ds_bpermute; every helper must return what __shfl_xor returns, lane for lane."""
+    lib = _lib()
+    n_waves = 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randint(0, 2 ** 31 - 1, (n_waves * 64,), generator=g, dtype=torch.int64).to(torch.int32).cuda()
+    out = torch.zeros(n_waves * 13 * 64, dtype=torch.int32, device="cuda")
+    assert lib.swx_test_lane_xor(_p(x), _p(out), n_waves, _stream()) == 0
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().reshape(n_waves, 13, 64)
+    xs = x.cpu().numpy().reshape(n_waves, 64)
+    lanes = np.arange(64)
+    for k, off in enumerate((32, 16, 8, 4, 2, 1)):
+        np.testing.assert_array_equal(o[:, 6 + k], xs[:, lanes ^ off], err_msg=f"__shfl_xor {off}")
+        np.testing.assert_array_equal(o[:, k], o[:, 6 + k], err_msg=f"lane_xor<{off}>")
+    assert (o[:, 12] == 127).all(), np.unique(o[:, 12])
+
+
+
