@@ -261,7 +261,7 @@ int swx_prof_enable(int on);
  * 16384 = decode loop without the captured step graph, 32768 = decode step without the cache prefetch of the next projection's
  * weights, 65536 / 131072 = tiled GEMM never on the ring / the 256 x 256 kernel (bit-identical either way), 2097152 = the decode step's
  * K-split projection reduces its slabs inside the GEMM launch (arrival tickets; bit-identical, measured slower in round 5),
- * 67108864 = f16 flash attention on generation 2's tile instead of the software-pipelined one (bit-identical).  Default 0; nothing reads an environment variable.
+ * 67108864 = f16 flash attention on round 6's software-pipelined tile (bit-identical, measured slower).  Default 0; nothing reads an environment variable.
  * flags < 0 only queries.  Returns the previous value. */
 int swx_debug_flags(int flags);
 int swx_prof_collect(double *out, int n_classes);

@@ -46,10 +46,13 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--flash-kernel", type=int, default=2, help="force_kernel of the flash attention: 2 default dispatch, 4 / 6 / 5 = 32 / 48 / 64 queries per wave")
     ap.add_argument("--gemm-kernel", type=int, default=7, help="force_kernel of the tiled GEMM: 1 register-staged, 7 direct-to-LDS (occupancy-overlapped), 8 / 9 = its 64-column tiles always / never, 10 / 11 ring kernel at 64 / 128 columns, 0 = dispatch")
+    ap.add_argument("--flags", type=int, default=0, help="swx_debug_flags for the whole run (A/B switches, csrc/swx_kernels.h)")
     args = ap.parse_args()
     from stable_ts_amd import _lib
     lib = _lib.load()
     _lib.require_gpu()
+    if args.flags:
+        lib.swx_debug_flags(args.flags)
     dev = "cuda:0"
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None

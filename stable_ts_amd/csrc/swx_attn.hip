@@ -203,15 +203,19 @@ __global__ __launch_bounds__(256, 2) void attn_flash2_f16(AttnArgs a)
 }
 
 // ================================================================================================ flash f16 (generation 3, round 6)
+// MEASURED SLOWER, kept behind SWX_FLAG_FLASH_PIPELINED as the record of the experiment.
 // The arithmetic of attn_flash2_f16<true, QB> operation for operation (bit-identical: tests/test_gpu_kernels.py::
-// test_flash3_is_bit_identical_to_flash2), re-staged so that the matrix pipe and the VALU of ONE wave overlap.  Generation 2's key
-// tile is  for qb: { 8 QK^T MFMAs -> softmax of that block (~100 VALU + 17 v_exp on the MFMA results) }  then 32 PV MFMAs: hipcc
-// keeps that order, so every wave alternates between MFMA-only and VALU-only stretches (0.25 MFMA utilisation by counters at two
+// test_flash3_is_bit_identical_to_flash2), re-staged so that the matrix pipe and the VALU of ONE wave could overlap.  Generation 2's
+// key tile is  for qb: { 8 QK^T MFMAs -> softmax of that block (~100 VALU + 17 v_exp on the MFMA results) }  then 32 PV MFMAs, and
+// hipcc keeps that order: every wave alternates between MFMA-only and VALU-only stretches (0.25 MFMA utilisation by counters at two
 // waves per SIMD).  Here the tile is ONE basic block (the key-range mask lives in a peeled instantiation for the last tile, the
 // next tile's loads / stores are unconditional) laid out as a software pipeline over the query blocks:
 //     QK(0) | softmax(0) + QK(1) | softmax(1) + QK(2) + PV(0) | softmax(2) + QK(3) + PV(1) | softmax(3) + PV(2) | PV(3)
-// with sched_group_barrier pipelines that put one MFMA in front of every few VALU instructions of a softmax.  Per accumulator the
-// MFMAs keep their order (QK^T: d-half 0 then 1; PV: key block 0 then 1, after that block's rescale).
+// with sched_group_barrier pipelines that put one MFMA in front of every few VALU instructions of a softmax (seen in the ISA).
+// Result on hardware (profiles/r06_c14_flash3_ab.json): 391-406 us against 376-387 us per encoder layer at 20 windows, 42.9 against
+// 37.4 us at one window; headline pass 428.6 vs 427.5 ms, align() 916 vs 902 ms.  What MI355X_MICROARCH.md says of two waves per
+// SIMD holds: VALU placed beside a wave's own dependency-paced MFMAs delays them, and the second wave of the SIMD already fills
+// generation 2's MFMA-only and VALU-only stretches -- moving work between the two is zero- or negative-sum.
 template <int QB>
 __global__ __launch_bounds__(256, 2) void attn_flash3_f16(AttnArgs a)
 {
@@ -1444,7 +1448,7 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         const bool wide_fills = (int64_t)a.B * a.H * cdiv(a.nq, 256) >= 256;
         const int qb = !a.vt_kp ? 2 : force_kernel == 4 ? 2 : force_kernel == 6 ? 3 : (force_kernel == 5 || (a.nq >= 1024 && wide_fills)) ? 4 : 2;
         dim3 g(cdiv(a.nq, 64 * qb), a.H, a.B);
-        const bool gen3 = a.vt_kp && !(swx_flags() & SWX_FLAG_FLASH_R5);     // round 6: the software-pipelined tile (bit-identical)
+        const bool gen3 = a.vt_kp && (swx_flags() & SWX_FLAG_FLASH_PIPELINED);  // round 6's software-pipelined tile: bit-identical, slower (A/B only)
         if (!a.vt_kp) hipLaunchKernelGGL((attn_flash2_f16<false, 2>), g, dim3(256), 0, s, a);
         else if (gen3 && qb == 4) hipLaunchKernelGGL((attn_flash3_f16<4>), g, dim3(256), 0, s, a);
         else if (gen3 && qb == 3) hipLaunchKernelGGL((attn_flash3_f16<3>), g, dim3(256), 0, s, a);

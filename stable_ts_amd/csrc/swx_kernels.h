@@ -64,7 +64,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_XKV_TWO_LAUNCHES 8388608 // cross-K/V projection as two launches (K, then V) instead of one over the fused weight rows (A/B; bit-identical)
 #define SWX_FLAG_LOUDNESS_ONE_WG 16777216  // silence analysis probe: always the one-workgroup-per-window selection kernel (A/B; the same element)
 #define SWX_FLAG_XATTN_R5 33554432     // decode cross-attention: one key block per wave in flight, default load policy (rounds 2-5) instead of two + nt (A/B; bit-identical)
-#define SWX_FLAG_FLASH_R5 67108864      // f16 flash attention: generation 2 (rounds 3-5) instead of the software-pipelined tile of round 6 (A/B; bit-identical)
+#define SWX_FLAG_FLASH_PIPELINED 67108864 // f16 flash attention: the software-pipelined tile attn_flash3_f16 (round 6: bit-identical, measured 4 % SLOWER than generation 2 -- DESIGN.md section 7) instead of attn_flash2_f16
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

@@ -323,9 +323,10 @@ def test_attention_kernels(B, H, nq, nk):
 @pytest.mark.parametrize("B,H,nq,nk", [(2, 3, 1500, 1500), (1, 2, 64, 64), (1, 2, 300, 128), (1, 1, 17, 70), (2, 2, 1500, 1), (1, 4, 257, 1472),
                                        (1, 2, 100, 1500)])
 def test_flash3_is_bit_identical_to_flash2(B, H, nq, nk):
-    """Round 6: the software-pipelined f16 flash tile (attn_flash3_f16: last tile peeled, MFMAs of the neighbouring query blocks
-    inside every softmax) against generation 2 (SWX_FLAG_FLASH_R5 = 67108864), 32 / 48 / 64 queries per wave, full and ragged
-    last key tiles: the same MFMA and softmax operations per accumulator, hence the same bits."""
+    """Round 6: the software-pipelined f16 flash tile (attn_flash3_f16, SWX_FLAG_FLASH_PIPELINED = 67108864: last tile peeled,
+    MFMAs of the neighbouring query blocks inside every softmax; measured slower and off by default) against generation 2,
+    32 / 48 / 64 queries per wave, full and ragged last key tiles: the same MFMA and softmax operations per accumulator, hence
+    the same bits."""
     lib = _lib()
     g = torch.Generator().manual_seed(B * 77 + nq + nk)
     q = (torch.randn(B, nq, H * 64, generator=g) * 1.5).half().cuda()
@@ -335,9 +336,9 @@ def test_flash3_is_bit_identical_to_flash2(B, H, nq, nk):
     old = lib.swx_debug_flags(-1)
     try:
         for force in (4, 6, 5, 2):
-            lib.swx_debug_flags(old | 67108864)
-            ref = _attn(1, q, k, v, force, kp).clone()
             lib.swx_debug_flags(old & ~67108864)
+            ref = _attn(1, q, k, v, force, kp).clone()
+            lib.swx_debug_flags(old | 67108864)
             got = _attn(1, q, k, v, force, kp)
             assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (force, (ref.float() - got.float()).abs().max().item())
     finally:
