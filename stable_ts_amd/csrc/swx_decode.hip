@@ -527,34 +527,33 @@ __global__ __launch_bounds__(256) void decode_beam_update_kernel(DecodeBufs b, i
         } else {
             for (int i = tid; i < b.TS; i += 256) dt[i] = (i < len) ? st[i] : (i == len ? sel_tok[s] : c.eot);
             for (int p = tid; p < b.n_ctx; p += 256) da[p] = (p < len) ? sa[p] : dst;
-            if (tid == 0) { b.sum_lp_next[dst] = sel_sc[s]; b.pos0[dst] = len; }
+            // (sum_logprobs written in place: every read of this window's rows sits in front of the barriers above and no other
+            //  workgroup touches them -- the separate commit launch of rounds 1-5 cost 4.7 us per step)
+            if (tid == 0) { b.sum_lp[dst] = sel_sc[s]; b.pos0[dst] = len; }
         }
     }
-}
-
-__global__ void decode_beam_commit_kernel(DecodeBufs b)
-{
-    // sum_logprobs of the new beams (kept separate so that the update above reads a consistent snapshot)
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < b.M && !b.win_done_prev[r / b.G]) b.sum_lp[r] = b.sum_lp_next[r];
 }
 
 // per-window completion (greedy: every row ended with EOT) and the global "all done" counter
-__global__ void decode_step_finish_kernel(DecodeBufs b)
+__global__ __launch_bounds__(64) void decode_step_finish_kernel(DecodeBufs b)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave, a window per lane (one lane had walked the windows one dependent load after the other: 6 us per step at 20 windows)
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     int nd = 0;
-    for (int w = 0; w < b.W; ++w) {
-        if (!b.cfg.beam && !b.win_done[w]) {
+    for (int w = lane; w < b.W; w += 64) {
+        int done = b.win_done[w];
+        if (!b.cfg.beam && !done) {
             int all = 1;
             for (int g = 0; g < b.G; ++g) all &= b.row_done[w * b.G + g];
-            if (all) b.win_done[w] = 1;
+            if (all) { b.win_done[w] = 1; done = 1; }
         }
-        b.win_done_prev[w] = b.win_done[w];
-        nd += b.win_done[w] ? 1 : 0;
+        b.win_done_prev[w] = done;
+        nd += done ? 1 : 0;
     }
-    *b.n_done = nd;
-    *b.step_dev += 1;
+    nd += lane_xor<32>(nd, lane); nd += lane_xor<16>(nd, lane); nd += lane_xor<8>(nd, lane);
+    nd += lane_xor<4>(nd, lane); nd += lane_xor<2>(nd, lane); nd += lane_xor<1>(nd, lane);
+    if (lane == 0) { *b.n_done = nd; *b.step_dev += 1; }
 }
 
 // ------------------------------------------------------------------------------------------------ finalize
@@ -651,7 +650,6 @@ int swx_decode_select(const DecodeBufs &b, int cur, hipStream_t s)
         hipLaunchKernelGGL(decode_select_kernel, dim3(b.M), dim3(SEL_T), 0, s, b, cur);
     if (b.cfg.beam) {
         hipLaunchKernelGGL(decode_beam_update_kernel, dim3(b.W), dim3(256), 0, s, b, cur);
-        hipLaunchKernelGGL(decode_beam_commit_kernel, dim3(cdiv(b.M, 256)), dim3(256), 0, s, b);
     }
     hipLaunchKernelGGL(decode_step_finish_kernel, dim3(1), dim3(64), 0, s, b);
     SWX_CHECK_LAUNCH();
