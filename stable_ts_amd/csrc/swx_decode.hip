@@ -27,19 +27,34 @@ __device__ __forceinline__ ArgMax argmax_combine(ArgMax a, ArgMax b)
     return a;
 }
 
+// Block reductions of the 1 024-thread selection kernels (16 waves): a wave butterfly, one LDS slot per wave, then the 16 wave
+// results.  Rounds 1-5 had EVERY thread walk the 16 slots one after the other (16 LDS reads + 16 combines, 11 times per row:
+// a third of the kernel's instructions in beam mode); now lanes take one slot each (slot = lane % 16) and run a 4-step butterfly
+// inside their row of 16 lanes (DPP).  Bit-identical: max is exact and order-free (-inf start values, NaN inputs are dropped by
+// v_max_f32 whichever side they are on); the arg-max order (value descending, index ascending) is total on the values it sees
+// (the filters have replaced NaN), so every combination tree has the same winner; the SUM keeps its order -- slots 0 .. 15 added
+// one after the other into 0 -- and only reads them as four 16-byte LDS loads.  -DSWX_SELECT_R5_REDUCE (A/B build) = the old walk.
+static_assert(SEL_T == 1024, "block reductions: 16 wave slots");
+
 __device__ ArgMax block_argmax(ArgMax x, ArgMax *sh)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // butterfly 32 .. 1 with own-vs-partner operand order as before; the exchange runs on the VALU (swx_common.h: lane_xor)
 #define SWX_ARGMAX_STEP(O) { ArgMax y; y.v = lane_xor<O>(x.v, lane); y.i = lane_xor<O>(x.i, lane); x = argmax_combine(x, y); }
     SWX_ARGMAX_STEP(32) SWX_ARGMAX_STEP(16) SWX_ARGMAX_STEP(8) SWX_ARGMAX_STEP(4) SWX_ARGMAX_STEP(2) SWX_ARGMAX_STEP(1)
-#undef SWX_ARGMAX_STEP
     __syncthreads();
     if (lane == 0) sh[wave] = x;
     __syncthreads();
+#ifdef SWX_SELECT_R5_REDUCE
     ArgMax r = sh[0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = argmax_combine(r, sh[w]);
     return r;
+#else
+    x = sh[lane & 15];
+    SWX_ARGMAX_STEP(8) SWX_ARGMAX_STEP(4) SWX_ARGMAX_STEP(2) SWX_ARGMAX_STEP(1)
+    return x;
+#endif
+#undef SWX_ARGMAX_STEP
 }
 
 __device__ float block_max(float x, float *sh)
@@ -49,9 +64,15 @@ __device__ float block_max(float x, float *sh)
     __syncthreads();
     if (lane == 0) sh[wave] = x;
     __syncthreads();
+#ifdef SWX_SELECT_R5_REDUCE
     float r = sh[0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sh[w]);
     return r;
+#else
+    float r = sh[lane & 15];
+    r = fmaxf(r, lane_xor<8>(r, lane)); r = fmaxf(r, lane_xor<4>(r, lane)); r = fmaxf(r, lane_xor<2>(r, lane)); r = fmaxf(r, lane_xor<1>(r, lane));
+    return r;
+#endif
 }
 
 __device__ float block_sum(float x, float *sh)
@@ -62,7 +83,13 @@ __device__ float block_sum(float x, float *sh)
     if (lane == 0) sh[wave] = x;
     __syncthreads();
     float r = 0.f;
+#ifdef SWX_SELECT_R5_REDUCE
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
+#else
+    const f32x4 *s4 = (const f32x4 *)sh;         // (16-byte aligned by its declarations)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const f32x4 v = s4[q]; r += v[0]; r += v[1]; r += v[2]; r += v[3]; }
+#endif
     return r;
 }
 
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(SEL_T) void decode_prefill_logits_kernel(DecodeBufs
                                                                       float *__restrict__ nospeech)
 {
     // lg2: [W][2][V] (row 0: position sot_index, row 1: last initial position); grid (M)
-    __shared__ float sh[SEL_T / 64];
+    __shared__ __attribute__((aligned(16))) float sh[SEL_T / 64];
     const int r = blockIdx.x, w = r / b.G, V = b.V;
     const float *last = lg2 + ((size_t)w * 2 + 1) * V;
     float *dst = b.logits + (size_t)r * V;
@@ -144,8 +171,8 @@ __global__ __launch_bounds__(SEL_T) void decode_prefill_logits_kernel(DecodeBufs
 __global__ __launch_bounds__(SEL_T) void decode_select_kernel(DecodeBufs b, int cur)
 {
     const int step = *b.step_dev;
-    __shared__ float shf[SEL_T / 64];
-    __shared__ ArgMax sha[SEL_T / 64];
+    __shared__ __attribute__((aligned(16))) float shf[SEL_T / 64];
+    __shared__ __attribute__((aligned(16))) ArgMax sha[SEL_T / 64];
     __shared__ int sh_last_ts;
     const int r = blockIdx.x, w = r / b.G, V = b.V, tid = threadIdx.x;
     const swx_decode_cfg &c = b.cfg;
@@ -278,8 +305,8 @@ template <int NV>
 __global__ __launch_bounds__(SEL_T) void decode_select_reg_kernel(DecodeBufs b, int cur)
 {
     const int step = *b.step_dev;
-    __shared__ float shf[SEL_T / 64];
-    __shared__ ArgMax sha[SEL_T / 64];
+    __shared__ __attribute__((aligned(16))) float shf[SEL_T / 64];
+    __shared__ __attribute__((aligned(16))) ArgMax sha[SEL_T / 64];
     __shared__ float sh_rot[SEL_T];
     __shared__ int sh_last_ts;
     __shared__ float sh_raw;
