@@ -182,6 +182,34 @@ def main():
             print(f"  {name:26s} N={N:5d} K={K:5d}: {us:7.2f} us  {2.0 * (N * K + M * K + M * N) / us / 1e3:7.1f} GB/s algorithmic")
         print(f"  sum of the six projections of one layer: {tot:.1f} us")
 
+    if args.only in ("logits",):
+        # the vocabulary projection of a decode step (133 MB of weights, no bias, f32 out): the tiled kernel it runs on today against
+        # the weight-streaming dec kernel at the nearest shape that kernel accepts (N = 810 x 64, residual epilogue) -- a price check
+        print("-- decode-step logits projection: tiled GEMM (today) vs the dec kernel at N = 51840")
+        K = 1280
+        for M in (100, 5):
+            N = 51866
+            a, ws = rnd(M, K), weight_copies(rnd, N, K, total_mb=700)
+            c = torch.empty(M, N, dtype=torch.float32, device=dev)
+            fn = lambda i: lib.swx_test_gemm(1, p(a), K, p(ws[i % len(ws)]), None, None, p(c), N, M, N, K, 8, 0, st)
+            assert fn(0) == 0
+            us = timed(fn, args.iters)
+            print(f"  tiled   M={M:4d} N={N}: {us:7.2f} us  {2.0 * N * K / us / 1e3:7.1f} GB/s of weights")
+            N = 51840
+            ws = weight_copies(rnd, N, K, total_mb=700)
+            x = rnd(M, N); c16 = torch.empty(M, N, dtype=torch.half, device=dev)
+            c1, c2 = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+            kc = torch.zeros(1, 448, 1280, dtype=torch.half, device=dev); pos0 = torch.full((M,), 17, dtype=torch.int32, device=dev)
+            scratch = torch.empty(N * K * 2 + 8 * N + (1 << 20), dtype=torch.uint8, device=dev)
+            fn2 = lambda i: lib.swx_test_dec_gemm(p(a), K, p(ws[i % len(ws)]), p(c1), p(c2), p(c2), p(c16), N, p(x), p(kc), p(kc), p(pos0), 448, 1280,
+                                                  M, N, K, 4 | 32, p(scratch), scratch.numel(), st)
+            rc = fn2(0)
+            if rc != 0:
+                print(f"  dec     M={M:4d} N={N}: rc {rc}")
+                continue
+            us = timed(fn2, args.iters)
+            print(f"  dec     M={M:4d} N={N}: {us:7.2f} us  {2.0 * N * K / us / 1e3:7.1f} GB/s of weights")
+
     if args.only in ("", "dtw"):
         print("-- DTW + backtrace (one workgroup per window)")
         from stable_ts_amd.engine import dtw as _dtw  # noqa: F401

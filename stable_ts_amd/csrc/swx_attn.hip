@@ -1120,13 +1120,19 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
 // shuffles).  Arithmetic order is self_attn_cached's, so both paths agree bit for bit.
 // HBM traffic: K and V of every cached position of every row once = R * (pos + 1) * d * 2 * 2 bytes per launch (57 MB at
 // position 111 for 100 rows of large-v3: at the end of a window's decode this kernel is bandwidth-, not latency-bound).
-template <bool LONG>
-__global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
+// WPB (round 6 experiment, SWX_FLAG_SELFATTN_WG5): waves per workgroup -- WPB consecutive rows of one head (the beams of a window)
+// share a workgroup, i.e. a CU's L1 and one workgroup dispatch; every wave still does exactly its row's arithmetic.
+template <bool LONG, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void self_attn_step_f16(SelfAttnArgs a)
 {
     constexpr int PF = 16;                   // prefetched V fragments per lane (keys kg + 8 i, i < PF  <=>  j < 128)
-    __shared__ float qs[DH];
-    __shared__ float ps[512];
-    const int lane = threadIdx.x, h = blockIdx.x, r = blockIdx.y;
+    __shared__ float qs_all[WPB][DH];
+    __shared__ float ps_all[WPB][512];
+    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6, h = blockIdx.x;
+    const int r_raw = blockIdx.y * WPB + wave_in_wg;
+    const bool r_live = r_raw < a.R;
+    const int r = r_live ? r_raw : a.R - 1;  // a wave past the last row repeats it (every wave reaches the barriers) and does not store
+    float *qs = qs_all[wave_in_wg], *ps = ps_all[wave_in_wg];
     const int d = a.d;
     const int pos = a.pos0[r];
     const int32_t *anc = a.anc ? a.anc + (size_t)r * a.n_ctx : nullptr;
@@ -1277,7 +1283,7 @@ __global__ __launch_bounds__(64) void self_attn_step_f16(SelfAttnArgs a)
         acc[e] = lane_xor16_add(acc[e]);
         acc[e] = lane_xor32_add(acc[e]);
     }
-    if (kg == 0) {
+    if (kg == 0 && r_live) {
         f16 *op = (f16 *)a.o + (size_t)r * a.ldo + h * DH + dc;
 #pragma unroll
         for (int e = 0; e < 8; ++e) op[e] = (f16)acc[e];
@@ -1534,8 +1540,14 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
         if (dtype != SWX_F16 || a.n_new != 1 || row_mul != 1 || !a.skip_append) return -5;
         // (a decode whose positions stay below 128 -- no prompt carried over -- takes the variant without the long-context code:
         // 157 instead of 211 registers, three waves per SIMD)
-        if (a.pos_bound > 0 && a.pos_bound <= 128) hipLaunchKernelGGL(self_attn_step_f16<false>, dim3(a.H, a.R), dim3(64), 0, s, a);
-        else hipLaunchKernelGGL(self_attn_step_f16<true>, dim3(a.H, a.R), dim3(64), 0, s, a);
+        const bool wg5 = (swx_flags() & SWX_FLAG_SELFATTN_WG5) != 0;       // A/B: five rows (a window's beams) per workgroup
+        if (a.pos_bound > 0 && a.pos_bound <= 128) {
+            if (wg5) hipLaunchKernelGGL((self_attn_step_f16<false, 5>), dim3(a.H, cdiv(a.R, 5)), dim3(320), 0, s, a);
+            else hipLaunchKernelGGL((self_attn_step_f16<false, 1>), dim3(a.H, a.R), dim3(64), 0, s, a);
+        } else {
+            if (wg5) hipLaunchKernelGGL((self_attn_step_f16<true, 5>), dim3(a.H, cdiv(a.R, 5)), dim3(320), 0, s, a);
+            else hipLaunchKernelGGL((self_attn_step_f16<true, 1>), dim3(a.H, a.R), dim3(64), 0, s, a);
+        }
         SWX_CHECK_LAUNCH();
         return 0;
     }

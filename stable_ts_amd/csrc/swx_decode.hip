@@ -64,13 +64,17 @@ __device__ float block_max(float x, float *sh)
     __syncthreads();
     if (lane == 0) sh[wave] = x;
     __syncthreads();
-#ifdef SWX_SELECT_R5_REDUCE
+#if defined(SWX_SELECT_R5_REDUCE) || defined(SWX_SELECT_MAX_WALK)
     float r = sh[0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sh[w]);
     return r;
 #else
-    float r = sh[lane & 15];
-    r = fmaxf(r, lane_xor<8>(r, lane)); r = fmaxf(r, lane_xor<4>(r, lane)); r = fmaxf(r, lane_xor<2>(r, lane)); r = fmaxf(r, lane_xor<1>(r, lane));
+    // (four 16-byte LDS reads, one at a time: the lane butterfly of block_argmax costs this kernel's callers -- two maxima live
+    //  at once at the 128-register cap -- a spilled register)
+    const f32x4 *s4 = (const f32x4 *)sh;
+    float r = -__builtin_inff();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const f32x4 v = s4[q]; r = fmaxf(r, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))); }
     return r;
 #endif
 }
@@ -83,7 +87,7 @@ __device__ float block_sum(float x, float *sh)
     if (lane == 0) sh[wave] = x;
     __syncthreads();
     float r = 0.f;
-#ifdef SWX_SELECT_R5_REDUCE
+#if defined(SWX_SELECT_R5_REDUCE) || defined(SWX_SELECT_SUM_WALK)
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r += sh[w];
 #else
     const f32x4 *s4 = (const f32x4 *)sh;         // (16-byte aligned by its declarations)

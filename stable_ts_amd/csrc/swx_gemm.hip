@@ -98,6 +98,10 @@ __device__ __forceinline__ void tile_epilogue_f16_one(const GemmArgs &g, unsigne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (f16)(Cv[rg * 4 + r][col] + b);
                     *(f16x4 *)(cbase + (size_t)gn * g.vt_kp) = o;
+                    if (g.vt_zero_pad && sidx + 4 == g.vt_s) {          // the row group that ends a batch item: its columns' key padding
+                        const f16x4 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                        for (int zp = 4; sidx + zp < g.vt_kp; zp += 4) *(f16x4 *)(cbase + (size_t)gn * g.vt_kp + zp) = z;
+                    }
                 }
             }
             if (half == 0) __syncthreads();
@@ -191,6 +195,16 @@ template <int NJ>
 __device__ __forceinline__ void tile_epilogue_f16(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][NJ], int m0, int n0,
                                                      int tid, int lane, int wm, int wn)
 {
+    if (g.epi & EPI_QKV_VT) {
+        // the encoder's fused Q | K | V projection: V (the last third of the columns; the third is a multiple of the tile width)
+        // leaves transposed per head -- what swx_transpose_v did in a launch of its own; per element the plain epilogue's value
+        GemmArgs h = g;
+        const int split = (g.N / 3) * 2;
+        h.epi = g.epi & ~EPI_QKV_VT;
+        if (n0 >= split) { h.epi |= EPI_STORE_VT; h.C = (f16 *)g.C2 - (size_t)split * g.vt_kp; h.bias = g.bias; }
+        tile_epilogue_f16_one<NJ>(h, smem, acc, m0, n0, tid, lane, wm, wn);
+        return;
+    }
     if (!(g.epi & EPI_KV)) { tile_epilogue_f16_one<NJ>(g, smem, acc, m0, n0, tid, lane, wm, wn); return; }
     GemmArgs h = g;
     const int half = g.N >> 1;

@@ -15,6 +15,10 @@
                             // [2d][d]): columns [0, N/2) are stored like EPI_CBATCH into C, columns [N/2, N) like EPI_STORE_VT into C2
                             // (column index relative to N/2); N/2 is a multiple of the tile width, so a tile is one or the other
 
+#define EPI_QKV_VT 256      // f16 tiled kernels only (round 6): the encoder's fused Q|K|V projection with V stored TRANSPOSED per head for the
+                            // flash kernel -- columns [0, 2N/3) plain into C, columns [2N/3, N) like EPI_STORE_VT into C2 (column index relative
+                            // to 2N/3; vt_zero_pad: the key padding [vt_s, vt_kp) of every column is zeroed by the tile that ends a batch item)
+
 struct GemmArgs {
     const void *A; int64_t lda;     // [M][K] compute dtype
     const void *W; int64_t ldw;     // [N][K] compute dtype
@@ -26,6 +30,7 @@ struct GemmArgs {
     int M, N, K;
     int epi;
     int vt_s, vt_kp; int64_t vt_bs;   // EPI_STORE_VT: rows per batch item, padded key stride, element stride between batch items
+    int vt_zero_pad;                  // EPI_STORE_VT fast path: also write zeros to keys [vt_s, vt_kp) of the columns it stores
     int tile_order;                   // gemm_f16_big8 only, set by swx_gemm: 0 = row-major, 1 = an XCD's concurrent tiles share a band of
                                       // weights that fits its L2 (groups of 4 column tiles, walked along M; SWX_FLAG_BIG8_GROUPED)
 };
@@ -65,6 +70,8 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_LOUDNESS_ONE_WG 16777216  // silence analysis probe: always the one-workgroup-per-window selection kernel (A/B; the same element)
 #define SWX_FLAG_XATTN_R5 33554432     // decode cross-attention: one key block per wave in flight, default load policy (rounds 2-5) instead of two + nt (A/B; bit-identical)
 #define SWX_FLAG_FLASH_PIPELINED 67108864 // f16 flash attention: the software-pipelined tile attn_flash3_f16 (round 6: bit-identical, measured 4 % SLOWER than generation 2 -- DESIGN.md section 7) instead of attn_flash2_f16
+#define SWX_FLAG_SELFATTN_WG5 134217728  // decode-step self-attention: five rows (the beams of a window) per workgroup instead of one wave per workgroup (A/B; the same arithmetic per row)
+#define SWX_FLAG_QKV_SEPARATE_VT 268435456 // encoder at few windows: V transposed by its own launch instead of by the QKV projection's epilogue (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

@@ -1037,7 +1037,16 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
     for (int l = 0; l < D.n_audio_layer; ++l) {
         const LayerW &w = m->enc[l];
         SWX_TRY(swx_layernorm(m->dtype, x, d, m->A<float>(w.ln1_g), m->A<float>(w.ln1_b), h, d, rows, d, s));
-        SWX_TRY(swx_gemm(m->dtype, gemm_args(h, d, m->arena + w.wqkv, d, m->A<float>(w.bqkv), qkv, 3 * d, rows, 3 * d, d, EPI_BIAS), 0, s));
+        // f16 at few windows (wherever the launch does not go to the 256 x 256 kernel, whose epilogue is plain): V leaves the
+        // projection's epilogue transposed per head (EPI_QKV_VT, round 6) instead of by a launch of its own -- 5 us x 32 layers per
+        // window pass of align(); the `u` buffer (MLP hidden, 4d wide) is free until the MLP of this layer
+        const bool fuse_vt = m->dtype == SWX_F16 && d % 128 == 0 && S_ % 4 == 0 && !(g_debug_flags & SWX_FLAG_QKV_SEPARATE_VT) &&
+                             swx_gemm_plan_f16(rows, 3 * d, d, EPI_BIAS, 3 * d, 1, true, 0, g_debug_flags) != SWX_GEMM_BIG;
+        {
+            GemmArgs gq = gemm_args(h, d, m->arena + w.wqkv, d, m->A<float>(w.bqkv), qkv, 3 * d, rows, 3 * d, d, EPI_BIAS | (fuse_vt ? EPI_QKV_VT : 0));
+            if (fuse_vt) { gq.C2 = u; gq.vt_s = S_; gq.vt_kp = SWX_VT_KP; gq.vt_bs = (int64_t)H * 64 * SWX_VT_KP; gq.vt_zero_pad = 1; }
+            SWX_TRY(swx_gemm(m->dtype, gq, 0, s));
+        }
         AttnArgs a{};
         a.q = qkv; a.ldq = 3 * d; a.k = qkv + (size_t)d * e; a.v = qkv + (size_t)2 * d * e; a.ldkv = 3 * d; a.o = att; a.ldo = d;
         a.k_bs = (int64_t)S_ * 3 * d; a.v_bs = a.k_bs; a.vt_kp = 0;
@@ -1045,7 +1054,7 @@ int swx_encode(swx_model *m, const float *d_mel, int B, void *d_xa, void *stream
         if (m->dtype == SWX_F16) {
             // V of this layer transposed per head (one streaming pass, ~35 us for 20 windows): the flash kernel then stages both
             // operands with 16-byte vector stores; the `u` buffer (MLP hidden, 4d wide) is free until the MLP of this layer
-            SWX_TRY(swx_transpose_v(a.v, 3 * d, a.v_bs, S_, u, SWX_VT_KP, (int64_t)H * 64 * SWX_VT_KP, B, H, s));
+            if (!fuse_vt) SWX_TRY(swx_transpose_v(a.v, 3 * d, a.v_bs, S_, u, SWX_VT_KP, (int64_t)H * 64 * SWX_VT_KP, B, H, s));
             a.v = u; a.vt_kp = SWX_VT_KP; a.v_bs = (int64_t)H * 64 * SWX_VT_KP;
         }
         SWX_TRY(swx_attention(m->dtype, a, 0, s));

@@ -418,6 +418,53 @@ def test_decode_f16_cross_attention_two_blocks_in_flight_is_bit_identical(name, 
     assert p1 == p2 and torch.equal(n1, n2)
 
 
+@pytest.mark.parametrize("name,windows", [("tiny.en", 1), ("base.en", 2), ("base.en", 5)])
+def test_encoder_f16_v_transposed_by_the_qkv_epilogue_is_bit_identical(name, windows):
+    # round 6: at few windows the encoder's Q | K | V projection stores V transposed per head from its own epilogue (EPI_QKV_VT, incl.
+    # the zeroed key padding) instead of through swx_transpose_v (flag 268435456 = SWX_FLAG_QKV_SEPARATE_VT): the same f16 values in
+    # the same places, so the encoder output must be IDENTICAL -- twice in a row (the V^T buffer is the MLP's hidden buffer and holds
+    # the previous layer's activations when the epilogue writes it)
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 91, B=windows).cuda().contiguous()
+    old = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(old | 268435456)
+        ref = eng.encode(mels).clone()
+        lib.swx_debug_flags(old & ~268435456)
+        got1 = eng.encode(mels).clone()
+        got2 = eng.encode(mels).clone()
+    finally:
+        lib.swx_debug_flags(old)
+    assert torch.equal(ref.view(torch.int16), got1.view(torch.int16)) and torch.equal(ref.view(torch.int16), got2.view(torch.int16))
+
+
+@pytest.mark.parametrize("name,beam,windows", [("tiny.en", True, 3), ("base.en", True, 4), ("base.en", False, 7)])
+def test_decode_f16_self_attention_five_rows_per_workgroup_is_bit_identical(name, beam, windows):
+    # round 6 experiment (flag 134217728 = SWX_FLAG_SELFATTN_WG5): the decode-step self-attention with five rows (a window's beams)
+    # per workgroup instead of one wave per workgroup -- per row the same instructions, incl. a row count that is no multiple of five
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 78, B=windows)
+    task = ost.DecodingTaskStable(m, DecodingOptions(fp16=False, language="en", max_initial_timestamp=None, sample_len=30,
+                                                     beam_size=5 if beam else None))
+    kw = dict(n_group=task.n_group, beam=beam, sample_len=30, sot_index=task.sot_index, min_tokens=30,
+              **_tok_cfg(task.tokenizer, task))
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    old = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(old & ~134217728)
+        a = eng.decode(xkv, [list(task.initial_tokens)] * windows, **kw)
+        lib.swx_debug_flags(old | 134217728)
+        b = eng.decode(xkv, [list(task.initial_tokens)] * windows, **kw)
+    finally:
+        lib.swx_debug_flags(old)
+    for key in ("lens", "tokens", "sum_logprobs", "no_speech_prob"):
+        assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), key
+
+
 @pytest.mark.parametrize("name,mode", [("tiny.en", "greedy"), ("tiny.en", "beam"), ("base.en", "sample"), ("base.en", "beam_masks"),
                                        ("tiny.en", "greedy_free")])
 def test_decode_select_register_kernel_is_bit_identical(name, mode):
