@@ -267,7 +267,7 @@ def test_bench_window_greedy_identical_or_located_near_tie(k, dtype):
         rescored = sum(lp_tok) / (len(toks) + 1)
         rep.update(first_diverging_step=n_same + 1, device_token=toks[n_same], oracle_token=ref.tokens[n_same],
                    oracle_logprob_of_device_token=lp_tok[n_same], oracle_logprob_of_its_argmax=lp_best[n_same],
-                   gap_at_first_divergence=gaps[n_same], budget=2 * mx,
+                   gap_at_first_divergence=gaps[n_same], budget=2 * mx, margin_to_budget=2 * mx - gaps[n_same],
                    steps_where_device_token_is_not_the_oracle_argmax=[dict(step=i + 1, gap=gp, device=toks[i], oracle_argmax=best[i])
                                                                       for i, gp in enumerate(gaps) if gp > 0],
                    avg_logprob_of_device_sequence_by_oracle=rescored, d_avg_logprob_same_sequence=abs(avg - rescored))
