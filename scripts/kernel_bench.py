@@ -182,6 +182,24 @@ def main():
             print(f"  {name:26s} N={N:5d} K={K:5d}: {us:7.2f} us  {2.0 * (N * K + M * K + M * N) / us / 1e3:7.1f} GB/s algorithmic")
         print(f"  sum of the six projections of one layer: {tot:.1f} us")
 
+    if args.only in ("gemm_gelu",):
+        # the MLP's first projection with pre-activations of REALISTIC magnitude (std ~1.5: erff's two branches both taken inside a wave;
+        # the 0.05-scaled operands of the other sections keep every lane on its cheap branch): does the 256 x 256 kernel (one workgroup per
+        # CU: nothing to overlap its epilogue with) still beat the 128 x 128 kernel (three workgroups per CU) when the epilogue is this heavy?
+        print("-- tiled MFMA GEMM + bias + GELU at realistic activation magnitudes: us per launch by force_kernel")
+        codes = [7, 12, 0]
+        print("  " + " " * 34 + "".join(f"{c:>10d}" for c in codes))
+        for M, N, K in [(30000, 5120, 1280), (12000, 5120, 1280), (1500, 5120, 1280)]:
+            for scale, tag in ((0.05, "tiny x"), (0.2, "std ~1.4")):
+                a = (torch.randn(M, K, device=dev) * scale).half(); w = (torch.randn(N, K, device=dev) * scale).half()
+                c = torch.empty(M, N, dtype=torch.half, device=dev); bias = torch.zeros(N, device=dev)
+                row = []
+                for fk in codes:
+                    rc = lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS | EPI_GELU, fk, st)
+                    row.append(timed(lambda: lib.swx_test_gemm(1, p(a), K, p(w), p(bias), None, p(c), N, M, N, K, EPI_BIAS | EPI_GELU, fk, st),
+                                     max(args.iters // 10, 5)) if rc == 0 else float("nan"))
+                print(f"  M={M:6d} N={N:5d} K={K:5d} {tag:9s}:" + "".join(f"{u:10.1f}" for u in row))
+
     if args.only in ("logits",):
         # the vocabulary projection of a decode step (133 MB of weights, no bias, f32 out): the tiled kernel it runs on today against
         # the weight-streaming dec kernel at the nearest shape that kernel accepts (N = 810 x 64, residual epilogue) -- a price check

@@ -620,8 +620,8 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
                     s[t][r] = v;
                     tmax = fmaxf(tmax, v);
                 }
-            tmax = lane_xor16_max(tmax);                // (VALU row swaps, not ds_bpermute: swx_common.h)
-            tmax = lane_xor32_max(tmax);
+            tmax = lane_xor16_max_lds(tmax);            // (through the LDS crossbar on purpose in this HBM-streaming kernel: swx_common.h)
+            tmax = lane_xor32_max_lds(tmax);
             const float m_new = fmaxf(m_run[u], tmax);
             const float alpha = __expf(m_run[u] - m_new);
             float psum = 0.f;
@@ -634,8 +634,8 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
                     psum += p;
                     pb[4 * t + r] = (f16)p;
                 }
-            psum = lane_xor16_add(psum);
-            psum = lane_xor32_add(psum);
+            psum = lane_xor16_add_lds(psum);
+            psum = lane_xor32_add_lds(psum);
             l_run[u] = l_run[u] * alpha + psum;
             m_run[u] = m_new;
 #pragma unroll
@@ -841,8 +841,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f32(AttnArgs a)
                         tmax = fmaxf(tmax, v);
                     }
                 }
-                tmax = lane_xor16_max(tmax);                // (VALU row swaps, not ds_bpermute: swx_common.h)
-                tmax = lane_xor32_max(tmax);
+                tmax = SPLIT ? lane_xor16_max_lds(tmax) : lane_xor16_max(tmax);     // (SPLIT = the HBM-streaming decode step: swx_common.h)
+                tmax = SPLIT ? lane_xor32_max_lds(tmax) : lane_xor32_max(tmax);
                 const float m_new = fmaxf(m_run[qb], tmax);
                 const float m_use = m_new == -__builtin_inff() ? 0.f : m_new;      // a wave whose keys are all masked so far (SPLIT)
                 const float alpha = expf(m_run[qb] - m_use);                        // m_run = -inf -> 0
@@ -926,8 +926,8 @@ __global__ __launch_bounds__(256, 2) void attn_flash_f32(AttnArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ov[r] += sm[(w * 18 + 2 + wave * 4 + r) * 64 + lane] * sc_w;
         }
-        l = lane_xor16_add(l);
-        l = lane_xor32_add(l);
+        l = lane_xor16_add_lds(l);                  // (the SPLIT form keeps its LDS exchanges: swx_common.h)
+        l = lane_xor32_add_lds(l);
         const int qi = q0 + qn;
         if (qi < a.nq) {
             const float inv = 1.0f / l;

@@ -115,6 +115,39 @@ __device__ __forceinline__ float lane_xor32_add(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// The same two steps through the LDS crossbar (ds_bpermute), for the HBM-streaming attention kernels: there the exchange is a few
+// instructions beside a memory wait, the asynchronous LDS operation costs the wave no VALU issue slot, and the VALU form measured
+// SLOWER (strict-f32 decode cross-attention 66.2 -> 78.5 us, fp16 25.9 -> 26.0 us: profiles/r06_c23_f32_lane_xor_by_kernel.txt).
+// -DSWX_XATTN_VALU (A/B build) puts them back on the VALU.
+__device__ __forceinline__ float lane_xor16_max_lds(float x) {
+#ifdef SWX_XATTN_VALU
+    return lane_xor16_max(x);
+#else
+    return fmaxf(x, __shfl_xor(x, 16, 64));
+#endif
+}
+__device__ __forceinline__ float lane_xor32_max_lds(float x) {
+#ifdef SWX_XATTN_VALU
+    return lane_xor32_max(x);
+#else
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+#endif
+}
+__device__ __forceinline__ float lane_xor16_add_lds(float x) {
+#ifdef SWX_XATTN_VALU
+    return lane_xor16_add(x);
+#else
+    return x + __shfl_xor(x, 16, 64);
+#endif
+}
+__device__ __forceinline__ float lane_xor32_add_lds(float x) {
+#ifdef SWX_XATTN_VALU
+    return lane_xor32_add(x);
+#else
+    return x + __shfl_xor(x, 32, 64);
+#endif
+}
+
 // wave reductions, butterfly from 32 down to 1 (the order every caller's bit-identity claims were made with)
 __device__ __forceinline__ float wave_max(float v) {
     const int lane = swx_lane_id();
