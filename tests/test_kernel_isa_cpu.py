@@ -294,3 +294,37 @@ def test_f32_rows64_asm_loads_are_not_touched_before_their_wait():
         assert n_loads >= 15 and n_waits >= 4, (key, n_loads, n_waits)       # prologue 2 x NL + two unrolled chunks; three counted waits + the drain
         assert not viol, (key, viol[:6])
         assert not any("scratch_" in ln for ln in body), key
+
+
+def _bpermutes_per_kernel(src_name):
+    """(kernel symbol -> number of ds_bpermute_b32 in its body) for one csrc file"""
+    out, name = {}, None
+    for ln in _device_asm(src_name).split("\n"):
+        m = re.match(r"^(_Z\S+):\s", ln + " ")
+        if m and not ln.startswith(".L"):
+            name = m.group(1)
+            out.setdefault(name, 0)
+        elif name and "ds_bpermute_b32" in ln:
+            out[name] += 1
+        if "s_endpgm" in ln:
+            name = None
+    return out
+
+
+def test_reductions_exchange_lanes_on_the_valu_except_in_the_streaming_attention_kernels():
+    """Round 6 (csrc/swx_common.h::lane_xor): every wave / block reduction, the LayerNorm statistics of the dec GEMMs and the flash
+    kernels' row statistics exchange lanes with v_permlane16/32_swap and DPP -- no ds_bpermute (an LDS round trip on the dependency
+    chain) -- EXCEPT the two HBM-streaming attention kernels, which keep it on purpose (measured: profiles/r06_c25_*.json): the fp16
+    decode cross-attention body and the key-split form of attn_flash_f32.  A regression in either direction shows up here."""
+    for src in ("swx_decstep.hip", "swx_decode.hip", "swx_norm.hip", "swx_align.hip"):
+        bad = {k: v for k, v in _bpermutes_per_kernel(src).items() if v}
+        assert not bad, (src, bad)
+    attn = _bpermutes_per_kernel("swx_attn.hip")
+    flash2 = {k: v for k, v in attn.items() if "attn_flash2_f16" in k}
+    assert flash2 and not any(flash2.values()), flash2
+    split = {k: v for k, v in attn.items() if "attn_flash_f32" in k and k.endswith("ELb1EEEv8AttnArgs")}
+    assert len(split) == 2 and all(v == 4 for v in split.values()), split        # tmax (2) + the row sums of the merge (2)
+    cross = {k: v for k, v in attn.items() if "attn_decode_cross" in k}
+    assert cross and all(v >= 4 for v in cross.values()), cross                  # max + sum exchanges of its streaming loop
+    step = {k: v for k, v in attn.items() if "self_attn_step_f16" in k}
+    assert step and all(v <= 32 for v in step.values()), step                    # only the ancestor-id broadcasts (__shfl by lane index)
