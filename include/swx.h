@@ -302,6 +302,12 @@ int swx_test_self_attn_step(const void *d_q, void *d_kcache, void *d_vcache, con
  * 8 / 16 lane_xor16_add / 32_add, 32 wave_max, 64 wave_sum: 127 = all).  Nothing in the reference corresponds to it. */
 int swx_test_lane_xor(const uint32_t *d_in, uint32_t *d_out, int n_waves, void *stream);
 
+/* csrc/swx_common.h::gelu_erf2 (the GELU of the tiled / dec GEMM epilogues: two values on packed f32 instructions, both sides of
+ * erff's branch) against gelu_erf (the device library's erff) over ALL 2^32 f32 bit patterns: d_out[0] = values whose results differ
+ * (NaN results with different payloads not counted), d_out[1] = the lowest such bit pattern (0xffffffff if none), d_out[2] = NaN
+ * results whose payloads differ.  Nothing in the reference corresponds to it. */
+int swx_test_gelu_pair(uint64_t *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -171,6 +171,73 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // exact GELU (erf form), f32 -- upstream nn.GELU()
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// The same function for TWO values at once, bit for bit (round 6).  `erff` is the device library's: a divergent branch at |z| = 1
+// (z = x / sqrt 2) between a degree-6 polynomial in z^2 and 1 - exp(-t(|z|)) with the library's extended-precision exp; with
+// real activations both sides run in every wave (~38 VALU instructions per element; the MLP's first projection applies it to
+// 4.9 G elements per headline pass with all eight waves of a CU in the epilogue at once).  Here the library's operation sequence --
+// read off the compiled ISA: the same constants, the same fused multiply-adds in the same order -- is written once for a pair on
+// packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and instruction), both sides
+// evaluated and selected: 26 VALU instructions per element.  Equality with gelu_erf is checked EXHAUSTIVELY on hardware: all 2^32
+// bit patterns (tests/test_gpu_kernels.py::test_gelu_pair_is_bit_identical_for_every_float).  -DSWX_GELU_SCALAR (A/B build) = gelu_erf.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 swx_k2(unsigned u) { const float f = __uint_as_float(u); return (f32x2){f, f}; }
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x)
+{
+#ifdef SWX_GELU_SCALAR
+    return (f32x2){gelu_erf(x[0]), gelu_erf(x[1])};
+#else
+    const f32x2 z = x * swx_k2(0x3f3504f3u);
+    const f32x2 az = __builtin_elementwise_abs(z);
+    // |z| >= 1 (and NaN): t = |z| + |z| P(|z|), erf = 1 - exp(-t)
+    f32x2 p = __builtin_elementwise_fma(az, swx_k2(0x378e98abu), swx_k2(0xb9c68948u));
+    p = __builtin_elementwise_fma(az, p, swx_k2(0x3b7cd369u));
+    p = __builtin_elementwise_fma(az, p, swx_k2(0xbcc618b2u));
+    p = __builtin_elementwise_fma(az, p, swx_k2(0x3dda74e4u));
+    p = __builtin_elementwise_fma(az, p, swx_k2(0x3f228afdu));
+    p = __builtin_elementwise_fma(az, p, swx_k2(0x3e03c728u));
+    const f32x2 t = __builtin_elementwise_fma(az, p, az);
+    f32x2 a = t * swx_k2(0xbfb8aa3bu);                                      // -t log2(e), head
+    f32x2 b = __builtin_elementwise_fma(t, swx_k2(0xbfb8aa3bu), -a);        // ... its rounding error
+    f32x2 r;
+    r[0] = __builtin_rintf(a[0]); r[1] = __builtin_rintf(a[1]);
+    b = __builtin_elementwise_fma(t, swx_k2(0xb2a5705fu), b);               // ... and the tail of log2(e)
+    a = a - r;
+    a = a + b;
+    f32x2 big;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float e = __builtin_amdgcn_exp2f(a[i]);
+        e = __builtin_ldexpf(e, (int)r[i]);
+        e = !(__uint_as_float(0x42ce8ed0u) < t[i]) ? e : 0.f;               // underflow of exp(-t)
+        e = !(__uint_as_float(0xc2b17218u) > t[i]) ? e : __builtin_inff();
+        big[i] = e;
+    }
+    big = swx_k2(0x3f800000u) - big;
+    // |z| < 1: erf = |z| + |z| Q(z^2)
+    const f32x2 t2 = z * z;
+    f32x2 q = __builtin_elementwise_fma(swx_k2(0xba1345e1u), t2, swx_k2(0x3ba10414u));
+    q = __builtin_elementwise_fma(t2, q, swx_k2(0xbcdac9b8u));
+    q = __builtin_elementwise_fma(t2, q, swx_k2(0x3de703beu));
+    q = __builtin_elementwise_fma(t2, q, swx_k2(0xbec09330u));
+    q = __builtin_elementwise_fma(t2, q, swx_k2(0x3e0375d0u));
+    const f32x2 small = __builtin_elementwise_fma(az, q, az);
+    f32x2 erf;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float res = !(az[i] < 1.0f) ? big[i] : small[i];
+        erf[i] = __uint_as_float((__float_as_uint(res) & 0x7fffffffu) | (__float_as_uint(z[i]) & 0x80000000u));    // copysign(res, z)
+    }
+    return (x * swx_k2(0x3f000000u)) * (erf + swx_k2(0x3f800000u));
+#endif
+}
+// n (even) values in place
+template <int N> __device__ __forceinline__ void gelu_erf_n(float (&v)[N])
+{
+    static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+    for (int e = 0; e < N; e += 2) { f32x2 t = {v[e], v[e + 1]}; t = gelu_erf2(t); v[e] = t[0]; v[e + 1] = t[1]; }
+}
+
 // monotone float <-> uint mapping for atomicMax on floats
 __device__ __forceinline__ unsigned f32_to_ordered(float f) {
     unsigned u = __float_as_uint(f);

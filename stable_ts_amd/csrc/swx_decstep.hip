@@ -297,8 +297,7 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
             for (int e = 0; e < 4; ++e) v[e] += c2[e];
         }
         if constexpr (E_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            { f32x2 g0 = {v[0], v[1]}, g1 = {v[2], v[3]}; g0 = gelu_erf2(g0); g1 = gelu_erf2(g1); v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1]; }
         }
         f16 *dst;
         if constexpr (E_RES) {
@@ -475,8 +474,7 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
             for (int e = 0; e < 4; ++e) v[e] += c2[e];
         }
         if constexpr (E_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            { f32x2 g0 = {v[0], v[1]}, g1 = {v[2], v[3]}; g0 = gelu_erf2(g0); g1 = gelu_erf2(g1); v[0] = g0[0]; v[1] = g0[1]; v[2] = g1[0]; v[3] = g1[1]; }
         }
         f16 *dst;
         if constexpr (E_RES) {

@@ -159,8 +159,7 @@ __device__ __forceinline__ void tile_epilogue_f16_one(const GemmArgs &g, unsigne
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bv[e];
             if (g.epi & EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                gelu_erf_n<8>(v);
             }
             f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
             if (g.epi & EPI_CBATCH) {
@@ -581,8 +580,7 @@ __device__ __forceinline__ void big_tile_epilogue(const GemmArgs &g, unsigned ch
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += bv[e];
             if (g.epi & EPI_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                gelu_erf_n<8>(v);
             }
             f16 *cp = (f16 *)g.C + (size_t)gm * g.ldc + gn;
             if (full) {

@@ -733,6 +733,25 @@ __global__ __launch_bounds__(64) void lane_xor_check_kernel(const uint32_t *__re
     o[12 * 64] = ok;
 }
 
+// gelu_erf2 (packed, both sides of erff's branch) vs gelu_erf (the device library's erff) over EVERY f32 bit pattern (swx_test_gelu_pair)
+__global__ __launch_bounds__(256) void gelu_pair_check_kernel(unsigned long long *__restrict__ out)
+{
+    const unsigned base = (blockIdx.x * 256u + threadIdx.x) * 32u;          // 2^27 threads x 32 values = 2^32
+    unsigned bad = 0, nan_bits = 0, first = 0xffffffffu;
+#pragma unroll 4
+    for (unsigned j = 0; j < 32; j += 2) {
+        const unsigned u0 = base + j, u1 = base + j + 1;
+        const f32x2 x = {__uint_as_float(u0), __uint_as_float(u1)};
+        const f32x2 got = gelu_erf2(x);
+        const float r0 = gelu_erf(x[0]), r1 = gelu_erf(x[1]);
+        const unsigned g0 = __float_as_uint(got[0]), g1 = __float_as_uint(got[1]), e0 = __float_as_uint(r0), e1 = __float_as_uint(r1);
+        if (g0 != e0) { if (r0 != r0 && got[0] != got[0]) ++nan_bits; else { ++bad; first = first < u0 ? first : u0; } }
+        if (g1 != e1) { if (r1 != r1 && got[1] != got[1]) ++nan_bits; else { ++bad; first = first < u1 ? first : u1; } }
+    }
+    if (bad) { atomicAdd(out, (unsigned long long)bad); atomicMin(out + 1, (unsigned long long)first); }
+    if (nan_bits) atomicAdd(out + 2, (unsigned long long)nan_bits);
+}
+
 extern "C" {
 
 int swx_debug_flags(int flags)
@@ -1626,6 +1645,19 @@ int swx_test_lane_xor(const uint32_t *d_in, uint32_t *d_out, int n_waves, void *
 {
     if (!d_in || !d_out || n_waves <= 0) return -1;
     hipLaunchKernelGGL(lane_xor_check_kernel, dim3(n_waves), dim3(64), 0, S(stream), d_in, d_out);
+    SWX_CHECK_LAUNCH();
+    return 0;
+}
+
+int swx_test_gelu_pair(uint64_t *d_out, void *stream)
+{
+    if (!d_out) return -1;
+    hipStream_t s = S(stream);
+    const unsigned long long init[3] = {0ull, 0xffffffffull, 0ull};
+    hipError_t e = hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);            // `init` is a stack-lifetime staging buffer
+    if (e != hipSuccess) return -100 - (int)e;
+    hipLaunchKernelGGL(gelu_pair_check_kernel, dim3(1u << 19), dim3(256), 0, s, (unsigned long long *)d_out);
     SWX_CHECK_LAUNCH();
     return 0;
 }

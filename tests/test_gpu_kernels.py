@@ -619,6 +619,19 @@ def test_cross_kv_from_one_launch_equals_two_launches(name, B):
     torch.cuda.synchronize()
     assert one.numel() == two.numel() and torch.equal(one, two), int((one != two).sum())
     assert float(one.view(torch.float16).float().abs().max()) > 0.1        # not a buffer of zeros@pytest.mark.gpu
+def test_gelu_pair_is_bit_identical_for_every_float():
+    """csrc/swx_common.h::gelu_erf2 -- the GELU of the GEMM epilogues restated for two values on packed f32 instructions, both sides of
+    the device library's erff branch evaluated and selected -- against 0.5 x (1 + erff(x / sqrt 2)) for ALL 2^32 f32 bit patterns."""
+    lib = _lib()
+    out = torch.zeros(3, dtype=torch.int64, device="cuda")
+    assert lib.swx_test_gelu_pair(_p(out), _stream()) == 0
+    torch.cuda.synchronize()
+    bad, first, nan_bits = out.cpu().tolist()
+    assert bad == 0, (bad, hex(first))
+    assert nan_bits == 0, nan_bits
+
+
+@pytest.mark.gpu
 def test_lane_xor_helpers_match_shuffles():
     """csrc/swx_common.h: the wave reductions and the online-softmax row statistics exchange lanes on the VALU (gfx950's
     v_permlane16/32_swap, DPP) instead of ds_bpermute; every helper must return what __shfl_xor returns, lane for lane."""
