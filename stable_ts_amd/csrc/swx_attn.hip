@@ -1291,6 +1291,164 @@ __global__ __launch_bounds__(64 * WPB) void self_attn_step_f16(SelfAttnArgs a)
 }
 
 
+// ---------------------------------------------------------------------------- decode-step self-attention, long context, few waves
+// Round 6.  A decode that starts from a carried-over prompt (the reference's sequential flow: `model.transcribe(audio)` decodes ONE
+// window per call, positions 228-340) runs self_attn_step_f16<true> as R x H = 100 waves, each a chain of DEPENDENT round trips:
+// pos0 -> ancestor ids -> K rows of positions < 128 -> K rows 128-255 -> K rows 256-383 -> [softmax] -> per 64 keys (ancestor ids ->
+// V fragments): 13 trips at position 340 = the launch's 13 us.  With at most one wave per SIMD there is no neighbour to hide them
+// behind and the whole register file belongs to the wave, so this variant requests EVERYTHING a row needs in two batches:
+//   1. the ancestor ids of all seven 64-position chunks;
+//   2. K rows of positions < 256, the V fragments of positions < 128 -- and, behind them in the queue, K rows of positions 256-447 and
+//      the V fragments of positions 128-447 (their ancestor ids travel between lanes by shuffles instead of being loaded again).
+// = pos0 + two round trips.  Per score and per output element the expressions and their ORDER are self_attn_step_f16's (one lane owns
+// a key's whole dot product; a lane group accumulates its keys in ascending order), so the result is bit-identical
+// (tests/hw_checks/self_attn_check.py, tests/test_gpu_model.py).  Dispatched for R x H <= 1024 (SWX_FLAG_SELFATTN_NO_DEEP: A/B).
+__global__ __launch_bounds__(64) void self_attn_step_long_f16(SelfAttnArgs a)
+{
+    constexpr int PF = 16;                   // V fragments per lane of positions < 128 (keys kg + 8 i)
+    constexpr int NC = 5;                    // 64-position chunks past 128: 128 + 64 * 5 = 448 = n_text_ctx
+    __shared__ float qs[DH];
+    __shared__ float ps[512];
+    const int lane = threadIdx.x, h = blockIdx.x, r = blockIdx.y;
+    const int d = a.d;
+    const int pos = a.pos0[r];
+    const int32_t *anc = a.anc ? a.anc + (size_t)r * a.n_ctx : nullptr;
+    const f16 *kc = (const f16 *)a.kcache, *vc = (const f16 *)a.vcache;
+    const int32_t *ap = anc ? anc : a.pos0;
+    // ---- batch 1: ancestor ids of every chunk (clamped unconditional loads + select; the new position is row r's own)
+    int pr[2 + NC];
+#pragma unroll
+    for (int c = 0; c < 2 + NC; ++c) {
+        const int j = lane + 64 * c;
+        const bool old = anc && j < pos;
+        const int t = ap[old ? j : 0];
+        pr[c] = old ? t : r;
+    }
+    qs[lane] = (float)((const f16 *)a.qkv)[(size_t)r * a.ldqkv + h * DH + lane];
+    // ---- batch 2: K rows (a lane owns whole keys) and V fragments (lane = key group kg, 8-wide d chunk dc)
+    auto load_k = [&](int c, f16x8 (&kk)[8]) {
+        const int j = lane + 64 * c;
+        const bool has = j <= pos;
+        const f16 *kr = kc + ((size_t)(has ? pr[c] : r) * a.n_ctx + (has ? j : 0)) * d + h * DH;     // clamped, never predicated
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kk[e] = *(const f16x8 *)(kr + 8 * e);
+    };
+    // the V side's ancestor ids (lane group kg reads keys kg + 8 u of every chunk: the id sits in lane kg + 8 u): all 56 exchanges as ONE
+    // batch in front of the loads -- inside the guarded load blocks each exchange is an LDS round trip of its own in front of its load
+    const int kg = lane >> 3, dc = (lane & 7) * 8;
+    int pv[2 + NC][8];
+#pragma unroll
+    for (int c = 0; c < 2 + NC; ++c)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[c][u] = __shfl(pr[c], kg + 8 * u, 64);
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 kA[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (64 * c <= pos) load_k(c, kA[c]);                // uniform: the chunk holds a cached position
+    f16x8 vpre[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        if (i * 8 <= pos) {                                  // uniform
+            const int j = kg + 8 * i;
+            const int prj = pv[i >> 3][i & 7];
+            const bool ok = j <= pos;
+            vpre[i] = *(const f16x8 *)(vc + ((size_t)(ok ? prj : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
+        }
+    }
+    constexpr int NE = 3;                    // V batches / K chunk requested up front: positions < 320; the rest (320-447) after the first scores
+    f16x8 kE[8];
+    if (64 * 4 <= pos) load_k(4, kE);
+    auto load_vb = [&](int b, f16x8 (&vv)[8]) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = kg + 128 + 64 * b + 8 * u;
+            const int prj = pv[2 + b][u];
+            const bool ok = j <= pos;
+            vv[u] = *(const f16x8 *)(vc + ((size_t)(ok ? prj : r) * a.n_ctx + (ok ? j : 0)) * d + h * DH + dc);
+        }
+    };
+    f16x8 vb[NC][8];
+#pragma unroll
+    for (int b = 0; b < NE; ++b)
+        if (128 + 64 * b <= pos) load_vb(b, vb[b]);          // uniform
+    __syncthreads();                                        // qs visible
+    // ---- scores
+    auto dot_regs = [&](const f16x8 *kk) {
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[c * 8 + e], (float)kk[c][e], acc);
+        return acc;
+    };
+    float mx = -__builtin_inff();
+    auto score = [&](int c, const f16x8 *kk) {
+        const int j = lane + 64 * c;
+        if (64 * c <= pos && j <= pos) {
+            const float sc = dot_regs(kk) * 0.125f;
+            ps[j] = sc; mx = fmaxf(mx, sc);
+        }
+    };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) score(c, kA[c]);
+    // positions >= 320 (never reached by the sequential flow's 223-token prompts + 112 steps; one more round trip when they are): their
+    // K rows and V fragments take over the registers of the rows just multiplied
+    __builtin_amdgcn_sched_barrier(0);
+    f16x8 kL[2][8];
+#pragma unroll
+    for (int c = 5; c < 2 + NC; ++c)
+        if (64 * c <= pos) load_k(c, kL[c - 5]);
+#pragma unroll
+    for (int b = NE; b < NC; ++b)
+        if (128 + 64 * b <= pos) load_vb(b, vb[b]);
+    score(4, kE);
+#pragma unroll
+    for (int c = 5; c < 2 + NC; ++c) score(c, kL[c - 5]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j <= pos; j += 64) { const float e = expf(ps[j] - mx); ps[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    // ---- P.V : keys in ascending order per lane group
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+        const int j = kg + 8 * i;
+        if (i * 8 <= pos && j <= pos) {
+            const float pj = ps[j] * inv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vpre[i][e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NC; ++b)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = kg + 128 + 64 * b + 8 * u;
+            if (128 + 64 * b <= pos && j <= pos) {
+                const float pj = ps[j] * inv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)vb[b][u][e], acc[e]);
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += lane_xor<8>(acc[e], lane);
+        acc[e] = lane_xor16_add(acc[e]);
+        acc[e] = lane_xor32_add(acc[e]);
+    }
+    if (kg == 0) {
+        f16 *op = (f16 *)a.o + (size_t)r * a.ldo + h * DH + dc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = (f16)acc[e];
+    }
+}
+
+
 // =============================================================================================== qk capture
 template <typename T>
 __global__ __launch_bounds__(256) void qk_capture_kernel(const T *__restrict__ q, int64_t ldq, int q_rows_per_w, int row0,
@@ -1545,7 +1703,10 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
             if (wg5) hipLaunchKernelGGL((self_attn_step_f16<false, 5>), dim3(a.H, cdiv(a.R, 5)), dim3(320), 0, s, a);
             else hipLaunchKernelGGL((self_attn_step_f16<false, 1>), dim3(a.H, a.R), dim3(64), 0, s, a);
         } else {
-            if (wg5) hipLaunchKernelGGL((self_attn_step_f16<true, 5>), dim3(a.H, cdiv(a.R, 5)), dim3(320), 0, s, a);
+            // few waves (one window of the sequential flow: 100): every load of a row in two batches (bit-identical)
+            const bool deep = !wg5 && (int64_t)a.R * a.H <= 1024 && a.n_ctx <= 448 && !(swx_flags() & SWX_FLAG_SELFATTN_NO_DEEP);
+            if (deep) hipLaunchKernelGGL(self_attn_step_long_f16, dim3(a.H, a.R), dim3(64), 0, s, a);
+            else if (wg5) hipLaunchKernelGGL((self_attn_step_f16<true, 5>), dim3(a.H, cdiv(a.R, 5)), dim3(320), 0, s, a);
             else hipLaunchKernelGGL((self_attn_step_f16<true, 1>), dim3(a.H, a.R), dim3(64), 0, s, a);
         }
         SWX_CHECK_LAUNCH();

@@ -52,20 +52,29 @@ constexpr int DEC_NPF = 4;        // prefetch loads per wave (64 lines of 128 B 
 // NKS = K-slice depth / 32 and the epilogue EPI are fixed at compile time: every loop below unrolls without branches, and no
 // load sits under a run-time condition (a conditional load compiles to a branch whose join waits vmcnt(0), which would drain
 // the weight stream before the barrier -- seen in the ISA of the run-time-epilogue version)
-template <int MT, int NKS, int EPI>
-__global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
+// WPB = waves per workgroup: 4 (a workgroup = the four 16-column groups of a 64-column panel, sharing one activation tile in LDS), or 1
+// (round 6, MT = 1, launches of few workgroups -- the 5 rows of the reference's sequential flow are 20-80 four-wave workgroups, each
+// asking ONE CU for 160 KB of weights + its tile: 2-3 round trips at the ~64 KB a CU keeps in flight; as single-wave workgroups the same
+// waves sit on 80-320 CUs with 40 KB + a tile each).  A wave's arithmetic -- its statistics, k-step order, epilogue -- does not depend
+// on WPB: bit-identical (tests/test_gpu_kernels.py).
+template <int MT, int NKS, int EPI, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void gemm_dec_f16(DecGemmArgs g)
 {
     constexpr bool E_LN = (EPI & DEC_LN) != 0, E_GELU = (EPI & DEC_GELU) != 0, E_RES = (EPI & DEC_RES) != 0,
                    E_QKV = (EPI & DEC_QKV) != 0, E_SLAB = (EPI & DEC_SLAB) != 0, E_TICKET = (EPI & DEC_TICKET) != 0;
     static_assert(!E_TICKET || (E_SLAB && E_RES && !E_LN), "the ticket reduction finishes x += bias + sum of slabs");
+    static_assert(WPB == 4 || (WPB == 1 && MT == 1 && !E_TICKET), "single-wave workgroups: one row tile, no in-launch reduction");
     constexpr bool E_FIN = !E_SLAB || E_TICKET;      // this launch finishes outputs itself: bias / residual operands are loaded
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // [MT*16][kslice] f16 | float2 stat[MT*16]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int li = lane & 15, lg = lane >> 4;
     // ---- block id -> (column panel, K slice, row group): all row groups of one (panel, slice) unit share an XCD
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
-    const int unit = (slot / g.n_rg) * 8 + xcd, rg = slot % g.n_rg;
+    const int unit_x = (slot / g.n_rg) * 8 + xcd, rg = slot % g.n_rg;       // WPB = 1: (unit, 16-column group) pairs
+    const int unit = WPB == 4 ? unit_x : unit_x >> 2;
+    const int wave = WPB == 4 ? tid >> 6 : unit_x & 3;                      // this wave's 16-column group of the panel
+    const int dwave = WPB == 4 ? wave : 0;                                  // ... and its share of the workgroup's common work
     const int panels = (g.N + 63) >> 6;
     if (unit >= panels * g.ks2) return;
     const int panel = unit / g.ks2, ks_id = unit - panel * g.ks2;
@@ -83,8 +92,8 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     {
         constexpr int n_instr = (MT * 16 * SPR) >> 6;      // = MT * NKS, a multiple of 4
 #pragma unroll
-        for (int j = 0; j < n_instr / 4; ++j) {
-            const int q = j * 4 + wave;
+        for (int j = 0; j < n_instr / WPB; ++j) {
+            const int q = j * WPB + dwave;
             const int p = q * 64 + lane;                    // 16-byte slot index of this lane's destination
             const int row = p / SPR, ps = p - row * SPR;
             const int kslot = ps ^ (row & 15);              // logical slot that must land there (swizzle on the source)
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_dec_f16(DecGemmArgs g)
     float2 *stat = (float2 *)(smem + (size_t)MT * 16 * RS);
     if constexpr (E_LN) {
         const f16x2 one2 = {(f16)1.f, (f16)1.f};
-        for (int rb = wave * 4 + lg; rb < MT * 16; rb += 16) {
+        for (int rb = dwave * 4 + lg; rb < MT * 16; rb += 4 * WPB) {
             const unsigned char *rp = smem + (size_t)rb * RS + li * 16;
             f16x8 v[SPR / 16];                      // the row's share of this lane: every read in flight before the first add
 #pragma unroll
@@ -642,6 +651,10 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     } else {
     const int grid = cdiv(units, 8) * g.n_rg * 8;
     const size_t lds = (size_t)mt * 16 * g.kslice * 2 + (size_t)mt * 16 * sizeof(float2);
+    // few workgroups (<= 80 of four waves: the 5 rows of a sequential window's decode step): the same waves as single-wave workgroups,
+    // spread over four times as many CUs (gemm_dec_f16<.., WPB = 1>; bit-identical; SWX_FLAG_DEC_NO_W1: A/B)
+    const bool w1 = mt == 1 && !ticket && units * g.n_rg <= ((swx_flags() & SWX_FLAG_DEC_W1_WIDE) ? 160 : 80) && !(swx_flags() & SWX_FLAG_DEC_NO_W1);
+    const int grid1 = cdiv(units * 4, 8) * g.n_rg * 8;
     {   // (profiler scopes must not nest: each one closes the most recent record)
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
     // the epilogues the decoder step uses (compile-time): QKV, out-projections, cross-q, MLP-in, MLP-out (split / un-split)
@@ -653,22 +666,35 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
             attr_done = true; \
         } \
         hipLaunchKernelGGL((gemm_dec_f16<MT_, NK_, EP_>), dim3(grid), dim3(256), lds, s, g); } while (0)
-#define SWX_DEC_MT(NK_, EP_) do { if (mt == 1) SWX_DEC(1, NK_, EP_); else if (mt == 2) SWX_DEC(2, NK_, EP_); else SWX_DEC(3, NK_, EP_); } while (0)
-#define SWX_DEC_NK(EP_) do { switch (nks) { \
-        case 12: SWX_DEC_MT(12, EP_); break; case 16: SWX_DEC_MT(16, EP_); break; case 20: SWX_DEC_MT(20, EP_); break; \
-        case 24: SWX_DEC_MT(24, EP_); break; case 32: SWX_DEC_MT(32, EP_); break; case 40: SWX_DEC_MT(40, EP_); break; \
+#define SWX_DEC_W1(NK_, EP_) do { \
+        static bool attr_done1 = false; \
+        if (!attr_done1) { \
+            hipError_t e_ = hipFuncSetAttribute((const void *)gemm_dec_f16<1, NK_, EP_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            if (e_ != hipSuccess) return -100 - (int)e_; \
+            attr_done1 = true; \
+        } \
+        hipLaunchKernelGGL((gemm_dec_f16<1, NK_, EP_, 1>), dim3(grid1), dim3(64), lds, s, g); } while (0)
+#define SWX_DEC_MT4(NK_, EP_) do { if (mt == 1) SWX_DEC(1, NK_, EP_); else if (mt == 2) SWX_DEC(2, NK_, EP_); else SWX_DEC(3, NK_, EP_); } while (0)
+#define SWX_DEC_MT(NK_, EP_) do { if (w1) SWX_DEC_W1(NK_, EP_); else SWX_DEC_MT4(NK_, EP_); } while (0)
+#define SWX_DEC_NK_(MTM_, EP_) do { switch (nks) { \
+        case 12: MTM_(12, EP_); break; case 16: MTM_(16, EP_); break; case 20: MTM_(20, EP_); break; \
+        case 24: MTM_(24, EP_); break; case 32: MTM_(32, EP_); break; case 40: MTM_(40, EP_); break; \
         default: return -4; } } while (0)
+#define SWX_DEC_NK(EP_) SWX_DEC_NK_(SWX_DEC_MT, EP_)
     switch (epi) {          // K-slice depths: d = 384 / 512 / 768 / 1024 / 1280 of the Whisper sizes and the pieces of 4d that fit
         case DEC_LN | DEC_QKV: SWX_DEC_NK(DEC_LN | DEC_QKV); break;
         case DEC_RES: SWX_DEC_NK(DEC_RES); break;
         case DEC_LN: SWX_DEC_NK(DEC_LN); break;
         case DEC_LN | DEC_GELU: SWX_DEC_NK(DEC_LN | DEC_GELU); break;
         case DEC_RES | DEC_SLAB: SWX_DEC_NK(DEC_RES | DEC_SLAB); break;
-        case DEC_RES | DEC_SLAB | DEC_TICKET: SWX_DEC_NK(DEC_RES | DEC_SLAB | DEC_TICKET); break;
+        case DEC_RES | DEC_SLAB | DEC_TICKET: SWX_DEC_NK_(SWX_DEC_MT4, DEC_RES | DEC_SLAB | DEC_TICKET); break;
         default: return -4;
     }
 #undef SWX_DEC_NK
+#undef SWX_DEC_NK_
 #undef SWX_DEC_MT
+#undef SWX_DEC_MT4
+#undef SWX_DEC_W1
 #undef SWX_DEC
     }
     }

@@ -2,7 +2,7 @@
 short and the long variant, and for every position up to the end of the context the long variant, must agree BIT FOR BIT with the
 general cached-attention kernel (self_attn_cached) on the same cache, with and without an ancestor table (beam search), with
 ragged positions per row.  Round 4 batches the loads of the positions >= 128 (a decode that started from a long prompt); the
-multiply-adds keep their order.  Exit code 0 = all agree.
+multiply-adds keep their order; round 6 adds the few-waves kernel that requests every load of a row in two batches.  Exit code 0 = all agree.
 
     python tests/hw_checks/self_attn_step_check.py
 """
@@ -28,7 +28,9 @@ def main() -> int:
                                                       (5, 20, 1280, 448, 200, 447, True), (5, 20, 1280, 448, 128, 129, False),
                                                       (40, 8, 512, 448, 0, 447, True), (7, 6, 384, 448, 250, 400, False),
                                                       (100, 20, 1280, 448, 127, 128, True), (33, 20, 1280, 448, 380, 447, True),
-                                                      (15, 6, 384, 448, 0, 127, True), (600, 20, 1280, 448, 3, 120, True)]:
+                                                      (15, 6, 384, 448, 0, 127, True), (600, 20, 1280, 448, 3, 120, True),
+                                                      (5, 20, 1280, 448, 228, 340, True), (51, 20, 1280, 448, 300, 447, True),
+                                                      (5, 20, 1280, 448, 0, 447, True), (10, 8, 512, 448, 319, 321, True)]:
         q = (torch.randn(R, d, generator=g) * 0.8).half().to(dev)
         kc = (torch.randn(R, n_ctx, d, generator=g) * 0.8).half().to(dev)
         vc = torch.randn(R, n_ctx, d, generator=g).half().to(dev)
@@ -40,14 +42,19 @@ def main() -> int:
             anc[torch.arange(R), pos.cpu().long()] = torch.arange(R).int()      # the newest position is the row's own (the beam
             anc = anc.to(dev)                                                    # update writes it so; the step kernel assumes it)
         outs = {}
-        for variant in (0, 1, 2):
+        # variant 1 = the long-context step: at R x H <= 1024 waves the kernel that requests every load of a row in two batches
+        # (self_attn_step_long_f16, round 6), else / with flag 4 (SWX_FLAG_SELFATTN_NO_DEEP) the chunk-by-chunk kernel: "1" and "1c"
+        old_flags = lib.swx_debug_flags(-1)
+        for variant in (0, 1, "1c", 2):
             if variant == 0 and pos_hi >= 128:
                 continue
             o = torch.full((R, d), float("nan"), dtype=torch.half, device=dev)
-            rc = lib.swx_test_self_attn_step(p(q), p(kc), p(vc), p(anc), p(pos), R, H, n_ctx, d, variant, p(o), st)
+            lib.swx_debug_flags((old_flags | 4) if variant == "1c" else (old_flags & ~4))
+            rc = lib.swx_test_self_attn_step(p(q), p(kc), p(vc), p(anc), p(pos), R, H, n_ctx, d, 1 if variant == "1c" else variant, p(o), st)
             torch.cuda.synchronize()
-            outs[variant] = (rc, o)
-        ref = outs[2]
+            lib.swx_debug_flags(old_flags)
+            outs[str(variant)] = (rc, o)
+        ref = outs["2"]
         ok = all(rc == 0 for rc, _ in outs.values()) and all(torch.equal(o, ref[1]) for _, o in outs.values()) and not torch.isnan(ref[1]).any()
         print(f"R={R:3d} H={H:2d} d={d:4d} pos {pos_lo:3d}..{pos_hi:3d} anc={use_anc}: variants {sorted(outs)} bit-identical {bool(ok)}")
         if not ok:

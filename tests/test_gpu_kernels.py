@@ -490,6 +490,40 @@ def test_dec_gemm_slab_reduction_inside_the_launch_is_bit_identical(M, N, K):
         lib.swx_debug_flags(prev)
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 1280, 1280), (5, 3840, 1280), (5, 5120, 1280), (5, 1280, 5120), (1, 384, 384), (16, 512, 2048),
+                                   (10, 768, 768), (13, 1024, 4096)])
+def test_dec_gemm_single_wave_workgroups_are_bit_identical(M, N, K):
+    # round 6: launches of at most 80 four-wave workgroups with one row tile (the 5 rows of a sequential window's decode step) run
+    # the same waves as SINGLE-wave workgroups (gemm_dec_f16<1, NKS, EPI, WPB = 1>: four times as many CUs share the weight stream);
+    # flag 16 = SWX_FLAG_DEC_NO_W1 puts the four-wave workgroups back.  Every epilogue the decode step uses: equal bits.
+    lib = _lib()
+    rng = np.random.default_rng(M * 7 + N + K)
+    a = (rng.standard_normal((M, K)) * rng.uniform(0.5, 2.0, (M, 1)) + rng.uniform(-1, 1, (M, 1))).astype(np.float32) * 0.5
+    w = rng.standard_normal((N, K)).astype(np.float32) * 0.03
+    b = rng.standard_normal(N).astype(np.float32) * 0.1
+    x = rng.standard_normal((M, N)).astype(np.float32)
+    gamma = (1.0 + 0.2 * rng.standard_normal(K)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(K)).astype(np.float32)
+    cases = [("res", dict(bias=b, x=x, epi=4 | 16), "x")]
+    if K <= 1280:
+        cases += [("ln", dict(gamma=gamma, beta=beta, bias=b, epi=1), "c"), ("ln+gelu", dict(gamma=gamma, beta=beta, bias=b, epi=1 | 2), "c")]
+        if N % 3 == 0 and N // 3 == K:
+            b3 = b.copy(); b3[K:2 * K] = 0.0
+            cases += [("qkv", dict(gamma=gamma, beta=beta, bias=b3, epi=1 | 8, d=K, n_ctx=8, pos0=rng.integers(0, 8, M)), None)]
+    prev = lib.swx_debug_flags(-1)
+    try:
+        for name, kw, key in cases:
+            lib.swx_debug_flags(prev & ~16)
+            got = _dec_gemm(a, w, **kw)
+            lib.swx_debug_flags(prev | 16)
+            ref = _dec_gemm(a, w, **kw)
+            for k in ([key] if key else ["c", "kcache", "vcache"]):
+                assert np.isfinite(got[k]).all() and np.abs(got[k]).max() > 0, (name, k)
+                assert np.array_equal(got[k], ref[k]), (name, k, float(np.abs(got[k] - ref[k]).max()))
+    finally:
+        lib.swx_debug_flags(prev)
+
+
 @pytest.mark.parametrize("M,N,K,gelu", [(100, 1280, 1280, False), (100, 5120, 1280, True), (7, 384, 384, False),
                                         (33, 2048, 512, True), (100, 3072, 768, True)])
 def test_dec_gemm_layernorm_fold(M, N, K, gelu):

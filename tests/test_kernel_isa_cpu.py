@@ -118,7 +118,11 @@ def test_dec_gemm_asm_loads_are_not_touched_before_their_wait(asm_text):
         assert n_pf == 4, (name, n_pf)
         assert not pending and not pf_pending and not red_pending, (name, len(pending), len(pf_pending), len(red_pending))
         assert n_red in (0, 4, 8, 12), (name, n_red)                 # four slab reads per row tile of a DEC_TICKET instantiation
-        assert first_barrier is not None and last_mfma is not None and first_barrier < last_mfma, name
+        if re.search(r"gemm_dec_f16ILi\d+ELi\d+ELi\d+ELi1EEE", name):
+            # WPB = 1 (round 6): a workgroup of ONE wave -- hipcc drops the barrier instructions; the tile is waited for by the wave itself
+            assert last_mfma is not None, name
+        else:
+            assert first_barrier is not None and last_mfma is not None and first_barrier < last_mfma, name
         early = [d for d in drains if d < last_mfma]
         assert not early, f"{name}: s_waitcnt vmcnt(0) before the last MFMA (lines {early[:3]}): the weight stream is drained"
 
