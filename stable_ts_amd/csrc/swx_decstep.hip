@@ -653,7 +653,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     const size_t lds = (size_t)mt * 16 * g.kslice * 2 + (size_t)mt * 16 * sizeof(float2);
     // few workgroups (<= 80 of four waves: the 5 rows of a sequential window's decode step): the same waves as single-wave workgroups,
     // spread over four times as many CUs (gemm_dec_f16<.., WPB = 1>; bit-identical; SWX_FLAG_DEC_NO_W1: A/B)
-    const bool w1 = mt == 1 && !ticket && units * g.n_rg <= ((swx_flags() & SWX_FLAG_DEC_W1_WIDE) ? 160 : 80) && !(swx_flags() & SWX_FLAG_DEC_NO_W1);
+    const bool w1 = mt == 1 && !ticket && units * g.n_rg <= 80 && !(swx_flags() & SWX_FLAG_DEC_NO_W1);
     const int grid1 = cdiv(units * 4, 8) * g.n_rg * 8;
     {   // (profiler scopes must not nest: each one closes the most recent record)
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
