@@ -491,9 +491,10 @@ def test_dec_gemm_slab_reduction_inside_the_launch_is_bit_identical(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(5, 1280, 1280), (5, 3840, 1280), (5, 5120, 1280), (5, 1280, 5120), (1, 384, 384), (16, 512, 2048),
-                                   (10, 768, 768), (13, 1024, 4096)])
+                                   (10, 768, 768), (13, 1024, 4096), (60, 1280, 1280), (40, 1280, 1280), (33, 512, 512), (17, 384, 1536)])
 def test_dec_gemm_single_wave_workgroups_are_bit_identical(M, N, K):
-    # round 6: launches of at most 80 four-wave workgroups with one row tile (the 5 rows of a sequential window's decode step) run
+    # round 6: launches of at most 80 four-wave workgroups with one row tile per workgroup (the 5 rows of a sequential window's decode step;
+    # several row groups: the 60 rows of a 20-window prefill at N = 1280) run
     # the same waves as SINGLE-wave workgroups (gemm_dec_f16<1, NKS, EPI, WPB = 1>: four times as many CUs share the weight stream);
     # flag 16 = SWX_FLAG_DEC_NO_W1 puts the four-wave workgroups back.  Every epilogue the decode step uses: equal bits.
     lib = _lib()
