@@ -345,14 +345,18 @@ __device__ __forceinline__ void dec_glds16_asm(const void *gsrc, unsigned lds_ds
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int NKS, int EPI>
-__global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
+// WPB = 8 (round 6): a workgroup = TWO neighbouring 64-column panels (eight waves, two per SIMD) walking the same run of tiles through the
+// same three LDS buffers: a tile's serial chain -- barrier, statistics, 40 dependent MFMAs behind LDS reads, barrier, epilogue -- is ~90 %
+// latency (0.27 us of MFMA per wave in 1.4-2.3 us per tile), so a second wave per SIMD fills it.  Per wave nothing changes: bit-identical.
+template <int NKS, int EPI, int WPB = 4>
+__global__ __launch_bounds__(64 * WPB) void gemm_dectall_f16(DecGemmArgs g)
 {
     constexpr bool E_LN = (EPI & DEC_LN) != 0, E_GELU = (EPI & DEC_GELU) != 0, E_RES = (EPI & DEC_RES) != 0,
                    E_QKV = (EPI & DEC_QKV) != 0, E_SLAB = (EPI & DEC_SLAB) != 0;
     constexpr int kslice = NKS * 32, SPR = kslice >> 3, RS = kslice * 2, TILE = 16 * RS;
-    constexpr int DMA_PER_WAVE = NKS / 4;          // 16 rows x SPR slots / 64 lanes = NKS instructions per tile, dealt over 4 waves
-    static_assert(NKS % 4 == 0, "tile = whole DMA instructions per wave");
+    constexpr int DMA_PER_WAVE = NKS / WPB;        // 16 rows x SPR slots / 64 lanes = NKS instructions per tile, dealt over the waves
+    static_assert(WPB == 4 || WPB == 8, "one or two panels per workgroup");
+    static_assert(NKS % WPB == 0, "tile = whole DMA instructions per wave");
     constexpr int NBUF = 3;                        // tile t computes while tiles t + 1 and t + 2 are on their way
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // NBUF x [16][kslice] f16 | float2 stat[NBUF][16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -361,9 +365,12 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int unit = (slot / g.n_rg) * 8 + xcd, rsplit = slot % g.n_rg;     // g.n_rg = row splits here
-    const int panels = (g.N + 63) >> 6;
+    constexpr int PW = WPB / 4;                                              // panels per workgroup
+    const int panels = ((g.N + 63) >> 6) / PW;                              // (WPB = 8: the launcher guarantees an even panel count)
     if (unit >= panels * g.ks2) return;
-    const int panel = unit / g.ks2, ks_id = unit - panel * g.ks2;
+    const int panel_u = unit / g.ks2, ks_id = unit - panel_u * g.ks2;
+    const int panel = panel_u * PW + (wave >> 2);
+    const int cw = wave & 3;                                                 // this wave's 16-column group of its panel
     const int k0 = ks_id * kslice;
     const int n_tiles = (g.M + 15) >> 4;
     const int t_begin = rsplit * g.tps;
@@ -374,7 +381,7 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
     auto stage = [&](int tile, int buf) {
 #pragma unroll
         for (int j = 0; j < DMA_PER_WAVE; ++j) {
-            const int q = j * 4 + wave_u;
+            const int q = j * WPB + wave_u;
             const int p = q * 64 + lane;
             const int row = p / SPR, ps = p - row * SPR;
             const int kslot = ps ^ (row & 15);
@@ -385,11 +392,11 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
     stage(t_begin, 0);
     stage(t_begin + 1 < t_end ? t_begin + 1 : t_begin, 1);
     // this wave's 16 columns of weights, resident for the whole run of tiles
-    const f16 *wp = g.W + ((size_t)(panel * 4 + wave) * (g.K >> 5) + (size_t)ks_id * NKS) * 512 + lane * 8;
+    const f16 *wp = g.W + ((size_t)(panel * 4 + cw) * (g.K >> 5) + (size_t)ks_id * NKS) * 512 + lane * 8;
     f16x8 wf[NKS];
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) wf[ks] = *(const f16x8 *)(wp + (size_t)ks * 512);
-    const int n = panel * 64 + wave * 16 + lg * 4;
+    const int n = panel * 64 + cw * 16 + lg * 4;
     const int nc = n < g.N ? n : g.N - 4;
     f32x4 c2 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (!E_SLAB) c2 = *(const f32x4 *)(g.c2 + nc);
@@ -423,22 +430,30 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
         stage(t + 2 < t_end ? t + 2 : t_end - 1, (t - t_begin + 2) % NBUF);    // (past the end: the last tile again, into the buffer
                                                                                //  tile t - 1 has left: never predicated, never read)
         const unsigned char *tile = smem + buf * TILE;
-        if constexpr (E_LN) {
+        if (E_LN && (WPB == 4 || wave_u < 4)) {            // (eight waves: the first four compute the 16 rows' statistics)
             const f16x2 one2 = {(f16)1.f, (f16)1.f};
             const int rb = wave * 4 + lg;                 // 16 lanes per row, one row per (wave, lane group)
             const unsigned char *rp = tile + (size_t)rb * RS + li * 16;
-            f16x8 v[SPR / 16];
-#pragma unroll
-            for (int i = 0; i < SPR / 16; ++i) v[i] = *(const f16x8 *)(rp + i * 256);
+            // (eight waves: the row's reads in batches of four -- 256 registers per wave; the sums keep their order)
+            constexpr int NV = SPR / 16, VB = WPB == 8 ? 4 : NV;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < SPR / 16; ++i)
+            for (int i0 = 0; i0 < NV; i0 += VB) {
+                f16x8 v[VB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const f16x2 pr = {v[i][2 * e], v[i][2 * e + 1]};
-                    s1 = __builtin_amdgcn_fdot2(pr, one2, s1, false);
-                    s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
-                }
+                for (int i = 0; i < VB; ++i) if (i0 + i < NV) v[i] = *(const f16x8 *)(rp + (i0 + i) * 256);
+#pragma unroll
+                for (int i = 0; i < VB; ++i)
+                    if (i0 + i < NV) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f16x2 pr = {v[i][2 * e], v[i][2 * e + 1]};
+                            s1 = __builtin_amdgcn_fdot2(pr, one2, s1, false);
+                            s2 = __builtin_amdgcn_fdot2(pr, pr, s2, false);
+                        }
+                    }
+                if (WPB == 8) __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int o = 0; o < 1; ++o) {        // 1, 2, 4, 8 in this order (DPP exchanges: swx_common.h)
                 s1 += lane_xor<1>(s1, lane); s2 += lane_xor<1>(s2, lane); s1 += lane_xor<2>(s1, lane); s2 += lane_xor<2>(s2, lane);
@@ -454,7 +469,7 @@ __global__ __launch_bounds__(256) void gemm_dectall_f16(DecGemmArgs g)
         }
         f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
         const unsigned char *abase = tile + (size_t)li * RS;
-        constexpr int PF = 8;                     // one MFMA per k-step here (16 cycles): eight fragment reads ahead cover the LDS latency
+        constexpr int PF = WPB == 8 ? 4 : 8;      // one MFMA per k-step here (16 cycles): eight fragment reads ahead cover the LDS latency (four with a second wave on the SIMD: 256 registers)
         f16x8 af[PF];
 #pragma unroll
         for (int ks = 0; ks < PF; ++ks) af[ks] = *(const f16x8 *)(abase + (((ks * 4 + lg) ^ li) << 4));
@@ -618,6 +633,10 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     if (use_tall) {
         // tall kernel: ~two rounds of the chip's 256 CUs, every workgroup a run of `tps` 16-row tiles
         const int n_tiles = cdiv(g.M, 16);
+        // eight waves = two panels per workgroup, from 40 (panel, K slice) units on (the un-split N = 1280 projections measured 27.4 vs 26.5 us
+        // that way: 10 double panels leave the row splits too short); bit-identical; SWX_FLAG_TALL_NO_W8: A/B
+        const bool w8 = !(swx_flags() & SWX_FLAG_TALL_NO_W8) && (g.N / 64) % 2 == 0 && nks % 8 == 0 && (g.N / 64) * ks2 >= 40;
+        const int units = w8 ? (g.N / 128) * ks2 : (g.N / 64) * ks2;
         int rs = 512 / (cdiv(units, 8) * 8);
         if (rs < 1) rs = 1;
         if (rs > n_tiles) rs = n_tiles;
@@ -634,10 +653,20 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
             attr_done = true; \
         } \
         hipLaunchKernelGGL((gemm_dectall_f16<NK_, EP_>), dim3(grid), dim3(256), lds, s, g); } while (0)
-#define SWX_TALL_NK(EP_) do { switch (nks) { \
+#define SWX_TALL8(NK_, EP_) do { \
+        static bool attr_done8 = false; \
+        if (!attr_done8) { \
+            hipError_t e_ = hipFuncSetAttribute((const void *)gemm_dectall_f16<NK_, EP_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024); \
+            if (e_ != hipSuccess) return -100 - (int)e_; \
+            attr_done8 = true; \
+        } \
+        hipLaunchKernelGGL((gemm_dectall_f16<NK_, EP_, 8>), dim3(grid), dim3(512), lds, s, g); } while (0)
+#define SWX_TALL_NK(EP_) do { if (w8) { switch (nks) { \
+        case 16: SWX_TALL8(16, EP_); break; case 24: SWX_TALL8(24, EP_); break; case 32: SWX_TALL8(32, EP_); break; case 40: SWX_TALL8(40, EP_); break; \
+        default: return -4; } } else { switch (nks) { \
         case 12: SWX_TALL(12, EP_); break; case 16: SWX_TALL(16, EP_); break; case 20: SWX_TALL(20, EP_); break; \
         case 24: SWX_TALL(24, EP_); break; case 32: SWX_TALL(32, EP_); break; case 40: SWX_TALL(40, EP_); break; \
-        default: return -4; } } while (0)
+        default: return -4; } } } while (0)
         switch (epi) {
             case DEC_LN | DEC_QKV: SWX_TALL_NK(DEC_LN | DEC_QKV); break;
             case DEC_RES: SWX_TALL_NK(DEC_RES); break;
@@ -647,6 +676,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
             default: return -4;
         }
 #undef SWX_TALL_NK
+#undef SWX_TALL8
 #undef SWX_TALL
     } else {
     const int grid = cdiv(units, 8) * g.n_rg * 8;

@@ -74,6 +74,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_QKV_SEPARATE_VT 268435456 // encoder at few windows: V transposed by its own launch instead of by the QKV projection's epilogue (A/B; bit-identical)
 #define SWX_FLAG_SELFATTN_NO_DEEP 4    // decode-step self-attention, long context at <= 1 024 waves: the chunk-by-chunk kernel instead of every load in two batches (A/B; bit-identical)
 #define SWX_FLAG_DEC_NO_W1 16           // decode-step GEMM at <= 80 workgroups: four-wave workgroups instead of single-wave ones (A/B; bit-identical)
+#define SWX_FLAG_TALL_NO_W8 32           // tall dec GEMM: four waves = one 64-column panel per workgroup (rounds 4-5) instead of eight waves = two panels (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

@@ -42,7 +42,7 @@ def main() -> int:
         pos0 = torch.randint(0, n_ctx - 8, (n_seq + 1,), generator=g).int().to(dev)
         scratch = torch.empty(N * K * 2 + 8 * N + 16 * M * N * 4 + 4096, dtype=torch.uint8, device=dev)
         outs = []
-        for flag in (0, TALL):
+        for flag in (0, TALL, "w4"):                # reference launch, tall kernel (eight waves per workgroup where the dispatch takes them), tall kernel with four waves always (flag 32)
             for rep in range(REPS if flag else 1):
                 c = torch.full((M, N if not (epi & DEC_QKV) else dd), float("nan"), dtype=torch.half, device=dev)
                 x = x0.clone()
@@ -51,7 +51,7 @@ def main() -> int:
                 # the regular launch scatters with rps = 0 (one token per row): give it the tall launch's row -> (sequence, token) map
                 # by running it tall-flagged too but below the tall threshold?  No: compare like with like -- both launches get bit 6
                 # (rps = 7); the kernel choice is forced by SWX_FLAG_NO_TALL instead.
-                lib.swx_debug_flags(0 if flag else 524288)
+                lib.swx_debug_flags(32 if flag == "w4" else 0 if flag else 524288)
                 rc = lib.swx_test_dec_gemm(p(a), K, p(w), p(gamma), p(beta), p(bias), p(c), c.shape[1], p(x), p(kc), p(vc), p(pos0),
                                            n_ctx, dd, M, N, K, epi | TALL, p(scratch), scratch.numel(), st)
                 torch.cuda.synchronize()
@@ -63,16 +63,18 @@ def main() -> int:
                     print(f"M={M} N={N} K={K} epi={epi}: tall kernel differs from its own previous run (rep {rep})")
                     bad += 1
                     break
-        (rc0, *t0), (rc1, *t1) = outs
+        (rc0, *t0), (rc1, *t1), (rc2, *t2) = outs
         names = ("C", "X", "kcache", "vcache")
-        same = rc0 == rc1 == 0 and all(torch.equal(u, v) or (torch.isnan(u) & torch.isnan(v) | (u == v)).all() for u, v in zip(t0, t1))
+        same = rc0 == rc1 == rc2 == 0 and all(torch.equal(u, v) or (torch.isnan(u) & torch.isnan(v) | (u == v)).all() for u, v in zip(t0, t1)) \
+            and all(torch.equal(u, v) or (torch.isnan(u) & torch.isnan(v) | (u == v)).all() for u, v in zip(t0, t2))
         touched = {n_: bool((~torch.isnan(u.float())).any() and (u.float().nan_to_num() != 0).any()) for n_, u in zip(names, t1)}
-        print(f"M={M:5d} N={N:5d} K={K:5d} epi={epi:2d}: rc {rc0} / {rc1}  bit-identical {bool(same)}  outputs written {touched}")
+        print(f"M={M:5d} N={N:5d} K={K:5d} epi={epi:2d}: rc {rc0} / {rc1} / {rc2} (reference / tall / tall, four waves)  bit-identical {bool(same)}  outputs written {touched}")
         if not same:
-            for n_, u, v in zip(names, t0, t1):
-                df = (u.float().nan_to_num() - v.float().nan_to_num()).abs()
-                if df.max() > 0:
-                    print(f"   {n_}: max |diff| {df.max().item():.4g} at {int((df > 0).sum())} elements")
+            for tag, tt in (("tall", t1), ("tall w4", t2)):
+                for n_, u, v in zip(names, t0, tt):
+                    df = (u.float().nan_to_num() - v.float().nan_to_num()).abs()
+                    if df.max() > 0:
+                        print(f"   {tag} {n_}: max |diff| {df.max().item():.4g} at {int((df > 0).sum())} elements")
             bad += 1
     print("FAILED" if bad else "all shapes bit-identical")
     return 1 if bad else 0

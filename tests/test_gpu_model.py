@@ -553,6 +553,41 @@ def test_decode_graph_replay_is_bit_identical(name, mode, sample_len):
     assert eng.graph_stats()["replays"] == st1["replays"]
 
 
+@pytest.mark.parametrize("name,beam,windows,prompt_len", [("tiny.en", False, 1, 223), ("base.en", True, 1, 223), ("base.en", True, 2, 150),
+                                                          ("tiny.en", True, 3, 0), ("base.en", False, 1, 0)])
+def test_decode_f16_few_workgroup_kernels_are_bit_identical(name, beam, windows, prompt_len):
+    # round 6: a decode of few rows -- the reference's sequential flow, one window per call, with up to 223 prompt tokens carried over
+    # (positions 226-340) -- runs its projections as SINGLE-wave workgroups (gemm_dec_f16<.., WPB = 1>, launches of <= 80 workgroups) and
+    # its long-context self-attention on the kernel that requests every load of a row in two batches (self_attn_step_long_f16, <= 1 024
+    # waves).  Flags 16 / 4 put the four-wave workgroups / the chunk-by-chunk kernel back: through the whole loop (prefill, captured
+    # step graph, beam bookkeeping) tokens, lengths, sums of log-probabilities and no-speech probabilities must be IDENTICAL.
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 117, B=windows)
+    o = dict(fp16=False, language="en", max_initial_timestamp=None, sample_len=40, beam_size=5 if beam else None)
+    if prompt_len:
+        o["prompt"] = list(range(1000, 1000 + prompt_len))
+    task = ost.DecodingTaskStable(m, DecodingOptions(**o))
+    kw = dict(n_group=task.n_group, beam=beam, sample_len=40, sot_index=task.sot_index, min_tokens=40, **_tok_cfg(task.tokenizer, task))
+    xkv = eng.cross_kv(eng.encode(mels.cuda().contiguous()))
+    init = [list(task.initial_tokens)] * windows
+    old = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(old & ~(4 | 16))
+        new1 = eng.decode(xkv, init, **kw)
+        lib.swx_debug_flags(old | 4 | 16)
+        ref = eng.decode(xkv, init, **kw)
+        lib.swx_debug_flags((old & ~4) | 16)
+        new2 = eng.decode(xkv, init, **kw)
+    finally:
+        lib.swx_debug_flags(old)
+    assert int(np.asarray(ref["lens"]).max()) > 8
+    for got in (new1, new2):
+        for key in ("lens", "tokens", "sum_logprobs", "no_speech_prob"):
+            assert np.array_equal(np.asarray(got[key]), np.asarray(ref[key])), key
+
+
 @pytest.mark.parametrize("name,heads", [("tiny.en", HEADS_TINY), ("base.en", None)])
 def test_score_alignment_dtw_strict(name, heads):
     m, eng = _oracle(name, heads=heads), _engine(name, "f32", heads=heads)
