@@ -296,6 +296,13 @@ int swx_test_attention(int dtype, const void *d_q, int64_t ldq, const void *d_k,
 int swx_test_self_attn_step(const void *d_q, void *d_kcache, void *d_vcache, const int32_t *d_anc, const int32_t *d_pos0,
                             int R, int H, int n_ctx, int d, int variant, void *d_o, void *stream);
 
+/* multi-token self-attention of a teacher-forced pass (f16, no ancestor table, every row starts at position 0): mq = 0 the kernel
+ * with one wave per (row, token, head) reading K / V from memory, mq = 1 several tokens of a (row, head) per workgroup with K / V
+ * staged in LDS once (round 6; bit-identical).  d_q [R * n_new][d] (row stride d); caches [R][n_ctx][d] holding the tokens' K / V at
+ * positions 0 .. n_new - 1; d_o [R * n_new][d].  Nothing in the reference corresponds to it. */
+int swx_test_self_attn_multi(const void *d_q, void *d_kcache, void *d_vcache, int R, int H, int n_new, int n_ctx, int d, int mq,
+                             void *d_o, void *stream);
+
 /* the VALU lane-exchange helpers of csrc/swx_common.h (v_permlane16/32_swap, DPP) against __shfl_xor, on n_waves waves of 64
  * u32 values: d_out[((w * 13 + k) * 64) + lane], k = 0..5 lane_xor<32, 16, 8, 4, 2, 1>, k = 6..11 the __shfl_xor of the same
  * offsets, k = 12 a bit mask of the derived forms that agreed with their shuffle form (1 wave_sum_d, 2 / 4 lane_xor16_max / 32_max,

@@ -98,6 +98,7 @@ SYMBOLS = {
                                   c_void_p]),
     "swx_test_self_attn_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p]),
+    "swx_test_self_attn_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "swx_test_gelu_pair": (c_int, [c_void_p, c_void_p]),
     "swx_test_lane_xor": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "swx_test_layernorm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -720,8 +720,10 @@ __global__ __launch_bounds__(256, 2) void attn_decode_cross_xq_f16(AttnArgs a) {
 // SWX_FLAG_XATTN_R5 keeps the one-block loop above as its bit-identity reference
 template <int FQ>
 __global__ __launch_bounds__(256, 2) void attn_decode_cross_xq2_f16(AttnArgs a) { attn_decode_cross_body<true, 1, FQ, 1>(a); }
+// (QG = 4: two workgroups per CU -- the four-group form of a many-window scoring pass compiled to 280 registers = ONE workgroup = one wave per SIMD = 64 KB
+// in flight per CU without the bound; held to 256 it has 234, no spill: 98 -> 68 us per layer of the 20-window scoring pass, profiles/r06_c34_*)
 template <bool PACKED, int QG>
-__global__ __launch_bounds__(256) void attn_decode_cross2_f16(AttnArgs a) { attn_decode_cross_body<PACKED, QG, 0, 1>(a); }
+__global__ __launch_bounds__(256, QG == 4 ? 2 : 1) void attn_decode_cross2_f16(AttnArgs a) { attn_decode_cross_body<PACKED, QG, 0, 1>(a); }
 
 // ================================================================================================ flash f32 (round 5)
 // Strict-f32 mode on the exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32: f32 operands, f32 accumulate).  Until round 5 every
@@ -1109,6 +1111,82 @@ __global__ __launch_bounds__(64) void self_attn_cached(SelfAttnArgs a, int row_m
         T *op = (T *)a.o + ((size_t)ri * a.n_new + i) * a.ldo + h * DH + dc;
 #pragma unroll
         for (int e = 0; e < 8; ++e) op[e] = from_f32<T>(acc[e]);
+    }
+}
+
+// ------------------------------------------------------------------ multi-token self-attention, several tokens per workgroup (round 6)
+// self_attn_cached gives every (row, token, head) its own wave, which reads positions 0 .. pos of the head's K and V from L2 again: a 113-token
+// scoring pass moves 655 MB per layer through the L1s for 11.6 MB of cache (80 us per layer at 20 windows).  Here a workgroup of NQW waves takes NQW
+// CONSECUTIVE tokens of one (row, head): the K and V rows up to its last token's position are staged in LDS ONCE (rows padded to 144 B: a quarter
+// wave's 16-byte reads fall on 64 different banks) and every wave runs self_attn_cached's arithmetic on its own token from there -- per score the
+// same fmaf chain over d, the same expf, per output element the same key order per lane group and the same lane reduction: bit-identical
+// (tests/test_gpu_kernels.py).  f16, no ancestor table, rows that start at position 0 (teacher-forced passes and prefills: the host knows it).
+template <int NQW>
+__global__ __launch_bounds__(64 * NQW) void self_attn_cached_mq_f16(SelfAttnArgs a, int row_mul, int lds_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char mq_smem[];   // K [lds_rows][72] | V [lds_rows][72] f16 | qs [NQW][64] | ps [NQW][lds_rows] f32
+    constexpr int LD = 72;
+    f16 *Ks = (f16 *)mq_smem, *Vs = Ks + (size_t)lds_rows * LD;
+    float *qs_all = (float *)(Vs + (size_t)lds_rows * LD), *ps_all = qs_all + NQW * DH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = blockIdx.x * NQW, h = blockIdx.y, ri = blockIdx.z;
+    const int r = ri * row_mul;
+    const int i_last = (i0 + NQW < a.n_new ? i0 + NQW : a.n_new) - 1;       // rows start at position 0: token i attends to positions 0 .. i
+    {
+        const f16 *kg_ = (const f16 *)a.kcache + (size_t)r * a.n_ctx * a.d + h * DH;
+        const f16 *vg_ = (const f16 *)a.vcache + (size_t)r * a.n_ctx * a.d + h * DH;
+        for (int c = tid; c < (i_last + 1) * 8; c += 64 * NQW) {
+            const int j = c >> 3, c8 = (c & 7) * 8;
+            *(f16x8 *)(Ks + j * LD + c8) = *(const f16x8 *)(kg_ + (size_t)j * a.d + c8);
+            *(f16x8 *)(Vs + j * LD + c8) = *(const f16x8 *)(vg_ + (size_t)j * a.d + c8);
+        }
+    }
+    const bool live = i0 + wave < a.n_new;
+    const int i = live ? i0 + wave : a.n_new - 1;      // a wave past the last token repeats it (every wave reaches the barriers) and stores nothing
+    const int pos = i;
+    float *qs = qs_all + wave * DH, *ps = ps_all + (size_t)wave * lds_rows;
+    qs[lane] = (float)((const f16 *)a.qkv)[((size_t)ri * a.n_new + i) * a.ldqkv + h * DH + lane];
+    __syncthreads();
+    float mx = -__builtin_inff();
+    for (int j = lane; j <= pos; j += 64) {
+        const f16 *kr = Ks + j * LD;
+        float acc = 0.f;
+#pragma unroll 2
+        for (int d0 = 0; d0 < DH; d0 += 8) {
+            const f16x8 t = *(const f16x8 *)(kr + d0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qs[d0 + e], (float)t[e], acc);
+        }
+        acc *= 0.125f;
+        ps[j] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j <= pos; j += 64) { const float e = expf(ps[j] - mx); ps[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    __syncthreads();
+    const float inv = 1.0f / sum;
+    const int kg = lane >> 3, dc = (lane & 7) * 8;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int j = kg; j <= pos; j += 8) {
+        const f16x8 t = *(const f16x8 *)(Vs + j * LD + dc);
+        const float pj = ps[j] * inv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = fmaf(pj, (float)t[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        acc[e] += lane_xor<8>(acc[e], lane);
+        acc[e] = lane_xor16_add(acc[e]);
+        acc[e] = lane_xor32_add(acc[e]);
+    }
+    if (kg == 0 && live) {
+        f16 *op = (f16 *)a.o + ((size_t)ri * a.n_new + i) * a.ldo + h * DH + dc;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) op[e] = (f16)acc[e];
     }
 }
 
@@ -1716,6 +1794,32 @@ int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_
     dim3 g2(a.n_new, a.H, a.R);
     if (dtype == SWX_F16) {
         if (!a.skip_append) hipLaunchKernelGGL(kv_append_kernel<f16>, g1, dim3(256), 0, s, a, row_mul);
+        // several tokens of a (row, head) per workgroup, K / V staged in LDS once (bit-identical; SWX_FLAG_SELFATTN_NO_MQ: A/B)
+        if (a.pos0_all_zero && !a.anc && a.n_new >= 8 && a.n_new <= a.n_ctx && !(swx_flags() & SWX_FLAG_SELFATTN_NO_MQ)) {
+            const int nqw = a.n_new >= 32 ? 8 : 4;
+            const int lds_rows = ((a.n_new + 7) / 8) * 8;
+            const size_t lds = (size_t)lds_rows * 72 * 2 * 2 + (size_t)nqw * 64 * 4 + (size_t)nqw * lds_rows * 4;
+            dim3 gq(cdiv(a.n_new, nqw), a.H, a.R);
+            if (nqw == 8) {
+                static bool attr8 = false;
+                if (!attr8) {
+                    hipError_t e_ = hipFuncSetAttribute((const void *)self_attn_cached_mq_f16<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+                    if (e_ != hipSuccess) return -100 - (int)e_;
+                    attr8 = true;
+                }
+                hipLaunchKernelGGL(self_attn_cached_mq_f16<8>, gq, dim3(512), lds, s, a, row_mul, lds_rows);
+            } else {
+                static bool attr4 = false;
+                if (!attr4) {
+                    hipError_t e_ = hipFuncSetAttribute((const void *)self_attn_cached_mq_f16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+                    if (e_ != hipSuccess) return -100 - (int)e_;
+                    attr4 = true;
+                }
+                hipLaunchKernelGGL(self_attn_cached_mq_f16<4>, gq, dim3(256), lds, s, a, row_mul, lds_rows);
+            }
+            SWX_CHECK_LAUNCH();
+            return 0;
+        }
         hipLaunchKernelGGL(self_attn_cached<f16>, g2, dim3(64), 0, s, a, row_mul);
     } else {
         if (!a.skip_append) hipLaunchKernelGGL(kv_append_kernel<float>, g1, dim3(256), 0, s, a, row_mul);

@@ -75,6 +75,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_SELFATTN_NO_DEEP 4    // decode-step self-attention, long context at <= 1 024 waves: the chunk-by-chunk kernel instead of every load in two batches (A/B; bit-identical)
 #define SWX_FLAG_DEC_NO_W1 16           // decode-step GEMM at <= 80 workgroups: four-wave workgroups instead of single-wave ones (A/B; bit-identical)
 #define SWX_FLAG_TALL_NO_W8 32           // tall dec GEMM: four waves = one 64-column panel per workgroup (rounds 4-5) instead of eight waves = two panels (A/B; bit-identical)
+#define SWX_FLAG_SELFATTN_NO_MQ 256       // multi-token self-attention: one wave per (row, token, head) reading K / V from L2 (rounds 1-5) instead of 4-8 tokens per workgroup from LDS (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
@@ -198,6 +199,8 @@ struct SelfAttnArgs {
     int step_pos;                    // profiler only: position of the new token when the host knows it (decode loop), else 0
     int pos_bound;                   // decode step: an upper bound of every row's position known to the host (initial tokens + sample
                                      // budget), or 0 = unknown.  <= 128: the kernel variant without the code for positions >= 128
+    int pos0_all_zero;               // multi-token pass: the host knows that every row starts at position 0 (a.pos0 is the zeros array):
+                                     // several tokens of a (row, head) per workgroup with K / V staged in LDS (self_attn_cached_mq_f16)
 };
 // logical row of grid index ri is ri * row_mul (prefill of beam groups computes one row per window)
 int swx_self_attention(int dtype, const SelfAttnArgs &a, int row_mul, hipStream_t s);

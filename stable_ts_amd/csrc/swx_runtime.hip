@@ -488,6 +488,7 @@ int decoder_forward_dec(swx_model *m, const FwdCfg &f, hipStream_t s)
         SelfAttnArgs sa{};
         sa.qkv = q; sa.ldqkv = d; sa.kcache = kc; sa.vcache = vc; sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = R; sa.n_new = f.n_new; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d; sa.skip_append = 1;
+        sa.pos0_all_zero = f.pos0 == m->Wp<int32_t>(m->L.zeros_i32) ? 1 : 0;
         SWX_TRY(swx_self_attention(m->dtype, sa, f.row_mul, s));
         g = DecGemmArgs{};
         g.M = rows; g.tall = 1; g.A = att; g.lda = d; g.W = m->A<f16>(w.wo_p); g.ldw = d; g.N = d; g.K = d; g.epi = DEC_RES;
@@ -569,6 +570,7 @@ int decoder_forward(swx_model *m, const FwdCfg &f, hipStream_t s)
         sa.vcache = f.vcache + (size_t)l * f.layer_stride;
         sa.anc = f.anc; sa.pos0 = f.pos0; sa.o = att; sa.ldo = d;
         sa.R = R; sa.n_new = f.n_new; sa.H = H; sa.n_ctx = D.n_text_ctx; sa.d = d;
+        sa.pos0_all_zero = f.pos0 == m->Wp<int32_t>(m->L.zeros_i32) ? 1 : 0;
         SWX_TRY(swx_self_attention(m->dtype, sa, f.row_mul, s));
         SWX_TRY(gemm_residual(m, att, d, w.wo, w.bo, x, d, rows, d, d, s));
         // cross attention
@@ -1622,6 +1624,27 @@ int swx_test_self_attn_step(const void *d_q, void *d_kcache, void *d_vcache, con
     sa.o = d_o; sa.ldo = d; sa.R = R; sa.n_new = 1; sa.H = H; sa.n_ctx = n_ctx; sa.d = d; sa.skip_append = 1;
     sa.step_cached = variant < 2 ? 1 : 0;
     sa.pos_bound = variant == 0 ? 128 : 0;
+    return swx_self_attention(SWX_F16, sa, 1, S(stream));
+}
+
+int swx_test_self_attn_multi(const void *d_q, void *d_kcache, void *d_vcache, int R, int H, int n_new, int n_ctx, int d, int mq,
+                             void *d_o, void *stream)
+{
+    static int32_t *d_zeros = nullptr;           // every row starts at position 0
+    static int zeros_n = 0;
+    if (R <= 0 || n_new <= 0 || n_new > n_ctx) return -2;
+    if (zeros_n < R) {
+        if (d_zeros) (void)hipFree(d_zeros);
+        zeros_n = 0; d_zeros = nullptr;
+        if (hipMalloc((void **)&d_zeros, (size_t)R * 4) != hipSuccess) return -3;
+        zeros_n = R;
+    }
+    hipError_t e = hipMemsetAsync(d_zeros, 0, (size_t)R * 4, S(stream));
+    if (e != hipSuccess) return -100 - (int)e;
+    SelfAttnArgs sa{};
+    sa.qkv = d_q; sa.ldqkv = d; sa.kcache = d_kcache; sa.vcache = d_vcache; sa.anc = nullptr; sa.pos0 = d_zeros;
+    sa.o = d_o; sa.ldo = d; sa.R = R; sa.n_new = n_new; sa.H = H; sa.n_ctx = n_ctx; sa.d = d; sa.skip_append = 1;
+    sa.pos0_all_zero = mq ? 1 : 0;
     return swx_self_attention(SWX_F16, sa, 1, S(stream));
 }
 

@@ -382,6 +382,36 @@ def test_attention_f32_mfma_edges(B, H, nq, nk):
         assert (o.cpu() - o1.cpu()).abs().max().item() < 3e-5, kp
 
 
+@pytest.mark.parametrize("R,H,d,n_new", [(20, 20, 1280, 113), (3, 6, 384, 8), (1, 8, 512, 33), (5, 20, 1280, 226), (2, 6, 384, 448),
+                                         (7, 8, 512, 31), (120, 20, 1280, 64)])
+def test_self_attention_several_tokens_per_workgroup_is_bit_identical(R, H, d, n_new):
+    # round 6: the multi-token self-attention of a teacher-forced pass (scoring pass, prefill: every row starts at position 0) takes 4-8
+    # consecutive tokens of a (row, head) per workgroup and stages the head's K / V rows in LDS once (self_attn_cached_mq_f16) instead of one
+    # wave per (row, token, head) reading them from L2 again (self_attn_cached): the same arithmetic per token -- equal bits, for token
+    # counts with and without a tail, up to the whole context
+    import ctypes
+    lib = _lib()
+    n_ctx = 448
+    g = torch.Generator().manual_seed(R * 1000 + n_new)
+    q = (torch.randn(R * n_new, d, generator=g) * 0.8).half().cuda()
+    kc = torch.zeros(R, n_ctx, d, dtype=torch.half)
+    vc = torch.zeros(R, n_ctx, d, dtype=torch.half)
+    kc[:, :n_new] = (torch.randn(R, n_new, d, generator=g) * 0.8).half()
+    vc[:, :n_new] = torch.randn(R, n_new, d, generator=g).half()
+    kc, vc = kc.cuda(), vc.cuda()
+    outs = []
+    for mq in (0, 1, 1):
+        o = torch.full((R * n_new, d), float("nan"), dtype=torch.half, device="cuda")
+        rc = lib.swx_test_self_attn_multi(_p(q), _p(kc), _p(vc), R, H, n_new, n_ctx, d, mq, _p(o), _stream())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert not torch.isnan(outs[0]).any() and float(outs[0].float().abs().max()) > 0
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # ... and it is an attention: token 0 attends to position 0 only = V[0] of its head, for every head
+    assert torch.equal(outs[0].view(R, n_new, d)[:, 0], vc[:, 0])
+
+
 @pytest.mark.parametrize("check", ["gemm_glds_check.py", "gemm_big8_check.py", "mel_ragged_check.py", "score_qk_check.py",
                                    "self_attn_step_check.py"])
 def test_new_kernel_paths_in_subprocess(check):
