@@ -1688,15 +1688,21 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         // workgroup for every CU that way (at one window 64 queries per wave are 6 x 20 = 120 workgroups), 32 otherwise;
         // force_kernel 4 / 6 / 5 pin 32 / 48 / 64 (scripts/kernel_bench.py --flash-kernel, --only flash_small)
         const bool wide_fills = (int64_t)a.B * a.H * cdiv(a.nq, 256) >= 256;
-        const int qb = !a.vt_kp ? 2 : force_kernel == 4 ? 2 : force_kernel == 6 ? 3 : (force_kernel == 5 || (a.nq >= 1024 && wide_fills)) ? 4 : 2;
+        // ... and 16 while 32 per wave would leave the launch at one workgroup per CU or less (the encoder of ONE window: 12 x 20 = 240 workgroups
+        // = one wave per SIMD on a kernel whose softmax and MFMA stretches want a second wave to fill them; 24 x 20 = 480 that way).  A
+        // query block's arithmetic does not depend on how many blocks its wave carries: bit-identical (SWX_FLAG_FLASH_NO_QB1: A/B)
+        const bool narrow_fills = a.vt_kp && force_kernel == 0 && a.nq >= 256 && (int64_t)a.B * a.H * cdiv(a.nq, 128) <= 256 &&
+                                  !(swx_flags() & SWX_FLAG_FLASH_NO_QB1);
+        const int qb = !a.vt_kp ? 2 : narrow_fills ? 1 : force_kernel == 4 ? 2 : force_kernel == 6 ? 3 : (force_kernel == 5 || (a.nq >= 1024 && wide_fills)) ? 4 : 2;
         dim3 g(cdiv(a.nq, 64 * qb), a.H, a.B);
         const bool gen3 = a.vt_kp && (swx_flags() & SWX_FLAG_FLASH_PIPELINED);  // round 6's software-pipelined tile: bit-identical, slower (A/B only)
         if (!a.vt_kp) hipLaunchKernelGGL((attn_flash2_f16<false, 2>), g, dim3(256), 0, s, a);
         else if (gen3 && qb == 4) hipLaunchKernelGGL((attn_flash3_f16<4>), g, dim3(256), 0, s, a);
         else if (gen3 && qb == 3) hipLaunchKernelGGL((attn_flash3_f16<3>), g, dim3(256), 0, s, a);
-        else if (gen3) hipLaunchKernelGGL((attn_flash3_f16<2>), g, dim3(256), 0, s, a);
+        else if (gen3 && qb == 2) hipLaunchKernelGGL((attn_flash3_f16<2>), g, dim3(256), 0, s, a);
         else if (qb == 4) hipLaunchKernelGGL((attn_flash2_f16<true, 4>), g, dim3(256), 0, s, a);
         else if (qb == 3) hipLaunchKernelGGL((attn_flash2_f16<true, 3>), g, dim3(256), 0, s, a);
+        else if (qb == 1) hipLaunchKernelGGL((attn_flash2_f16<true, 1>), g, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((attn_flash2_f16<true, 2>), g, dim3(256), 0, s, a);
     } else if (dtype == SWX_F32 && (force_kernel == 0 || force_kernel == 7) && a.vt_kp % F32_KT == 0 &&
                // a transposed V is read as V[d][kt0 .. kt0 + 63] for every key tile: its row pitch must cover the padded key axis

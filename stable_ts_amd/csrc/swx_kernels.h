@@ -76,6 +76,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_DEC_NO_W1 16           // decode-step GEMM at <= 80 workgroups: four-wave workgroups instead of single-wave ones (A/B; bit-identical)
 #define SWX_FLAG_TALL_NO_W8 32           // tall dec GEMM: four waves = one 64-column panel per workgroup (rounds 4-5) instead of eight waves = two panels (A/B; bit-identical)
 #define SWX_FLAG_SELFATTN_NO_MQ 256       // multi-token self-attention: one wave per (row, token, head) reading K / V from L2 (rounds 1-5) instead of 4-8 tokens per workgroup from LDS (A/B; bit-identical)
+#define SWX_FLAG_FLASH_NO_QB1 64           // f16 flash attention of launches with <= 256 workgroups at 32 queries per wave: 32 queries per wave (rounds 3-5) instead of 16 (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

@@ -345,6 +345,31 @@ def test_flash3_is_bit_identical_to_flash2(B, H, nq, nk):
         lib.swx_debug_flags(old)
 
 
+@pytest.mark.parametrize("B,H,nq,nk", [(1, 20, 1500, 1500), (1, 6, 1500, 1500), (2, 4, 300, 128), (1, 2, 257, 1472), (1, 8, 1500, 1500)])
+def test_flash_16_queries_per_wave_is_bit_identical(B, H, nq, nk):
+    # round 6: launches that 32 queries per wave would leave at one workgroup per CU or less (the encoder of ONE window: 240 workgroups)
+    # run 16 queries per wave (attn_flash2_f16<true, 1>: twice the workgroups, a second wave per SIMD); flag 64 =
+    # SWX_FLAG_FLASH_NO_QB1 puts 32 back.  A query block's arithmetic does not depend on its wave's other blocks: equal bits.
+    lib = _lib()
+    g = torch.Generator().manual_seed(B * 31 + H + nq + nk)
+    q = (torch.randn(B, nq, H * 64, generator=g) * 1.5).half().cuda()
+    k = torch.randn(B, nk, H * 64, generator=g).half().cuda()
+    v = torch.randn(B, nk, H * 64, generator=g).half().cuda()
+    kp = ((nk + 63) // 64) * 64 if nk > 1000 else 1536
+    old = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(old | 64)
+        ref = _attn(1, q, k, v, 0, kp).clone()
+        lib.swx_debug_flags(old & ~64)
+        got = _attn(1, q, k, v, 0, kp)
+    finally:
+        lib.swx_debug_flags(old)
+    assert torch.isfinite(got.float()).all()
+    assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (ref.float() - got.float()).abs().max().item()
+    err = (got.cpu().double() - _attn_ref(q.cpu(), k.cpu(), v.cpu())).abs().max().item()
+    assert err < 8e-3, err
+
+
 @pytest.mark.parametrize("B,H,nq,nk", [(1, 1, 1, 1500), (3, 4, 5, 1500), (2, 2, 16, 1500), (1, 3, 7, 333)])
 def test_attention_decode_cross_kernel(B, H, nq, nk):
     # the HBM-streaming decode-step kernel (<=16 queries, transposed V) vs f64 reference; fp16 P rounding: 6e-3
