@@ -53,6 +53,24 @@ constexpr int CLD = BN + 4;                 // f32 staging row of the epilogue
 // 8 columns for every row group of a thread) and the residual rows of a half are requested BEFORE the accumulators are
 // staged: loaded per row group after the previous group's store (a store through a f16 pointer may alias the f32 bias, so
 // hipcc keeps the order) they were eight dependent L2 round trips per tile -- 43 % of a K = 1280 launch (see below).
+// EPI_KV with GemmArgs::P (round 6): the decode-step cross-attention's fragment-ordered copy (swx_attn.hip::xkv_pack_kernel's index maps)
+// written from the projection's epilogue.  K: the 16-byte piece (key, head, dims 8 c .. 8 c + 7) is lane (g = c & 3, qn) of fragment 2 t + (c >> 2)
+// of the key's 32-key block, key % 32 = (qn >> 2) * 8 + 4 t + (qn & 3).  V^T: the 8-byte piece (4 keys from key0 = a multiple of 4, head, dim) is
+// half (key0 % 8) / 4 of lane (g = (key0 % 32) / 8, qn = dim % 16) of fragment dim / 16.  Keys [vt_s, p_nkpad) of a head are zeros.
+__device__ __forceinline__ f16 *xkv_packed_k_piece(const GemmArgs &g, int wb, int key, int col)
+{
+    const int h = col >> 6, c = (col & 63) >> 3, kq = key & 31;
+    const int frag = (((kq >> 2) & 1) << 1) + (c >> 2), lane_ = (c & 3) * 16 + (kq >> 3) * 4 + (kq & 3);
+    return (f16 *)g.P + (size_t)wb * g.p_bs + (size_t)h * swx_xkv_packed_elems_per_head(g.vt_s) + ((size_t)(key >> 5) * 4 + frag) * 512 + lane_ * 8;
+}
+__device__ __forceinline__ f16 *xkv_packed_v_piece(const GemmArgs &g, int wb, int key0, int vcol)
+{
+    const int h = vcol >> 6, dd = vcol & 63, kq = key0 & 31;
+    const int64_t per_head = swx_xkv_packed_elems_per_head(g.vt_s);
+    return (f16 *)g.P + (size_t)wb * g.p_bs + (size_t)h * per_head + per_head / 2 + ((size_t)(key0 >> 5) * 4 + (dd >> 4)) * 512 +
+           ((kq >> 3) * 16 + (dd & 15)) * 8 + ((kq & 7) >> 2) * 4;
+}
+
 template <int NJ>      // NJ 16-column fragments per wave: tile width BNT = 32 NJ (128 or 64 columns)
 __device__ __forceinline__ void tile_epilogue_f16_one(const GemmArgs &g, unsigned char *smem, f32x4 (&acc)[4][NJ], int m0, int n0,
                                                          int tid, int lane, int wm, int wn)
@@ -98,6 +116,13 @@ __device__ __forceinline__ void tile_epilogue_f16_one(const GemmArgs &g, unsigne
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = (f16)(Cv[rg * 4 + r][col] + b);
                     *(f16x4 *)(cbase + (size_t)gn * g.vt_kp) = o;
+                    if (g.P) {                                          // ... and the fragment-ordered copy (with its zeroed key padding)
+                        *(f16x4 *)xkv_packed_v_piece(g, wb, sidx, gn - g.p_vcol0) = o;
+                        if (sidx + 4 == g.vt_s) {
+                            const f16x4 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                            for (int kz = g.vt_s; kz < g.p_nkpad; kz += 4) *(f16x4 *)xkv_packed_v_piece(g, wb, kz, gn - g.p_vcol0) = z;
+                        }
+                    }
                     if (g.vt_zero_pad && sidx + 4 == g.vt_s) {          // the row group that ends a batch item: its columns' key padding
                         const f16x4 z = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
                         for (int zp = 4; sidx + zp < g.vt_kp; zp += 4) *(f16x4 *)(cbase + (size_t)gn * g.vt_kp + zp) = z;
@@ -175,6 +200,12 @@ __device__ __forceinline__ void tile_epilogue_f16_one(const GemmArgs &g, unsigne
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
                 *(f16x8 *)cp = o;
+                if (g.P && (g.epi & EPI_CBATCH)) {                      // K of the cross-attention: ... and the fragment-ordered copy
+                    const int wb = gm / g.vt_s, key = gm - wb * g.vt_s;
+                    *(f16x8 *)xkv_packed_k_piece(g, wb, key, gn) = o;
+                    if (key + 1 == g.vt_s)
+                        for (int kz = g.vt_s; kz < g.p_nkpad; ++kz) *(f16x8 *)xkv_packed_k_piece(g, wb, kz, gn) = (f16x8)(f16)0;
+                }
             } else {
                 for (int e = 0; e < 8 && gn + e < g.N; ++e) {
                     float t = v[e];

@@ -27,6 +27,9 @@ struct GemmArgs {
     const float *Rf; int res_mod;   // f32 residual [res_mod][N], row index = m % res_mod
     void *C; int64_t ldc;           // compute dtype, or f32 with EPI_OUT_F32
     void *C2;                       // EPI_KV: base of the transposed half
+    void *P; int64_t p_bs;          // EPI_KV, optional (round 6): the fragment-ordered copy of K / V^T the decode-step cross-attention streams
+    int p_nkpad, p_vcol0;           // (swx_xkv_packed_elems_per_head) written by the same epilogue instead of by swx_xkv_pack: base of batch item
+                                    // 0, batch stride in elements, keys per head rounded up to 32 (the padding keys are zeroed), first V column
     int M, N, K;
     int epi;
     int vt_s, vt_kp; int64_t vt_bs;   // EPI_STORE_VT: rows per batch item, padded key stride, element stride between batch items
@@ -77,6 +80,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_TALL_NO_W8 32           // tall dec GEMM: four waves = one 64-column panel per workgroup (rounds 4-5) instead of eight waves = two panels (A/B; bit-identical)
 #define SWX_FLAG_SELFATTN_NO_MQ 256       // multi-token self-attention: one wave per (row, token, head) reading K / V from L2 (rounds 1-5) instead of 4-8 tokens per workgroup from LDS (A/B; bit-identical)
 #define SWX_FLAG_FLASH_NO_QB1 64           // f16 flash attention of launches with <= 256 workgroups at 32 queries per wave: 32 queries per wave (rounds 3-5) instead of 16 (A/B; bit-identical)
+#define SWX_FLAG_XKV_PACK_SEPARATE 128     // cross-K/V: the fragment-ordered copy by its own launch (swx_xkv_pack, rounds 2-5) instead of by the projection's epilogue (A/B; the same bytes)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();

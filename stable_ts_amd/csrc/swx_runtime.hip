@@ -1111,12 +1111,18 @@ int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *strea
         const LayerW &w = m->dec[l];
         unsigned char *base = (unsigned char *)d_xkv + (size_t)l * B * chunk * e;
         const bool one_launch = m->dtype == SWX_F16 && d % 128 == 0 && (int64_t)B * S_ > 128 && !(g_debug_flags & SWX_FLAG_XKV_TWO_LAUNCHES);
+        bool packed_by_epilogue = false;
         if (one_launch) {
             // round 6: K and V of the layer from ONE launch over the fused weight rows [2d][d] (EPI_KV: a tile left of column d stores
             // K rows per window, a tile right of it V transposed per head) -- at one window 240 tiles of 128 x 128 on the ring kernel
             // instead of two launches of 240 tiles of 128 x 64; per element the same MFMA sequence, so bit-identical
             GemmArgs gkv = gemm_args(d_xa, d, m->arena + w.wckv, d, m->A<float>(w.bckv), base, d, B * S_, 2 * d, d, EPI_BIAS | EPI_KV);
             gkv.vt_s = S_; gkv.vt_kp = SWX_VT_KP; gkv.vt_bs = chunk; gkv.C2 = base + (size_t)S_ * d * e;
+            if (!(g_debug_flags & SWX_FLAG_XKV_PACK_SEPARATE)) {
+                // ... and the fragment-ordered copy from the same epilogue (round 6: swx_xkv_pack read and wrote the layer's K / V^T once more)
+                gkv.P = base + (size_t)xkv_plain_elems(D) * e; gkv.p_bs = chunk; gkv.p_nkpad = ((S_ + 31) / 32) * 32; gkv.p_vcol0 = d;
+                packed_by_epilogue = true;
+            }
             SWX_TRY(swx_gemm(m->dtype, gkv, 0, s));
         } else {
         // K (no bias upstream; the fused bias slot is zero): one GEMM over all windows, rows scattered per window chunk
@@ -1129,7 +1135,7 @@ int swx_cross_kv(swx_model *m, const void *d_xa, int B, void *d_xkv, void *strea
         gv.vt_s = S_; gv.vt_kp = SWX_VT_KP; gv.vt_bs = chunk;
         SWX_TRY(swx_gemm(m->dtype, gv, 0, s));
         }
-        if (m->dtype == SWX_F16)      // the decode-step cross-attention streams the fragment-ordered copy
+        if (m->dtype == SWX_F16 && !packed_by_epilogue)      // the decode-step cross-attention streams the fragment-ordered copy
             SWX_TRY(swx_xkv_pack(base, base + (size_t)S_ * d * e, base + (size_t)xkv_plain_elems(D) * e, B, D.n_text_head, S_, d,
                                  SWX_VT_KP, chunk, s));
     }

@@ -418,6 +418,32 @@ def test_decode_f16_cross_attention_two_blocks_in_flight_is_bit_identical(name, 
     assert p1 == p2 and torch.equal(n1, n2)
 
 
+@pytest.mark.parametrize("name,windows", [("tiny.en", 1), ("base.en", 1), ("base.en", 3), ("tiny.en", 7)])
+def test_cross_kv_fragment_ordered_copy_from_the_projection_epilogue_is_the_same_bytes(name, windows):
+    # round 6: the fragment-ordered copy of a layer's cross-attention K / V^T (what the decode-step cross-attention streams) is written by
+    # the K | V projection's own epilogue (GemmArgs::P) instead of by a launch that reads K / V^T again (swx_xkv_pack; flag 128 =
+    # SWX_FLAG_XKV_PACK_SEPARATE): the WHOLE cross-K/V buffer -- row-layout K, V^T with its zeroed key padding, the packed copy with its
+    # zeroed padding keys -- must hold the same bytes, twice in a row (a second call must not depend on what the first one left behind)
+    from stable_ts_amd import _lib
+    lib = _lib.load()
+    m, eng = _oracle(name), _engine(name, "f16")
+    mels = _mel(m.dims.n_mels, 131, B=windows).cuda().contiguous()
+    xa = eng.encode(mels).clone()
+    old = lib.swx_debug_flags(-1)
+    try:
+        lib.swx_debug_flags(old | 128)
+        ref = eng.cross_kv(xa).clone()
+        lib.swx_debug_flags(old & ~128)
+        got1 = eng.cross_kv(xa).clone()
+        eng.cross_kv(eng.encode(_mel(m.dims.n_mels, 132, B=windows).cuda().contiguous()))      # other contents in between
+        got2 = eng.cross_kv(xa).clone()
+    finally:
+        lib.swx_debug_flags(old)
+    assert ref.numel() > 0 and int((ref != 0).sum()) > ref.numel() // 2
+    assert torch.equal(ref, got1), int((ref != got1).sum())
+    assert torch.equal(ref, got2), int((ref != got2).sum())
+
+
 @pytest.mark.parametrize("name,windows", [("tiny.en", 1), ("base.en", 2), ("base.en", 5)])
 def test_encoder_f16_v_transposed_by_the_qkv_epilogue_is_bit_identical(name, windows):
     # round 6: at few windows the encoder's Q | K | V projection stores V transposed per head from its own epilogue (EPI_QKV_VT, incl.
