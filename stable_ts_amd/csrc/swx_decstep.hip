@@ -91,6 +91,21 @@ __global__ __launch_bounds__(64 * WPB) void gemm_dec_f16(DecGemmArgs g)
     // ---- activation tile -> LDS by LDS-DMA; instruction q writes LDS bytes [q*1024, q*1024 + 1024)
     {
         constexpr int n_instr = (MT * 16 * SPR) >> 6;      // = MT * NKS, a multiple of 4
+        if constexpr (WPB == 1) {
+            // single-wave workgroups (few rows): only the instructions that hold a row below M -- the 5 rows of a sequential window are 13 of
+            // the tile's 40 KB; rows past M stay whatever LDS held (their results are never stored: an MFMA output column depends on its
+            // own row only).  A run-time loop: no instruction sits under a branch of its own
+            const int rows_here = g.M - r0 < MT * 16 ? g.M - r0 : MT * 16;
+            const int n_need = g.w1_full_tile ? n_instr : (rows_here * SPR + 63) >> 6;
+            for (int q = 0; q < n_need; ++q) {
+                const int p = q * 64 + lane;
+                const int row = p / SPR, ps = p - row * SPR;
+                const int kslot = ps ^ (row & 15);
+                const int gr = r0 + row < g.M ? r0 + row : g.M - 1;
+                const f16 *src = g.A + (size_t)gr * g.lda + k0 + kslot * 8;
+                __builtin_amdgcn_global_load_lds(src, (lds_void *)(smem + q * 1024), 16, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int j = 0; j < n_instr / WPB; ++j) {
             const int q = j * WPB + dwave;
@@ -100,6 +115,7 @@ __global__ __launch_bounds__(64 * WPB) void gemm_dec_f16(DecGemmArgs g)
             const int gr = r0 + row < g.M ? r0 + row : g.M - 1;
             const f16 *src = g.A + (size_t)gr * g.lda + k0 + kslot * 8;
             __builtin_amdgcn_global_load_lds(src, (lds_void *)(smem + q * 1024), 16, 0, 0);
+        }
         }
     }
     // ---- weights of this wave's 16 columns: every fragment of the slice in flight at once (HBM, or L2 behind a sibling).
@@ -685,6 +701,7 @@ int swx_gemm_dec(DecGemmArgs g, hipStream_t s)
     // spread over four times as many CUs (gemm_dec_f16<.., WPB = 1>; bit-identical; SWX_FLAG_DEC_NO_W1: A/B)
     const bool w1 = mt == 1 && !ticket && units * g.n_rg <= 80 && !(swx_flags() & SWX_FLAG_DEC_NO_W1);
     const int grid1 = cdiv(units * 4, 8) * g.n_rg * 8;
+    g.w1_full_tile = (swx_flags() & SWX_FLAG_DEC_W1_FULL_TILE) ? 1 : 0;
     {   // (profiler scopes must not nest: each one closes the most recent record)
     SwxProfScope prof(PC_GEMM_SKINNY, 2.0 * ((double)g.N * g.K + (double)g.M * g.K) + (double)g.M * g.N * 2, s);
     // the epilogues the decoder step uses (compile-time): QKV, out-projections, cross-q, MLP-in, MLP-out (split / un-split)

@@ -81,6 +81,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_SELFATTN_NO_MQ 256       // multi-token self-attention: one wave per (row, token, head) reading K / V from L2 (rounds 1-5) instead of 4-8 tokens per workgroup from LDS (A/B; bit-identical)
 #define SWX_FLAG_FLASH_NO_QB1 64           // f16 flash attention of launches with <= 256 workgroups at 32 queries per wave: 32 queries per wave (rounds 3-5) instead of 16 (A/B; bit-identical)
 #define SWX_FLAG_XKV_PACK_SEPARATE 128     // cross-K/V: the fragment-ordered copy by its own launch (swx_xkv_pack, rounds 2-5) instead of by the projection's epilogue (A/B; the same bytes)
+#define SWX_FLAG_DEC_W1_FULL_TILE 256     // single-wave dec GEMM workgroups: DMA all 16 rows of the activation tile (rows past M clamped) instead of the rows that exist (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
@@ -124,6 +125,7 @@ struct DecGemmArgs {
                                          // kernel that keeps the weights in registers and walks 16-row tiles (same arithmetic per element)
     int tps;                             // launcher (tall kernel): 16-row tiles per workgroup; n_rg = row splits
     DecPrefetch pf;                      // cache prefetch of the NEXT projection's weights (pf.base == null: none)
+    int w1_full_tile;               // single-wave workgroups: stage the whole 16-row tile although fewer rows exist (A/B: SWX_FLAG_DEC_W1_FULL_TILE)
 };
 #define SWX_DEC_TICKETS 4096
 int swx_dec_plan(int M, int N, int K, int epi, int *mt, int *ks2);    // <0: shape not supported by this generation
