@@ -507,15 +507,18 @@ __device__ __forceinline__ void attn_decode_cross_body(const AttnArgs &a)
         constexpr int kslice = FQ * 32, SPR = kslice >> 3, RS = kslice * 2;
         const int li = lane & 15, lg = lane >> 4;
         const int row0 = b * a.q_rows_per_batch;
-        // residual tile -> LDS (rows past the stream's end are clamped: their results are never read)
-#pragma unroll
-        for (int j = 0; j < FQ / 4; ++j) {
-            const int qi = j * 4 + wave;
-            const int p = qi * 64 + lane;
-            const int row = p / SPR, ps = p - row * SPR;
-            const int kslot = ps ^ (row & 15);
-            const int gr = row0 + row < a.fq_rows ? row0 + row : a.fq_rows - 1;
-            __builtin_amdgcn_global_load_lds(a.fq_x + (size_t)gr * a.fq_ldx + kslot * 8, (lds_void *)(fq_smem + qi * 1024), 16, 0, 0);
+        // residual tile -> LDS: only the instructions that hold one of the window's nq rows (5 beams = 13 of the 16-row tile's FQ = 40; round 6:
+        // the tile was 40 KB of the ~590 KB a workgroup pulls through its CU).  Rows past nq stay whatever LDS held: their projections are
+        // never read (qok below).  A run-time loop: no instruction under a branch of its own; a.fq_full_tile (A/B) stages all 16 rows
+        {
+            const int n_need = a.fq_full_tile ? FQ : (a.nq * SPR + 63) >> 6;
+            for (int qi = wave; qi < n_need; qi += 4) {
+                const int p = qi * 64 + lane;
+                const int row = p / SPR, ps = p - row * SPR;
+                const int kslot = ps ^ (row & 15);
+                const int gr = row0 + row < a.fq_rows ? row0 + row : a.fq_rows - 1;
+                __builtin_amdgcn_global_load_lds(a.fq_x + (size_t)gr * a.fq_ldx + kslot * 8, (lds_void *)(fq_smem + qi * 1024), 16, 0, 0);
+            }
         }
         const f16 *wp = a.fq_w + ((size_t)(h * 4 + wave) * FQ) * 512 + lane * 8;
         f16x8 wf[FQ];
@@ -1614,8 +1617,9 @@ static bool f32_flash_ready(bool vt, bool split)
     return state[dev][v] > 0;
 }
 
-int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
+int swx_attention(int dtype, const AttnArgs &a_in, int force_kernel, hipStream_t s)
 {
+    const AttnArgs &a = a_in;
     if (a.B <= 0 || a.nq <= 0 || a.nk <= 0) return 0;
     if (a.nk > RW_MAXK) return -5;
     const bool flash = (dtype == SWX_F16) && (force_kernel == 2 || (force_kernel >= 4 && force_kernel <= 6) || (force_kernel == 0 && a.nq >= 32));
@@ -1640,6 +1644,8 @@ int swx_attention(int dtype, const AttnArgs &a, int force_kernel, hipStream_t s)
         const bool r5_loop = (swx_flags() & SWX_FLAG_XATTN_R5) != 0;                    // one key block per wave in flight (A/B)
         if (packed && a.fq_w && qg == 1 && a.nq <= 16) {
             // fused query projection: + [16][K] residual tile, statistics, q tile in dynamic LDS
+            AttnArgs a = a_in;
+            a.fq_full_tile = (swx_flags() & SWX_FLAG_XQ_FULL_TILE) ? 1 : 0;
             const int fq = a.fq_k / 32;
             const size_t lds = (size_t)16 * a.fq_k * 2 + 16 * sizeof(float2) + 16 * DH * 2;
 

@@ -82,6 +82,7 @@ int swx_gemm_plan_f16(int M, int N, int K, int epi, int64_t ldc, int64_t ldr, bo
 #define SWX_FLAG_FLASH_NO_QB1 64           // f16 flash attention of launches with <= 256 workgroups at 32 queries per wave: 32 queries per wave (rounds 3-5) instead of 16 (A/B; bit-identical)
 #define SWX_FLAG_XKV_PACK_SEPARATE 128     // cross-K/V: the fragment-ordered copy by its own launch (swx_xkv_pack, rounds 2-5) instead of by the projection's epilogue (A/B; the same bytes)
 #define SWX_FLAG_DEC_W1_FULL_TILE 256     // single-wave dec GEMM workgroups: DMA all 16 rows of the activation tile (rows past M clamped) instead of the rows that exist (A/B; bit-identical)
+#define SWX_FLAG_XQ_FULL_TILE 512          // decode cross-attention's fused query projection: DMA all 16 rows of the residual tile instead of the window's nq rows (A/B; bit-identical)
 #define SWX_FLAG_NO_BIG_TILE 131072   // tiled GEMM: never the 256 x 256 kernel (A/B; results are bit-identical)
 #define SWX_DEFAULT_FLAGS 0
 int swx_flags();
@@ -180,6 +181,7 @@ struct AttnArgs {
     const _Float16 *fq_x; int64_t fq_ldx; int fq_rows;      // residual stream [fq_rows][d]; window b owns rows b * q_rows_per_batch ..
     const _Float16 *fq_w; const float *fq_c1, *fq_c2; int fq_k;   // packed folded weights [d][fq_k], column constants
     const void *fq_pf; int fq_pf_lines;                     // weights to touch for the NEXT projection (cache prefetch), or null
+    int fq_full_tile;                                       // A/B (SWX_FLAG_XQ_FULL_TILE): stage all 16 rows of the residual tile, not only the nq that exist
 };
 // fragment-ordered copy of one layer's cross K / V^T for the decode-step cross-attention: per (window, head)
 // [K: blocks of 32 keys x 4 fragments x 64 lanes x 8 halfs | V^T: the same], zero padded past nk
