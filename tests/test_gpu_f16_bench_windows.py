@@ -52,6 +52,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADS = ((7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6))   # large-v3's
 WINDOWS = (0, 7, 19)            # tests/test_gpu_batch_invariance.py::ALONE
+# SWX_BENCH_WINDOWS=all (or "3,4,5"): the same cases on other windows of the timed recording -- ~50 s of oracle decoding per window, so
+# the suite keeps the three; the sweep over all 20 is run once per round by hand (profiles/r06_bench_windows_all20_report.json)
+if os.environ.get("SWX_BENCH_WINDOWS"):
+    WINDOWS = tuple(range(20)) if os.environ["SWX_BENCH_WINDOWS"] == "all" else tuple(int(x) for x in os.environ["SWX_BENCH_WINDOWS"].split(","))
 DTYPES = ("f16", "f32")
 STEPS, BEAM = 112, 5
 # strict mode: per-token |delta log p| against the oracle, (max, mean).  Measured on the three windows (profiles/r06_bench_windows_report.json,
