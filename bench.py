@@ -20,7 +20,8 @@ Default mode (``--mode transcribe``): one "step" = one full pass of model.transc
 ``--mode sharded`` = BASELINE.json configs[4]'s shape: ONE recording of world x minutes scattered by 30-s window over the ranks
   (parallel.transcribe_sharded), segments gathered and regrouped on rank 0 inside the timed pass.
 ``--model base.en --minutes 0.5 --batch 1 --beam 1`` = configs[1] (one window, greedy): ``latency_ms_per_window``.
-``--minutes 60 --batch 120`` = one GPU's share of the 8-h / 8-GPU job at the batch size that amortises the decode-step launches.
+``--minutes 60 --batch 120`` = one GPU's share of the 8-h / 8-GPU job at the batch size that amortises the decode-step launches
+  (at any N; the DEFAULT per-GPU workload is configs[2] at every N, so that the per-N values form one weak-scaling curve).
 ``--spans K`` = the reference-exact sequential algorithm on K spans in lockstep (spans.py); ``--sequential`` = the default
   transcribe() (one window per pass).  ``--debug-flags`` = the library's A/B switches (16384 no graph replay, 32768 no prefetch).
 Weak scaling: every rank processes its own recording; value = N * K * seconds / max-over-ranks wall time.  The default
@@ -109,7 +110,7 @@ def main():
     ap.add_argument("--mode", default="transcribe", choices=["transcribe", "align", "sharded"])
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--minutes", type=float, default=None, help="audio per GPU (default 10 for transcribe, 30 for align)")
-    ap.add_argument("--batch", type=int, default=None, help="windows per GPU batch (default 20; 120 when --gpus > 1, see --minutes)")
+    ap.add_argument("--batch", type=int, default=None, help="windows per GPU batch (default 20 at every N)")
     ap.add_argument("--host-audio", action="store_true", help="hand transcribe() the recording as a HOST tensor, as the reference's "
                     "callers do (the default keeps it resident in HBM, as the bench contract asks): the PCIe-inclusive rate")
     ap.add_argument("--beam", type=int, default=5)
@@ -147,14 +148,15 @@ def main():
                     "boundary: wall ms per stage (host share of the pass) under \"phase_ms\"; not part of `value`")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="hard cap (s) on the CPU-baseline leg")
     args = ap.parse_args()
-    # N = 1: BASELINE.json configs[2] (10 min, 20 windows in one batch).  N > 1: one GPU's share of configs[4] (8 h over 8 GPUs =
-    # 60 min per GPU) at the batch size that amortises the decode-step launches (120 windows: 1 903x per GPU in round 3 against
-    # 1 376x at 20) -- weak scaling, every rank transcribes its own 60 minutes; compare with `bench.py --minutes 60 --batch 120` at N = 1.
-    multi = args.gpus > 1 and args.mode == "transcribe"
+    # Every N runs the SAME per-GPU workload -- BASELINE.json configs[2]: 10 min, 20 windows in one batch, per rank -- so that the
+    # values at N = 1, 2, 4, 8 are one weak-scaling curve (per-GPU work fixed as N grows; rounds 3-5 switched N > 1 to 60 min at
+    # 120 windows per batch, which made value(N) / (N x value(1)) compare two workloads).  One GPU's share of configs[4] (8 h over
+    # 8 GPUs = 60 min per GPU, at the batch size that amortises the decode-step launches: ~2 020x per GPU against ~1 460x at 20) is
+    # `--minutes 60 --batch 120`, at any N.
     if args.minutes is None:
-        args.minutes = 30.0 if args.mode == "align" else (60.0 if multi else 10.0)
+        args.minutes = 30.0 if args.mode == "align" else 10.0
     if args.batch is None:
-        args.batch = 120 if multi else 20
+        args.batch = 20
 
     import stable_ts_amd as sw
     from stable_ts_amd import parallel as par
