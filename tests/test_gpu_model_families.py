@@ -116,9 +116,12 @@ def _same_prefix(a, b):
     return n
 
 
-@pytest.mark.parametrize("beam", [False, True])
+@pytest.mark.parametrize("case", ["greedy", "beam", "score"])
 @pytest.mark.parametrize("name", NAMES)            # (the decorator next to the function is the OUTER loop: one model build per family)
-def test_family_decode_strict_f32_identical_tokens(name, beam):
+def test_family_strict_f32_vs_oracle(name, case):
+    if case == "score":
+        return _score_alignment_dtw_strict(name)
+    beam = case == "beam"
     _drop(name)
     _product_table_agrees(name)
     m, eng = _oracle(name), _engine(name, "f32")
@@ -138,8 +141,7 @@ def test_family_decode_strict_f32_identical_tokens(name, beam):
     assert abs(out["no_speech_prob"][0] - res.no_speech_prob) < 1e-4 + 1e-2 * res.no_speech_prob
 
 
-@pytest.mark.parametrize("name", NAMES)
-def test_family_score_alignment_dtw_strict(name):
+def _score_alignment_dtw_strict(name):
     _drop(name)
     m, eng = _oracle(name), _engine(name, "f32")
     tok = get_tokenizer(m.is_multilingual, num_languages=m.num_languages, language="en", task="transcribe")
