@@ -217,3 +217,25 @@ def test_family_transcribe_end_to_end_turbo():
     assert all(0.0 <= w.start <= w.end <= 65.0 + 1e-6 for w in words)
     starts = [s.start for s in res.segments]
     assert starts == sorted(starts)
+
+
+def test_family_sequential_transcribe_and_align_end_to_end_medium():
+    """the reference's OWN control flow (model.transcribe(audio): one window per decode call, seek from the last timestamp, prompt carried
+    over -- original_whisper.py:492-710) and model.align() (alignment.py:396-429) on the d = 1024 family: five-row launches of the
+    single-wave dec GEMMs at K = 1024, the long-context self-attention behind a carried-over prompt, one window per encoder pass"""
+    import bench
+    import stable_ts_amd as sw
+    _CACHE.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
+    model = sw.load_model("medium", device="cuda:0", weights="random")
+    audio = bench.synth_audio(75.0, seed=4)
+    res = model.transcribe(audio, language="en", temperature=0.0, beam_size=5, sample_len=32, min_tokens=32, word_timestamps=True,
+                           logprob_threshold=None, compression_ratio_threshold=None, no_speech_threshold=None)
+    assert all(0.0 <= w.start <= w.end <= 75.0 + 1e-6 for w in res.all_words())
+    assert [s.start for s in res.segments] == sorted(s.start for s in res.segments)
+    text = torch.randint(18, 50000, (60,), generator=torch.Generator().manual_seed(9)).tolist()
+    al = model.align(audio, text, language="en", token_step=40)
+    words = al.all_words()
+    assert len(words) >= 10 and all(0.0 <= w.start <= w.end <= 75.0 + 1e-6 for w in words)
+    assert sum(len(w.tokens) for w in words) == len(text)
